@@ -1,0 +1,161 @@
+/*
+ * zopfli_amd — MI355X-native drop-in for the LZ77 optimal-parse hot path of
+ * google/zopfli.  C ABI of libzopfli_amd.so.
+ *
+ * Part 1 is the reference's own public surface (same names, same struct
+ * layout, same ownership rules), so existing callers of libzopfli — the CLI
+ * (zopfli_bin.c:112), the cgo binding (go/zopfli/zopfli.go:46) and zopflipng's
+ * CustomPNGDeflate (zopflipng_lib.cc:60) — link against this library unchanged.
+ *
+ * Part 2 is the thin device layer the host code calls into ("zmx_*"): plain
+ * pointers and sizes, opaque handles, int status (0 = ok), no exceptions.
+ * Each entry point names the reference function whose work it replaces.
+ * There is no CPU fallback: every zmx_* call fails (non-zero) and the
+ * Zopfli* calls abort with a message if no gfx950 device is usable.
+ */
+#ifndef ZOPFLI_AMD_H_
+#define ZOPFLI_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ Part 1 */
+
+/* reference: src/zopfli/zopfli.h:33-64 (six ints, this order) */
+typedef struct ZopfliOptions {
+  int verbose;
+  int verbose_more;
+  int numiterations;
+  int blocksplitting;
+  int blocksplittinglast; /* unused, kept for layout compatibility */
+  int blocksplittingmax;
+} ZopfliOptions;
+
+/* reference: src/zopfli/zopfli.h:70-74 */
+typedef enum {
+  ZOPFLI_FORMAT_GZIP,
+  ZOPFLI_FORMAT_ZLIB,
+  ZOPFLI_FORMAT_DEFLATE
+} ZopfliFormat;
+
+/* reference: src/zopfli/util.c:28 — numiterations 15, blocksplitting 1, max 15 */
+void ZopfliInitOptions(ZopfliOptions* options);
+
+/* reference: src/zopfli/zopfli_lib.c:28.  Appends to the malloc'ed array
+ * (*out, *outsize); caller frees.  Capacity keeps the reference's
+ * power-of-two invariant (util.h:135-155) so callers may keep appending. */
+void ZopfliCompress(const ZopfliOptions* options, ZopfliFormat output_type,
+                    const unsigned char* in, size_t insize,
+                    unsigned char** out, size_t* outsize);
+
+/* reference: src/zopfli/deflate.c:908 (deflate.h:58).  `bp` = bits already used
+ * in the last output byte (0..7), carried between calls. */
+void ZopfliDeflate(const ZopfliOptions* options, int btype, int final,
+                   const unsigned char* in, size_t insize,
+                   unsigned char* bp, unsigned char** out, size_t* outsize);
+
+/* reference: src/zopfli/deflate.c:811 (deflate.h:67).  Reads only
+ * in[max(0,instart-32768) .. inend). */
+void ZopfliDeflatePart(const ZopfliOptions* options, int btype, int final,
+                       const unsigned char* in, size_t instart, size_t inend,
+                       unsigned char* bp, unsigned char** out, size_t* outsize);
+
+/* reference: src/zopfli/gzip_container.c:84 */
+void ZopfliGzipCompress(const ZopfliOptions* options,
+                        const unsigned char* in, size_t insize,
+                        unsigned char** out, size_t* outsize);
+
+/* reference: src/zopfli/zlib_container.c:50 */
+void ZopfliZlibCompress(const ZopfliOptions* options,
+                        const unsigned char* in, size_t insize,
+                        unsigned char** out, size_t* outsize);
+
+/* ------------------------------------------------------------------ Part 2 */
+
+typedef struct zmx_ctx zmx_ctx;       /* one HIP device + stream + resident input */
+typedef struct zmx_tables zmx_tables; /* match tables + LZ77 stores of a batch of blocks */
+
+/* One deflate block: bytes [instart, inend) of the resident input.  Matches may
+ * reach back to max(0, instart-32768) and never extend past inend
+ * (lz77.c:551-552, squeeze.c:229-230). */
+typedef struct zmx_block {
+  uint64_t instart;
+  uint64_t inend;
+} zmx_block;
+
+#define ZMX_NUM_LL 288
+#define ZMX_NUM_D 32
+#define ZMX_HIST (ZMX_NUM_LL + ZMX_NUM_D) /* litlen bins then dist bins */
+
+int zmx_device_count(void);
+const char* zmx_last_error(void);
+
+int zmx_ctx_create(int device, zmx_ctx** ctx);
+void zmx_ctx_destroy(zmx_ctx* ctx);
+
+/* Copies the whole input to HBM once; every later call works on that copy. */
+int zmx_set_input(zmx_ctx* ctx, const unsigned char* in, size_t insize);
+
+/* Kernel A.  For every block: the static hash arrays (hash.c:100-137 val/same/
+ * prev links as pure functions of the data and inend) and, for every position,
+ * the result of ZopfliFindLongestMatch(limit 258, sublen) (lz77.c:407-542):
+ * longest length, its distance and the sublen step function.  Replaces the
+ * hash replay + longest-match cache (cache.c) of the reference. */
+int zmx_tables_build(zmx_ctx* ctx, const zmx_block* blocks, size_t nblocks, zmx_tables** tables);
+void zmx_tables_free(zmx_ctx* ctx, zmx_tables* tables);
+
+/* ZopfliLZ77Greedy (lz77.c:544-630) on every block, into store slot `slot`
+ * (0 or 1).  nsym[b] = symbols emitted, hist[b*ZMX_HIST..] = their histogram
+ * (litlen bins 0..287 then dist bins 0..31, end symbol not counted). */
+int zmx_lz77_greedy(zmx_ctx* ctx, zmx_tables* tables, int slot, uint32_t* nsym, uint32_t* hist);
+
+/* One LZ77OptimalRun (squeeze.c:429): GetBestLengths (:217) forward DP with the
+ * given per-block cost model, TraceBackwards (:317), FollowPath (:338).
+ * cost[b*ZMX_HIST..] = ll_symbols[288] then d_symbols[32] in bits, mincost[b] =
+ * GetCostModelMinCost (:163).  slot[b] selects the store written for block b. */
+int zmx_squeeze_run(zmx_ctx* ctx, zmx_tables* tables, const double* cost, const double* mincost,
+                    const int32_t* slot, uint32_t* nsym, uint32_t* hist);
+
+/* Copies store `slot` of block `block` (nsym entries) to the host: litlens[i] is
+ * a literal byte when dists[i]==0, else a match length (lz77.h:44-49). */
+int zmx_store_download(zmx_ctx* ctx, zmx_tables* tables, size_t block, int slot,
+                       uint16_t* litlens, uint16_t* dists, size_t nsym);
+
+/* Parity probe: the ZopfliFindLongestMatch result for one position of one
+ * block, expanded to the reference's sublen[259] convention. */
+int zmx_find_longest_match(zmx_ctx* ctx, zmx_tables* tables, size_t block, size_t pos,
+                           uint16_t* sublen, uint16_t* distance, uint16_t* length);
+
+/* Parity probe: length_array[0..blocksize] of the last zmx_squeeze_run. */
+int zmx_length_array_download(zmx_ctx* ctx, zmx_tables* tables, size_t block, uint16_t* out);
+
+/* -------- whole-stream entry points on a resident input (bench, multi-GPU) */
+
+/* ZopfliDeflate of master blocks [first_mb, last_mb) of the resident input
+ * (master block = 1 000 000 bytes, util.h:60), serialised as position
+ * independent bit chunks; see zmx_chunks_merge.  `final` marks the very last
+ * block of the stream.  *blob is malloc'ed; caller frees. */
+int zmx_deflate_master_blocks(zmx_ctx* ctx, const ZopfliOptions* options, size_t first_mb,
+                              size_t last_mb, int final, unsigned char** blob, size_t* blobsize);
+
+/* Concatenates chunk blobs (in stream order) into a deflate bit stream appended
+ * to (*out,*outsize) at bit pointer *bp, exactly as consecutive
+ * ZopfliDeflatePart calls would. */
+int zmx_chunks_merge(const unsigned char* const* blobs, const size_t* blobsizes, size_t nblobs,
+                     const unsigned char* in, unsigned char* bp, unsigned char** out, size_t* outsize);
+
+/* Timing breakdown of the last Zopfli* / zmx_deflate_master_blocks call on this
+ * thread: seconds spent in [0] match tables [1] greedy [2] squeeze runs
+ * [3] host cost model [4] block split [5] encode [6] kernel-only squeeze time
+ * (HIP events) [7] squeeze launches.  For bench.py's roofline object. */
+int zmx_last_timing(double* out8);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* ZOPFLI_AMD_H_ */

@@ -1,0 +1,124 @@
+// TEST-ONLY implementation of the zmx_* device layer on top of oracle/.
+//
+// Linked (by tests/hostlib/Makefile) with the product's host sources into
+// tests/_build/libzopfli_hosttest.so so that the host logic (block splitter,
+// block cost model, iteration control, encoder, containers) can be checked
+// against the real reference on machines without a GPU.  The product library
+// libzopfli_amd.so never links this file: its zmx_* symbols come from the HIP
+// device layer only.
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "zopfli_amd.h"
+extern "C" {
+#include "zopfli_oracle.h"
+}
+
+struct zmx_ctx {
+  std::vector<unsigned char> input;
+};
+
+struct BlockData {
+  zmx_block blk;
+  zo_table* table = nullptr;
+  std::vector<uint16_t> litlens[2], dists[2];
+  size_t nsym[2] = {0, 0};
+  std::vector<uint16_t> length_array;
+};
+
+struct zmx_tables {
+  std::vector<BlockData> blocks;
+};
+
+static std::string g_err;
+
+extern "C" {
+
+int zmx_device_count(void) { return 1; }
+const char* zmx_last_error(void) { return g_err.c_str(); }
+
+int zmx_ctx_create(int, zmx_ctx** ctx) {
+  *ctx = new zmx_ctx();
+  return 0;
+}
+void zmx_ctx_destroy(zmx_ctx* ctx) { delete ctx; }
+
+int zmx_set_input(zmx_ctx* ctx, const unsigned char* in, size_t insize) {
+  ctx->input.assign(in, in + insize);
+  return 0;
+}
+size_t zmx_internal_input_size(zmx_ctx* ctx) { return ctx->input.size(); }
+void zmx_internal_kernel_stats(double* a, double* b, int) { *a = 0; *b = 0; }
+
+int zmx_tables_build(zmx_ctx* ctx, const zmx_block* blocks, size_t nblocks, zmx_tables** tables) {
+  zmx_tables* t = new zmx_tables();
+  t->blocks.resize(nblocks);
+  for (size_t b = 0; b < nblocks; ++b) {
+    BlockData& d = t->blocks[b];
+    d.blk = blocks[b];
+    d.table = zo_table_build(ctx->input.data(), blocks[b].instart, blocks[b].inend);
+    const size_t B = blocks[b].inend - blocks[b].instart;
+    for (int s = 0; s < 2; ++s) {
+      d.litlens[s].resize(B + 1);
+      d.dists[s].resize(B + 1);
+    }
+    d.length_array.resize(B + 1);
+  }
+  *tables = t;
+  return 0;
+}
+
+void zmx_tables_free(zmx_ctx*, zmx_tables* t) {
+  if (!t) return;
+  for (auto& d : t->blocks) zo_table_free(d.table);
+  delete t;
+}
+
+int zmx_lz77_greedy(zmx_ctx*, zmx_tables* t, int slot, uint32_t* nsym, uint32_t* hist) {
+  for (size_t b = 0; b < t->blocks.size(); ++b) {
+    BlockData& d = t->blocks[b];
+    d.nsym[slot] = zo_greedy(d.table, d.litlens[slot].data(), d.dists[slot].data());
+    nsym[b] = static_cast<uint32_t>(d.nsym[slot]);
+    zo_histogram(d.litlens[slot].data(), d.dists[slot].data(), d.nsym[slot], hist + b * ZMX_HIST);
+  }
+  return 0;
+}
+
+int zmx_squeeze_run(zmx_ctx*, zmx_tables* t, const double* cost, const double* mincost, const int32_t* slot,
+                    uint32_t* nsym, uint32_t* hist) {
+  for (size_t b = 0; b < t->blocks.size(); ++b) {
+    BlockData& d = t->blocks[b];
+    const int s = slot[b];
+    const double* ll = cost + b * ZMX_HIST;
+    zo_get_best_lengths(d.table, ll, ll + ZMX_NUM_LL, mincost[b], d.length_array.data());
+    d.nsym[s] = zo_trace_follow(d.table, d.length_array.data(), d.litlens[s].data(), d.dists[s].data());
+    nsym[b] = static_cast<uint32_t>(d.nsym[s]);
+    zo_histogram(d.litlens[s].data(), d.dists[s].data(), d.nsym[s], hist + b * ZMX_HIST);
+  }
+  return 0;
+}
+
+int zmx_store_download(zmx_ctx*, zmx_tables* t, size_t block, int slot, uint16_t* litlens, uint16_t* dists,
+                       size_t nsym) {
+  BlockData& d = t->blocks[block];
+  if (nsym > d.nsym[slot]) return -1;
+  std::memcpy(litlens, d.litlens[slot].data(), nsym * 2);
+  std::memcpy(dists, d.dists[slot].data(), nsym * 2);
+  return 0;
+}
+
+int zmx_find_longest_match(zmx_ctx*, zmx_tables* t, size_t block, size_t pos, uint16_t* sublen,
+                           uint16_t* distance, uint16_t* length) {
+  zo_find_longest_match(t->blocks[block].table, pos, sublen, distance, length);
+  return 0;
+}
+
+int zmx_length_array_download(zmx_ctx*, zmx_tables* t, size_t block, uint16_t* out) {
+  const auto& la = t->blocks[block].length_array;
+  std::memcpy(out, la.data(), la.size() * 2);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,296 @@
+// C ABI of libzopfli_amd.so, part 1: the reference's public surface
+// (zopfli.h:67,86; deflate.h:58,67; gzip_container.h:42; zlib_container.h:42),
+// plus the resident-input stream entry points used by bench.py and by the
+// multi-GPU gather.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "deflate.h"
+#include "lz77_optimal.h"
+#include "symbols.h"
+#include "zopfli_amd.h"
+
+// implemented by the device layer: kernel-only seconds / launches of the squeeze kernel
+extern "C" void zmx_internal_kernel_stats(double* squeeze_seconds, double* squeeze_launches, int reset);
+// implemented by the device layer: size of the resident input
+extern "C" size_t zmx_internal_input_size(zmx_ctx* ctx);
+
+namespace {
+
+using zamd::kMasterBlock;
+
+std::mutex g_mutex;       // one request at a time on the shared context
+zmx_ctx* g_ctx = nullptr;
+
+[[noreturn]] void Die(const char* what) {
+  std::fprintf(stderr, "zopfli_amd: %s: %s\n", what, zmx_last_error());
+  std::exit(EXIT_FAILURE);
+}
+
+// The context the Zopfli* entry points run on: device ZOPFLI_AMD_DEVICE, else
+// LOCAL_RANK (one process per GPU under torchrun), else 0.
+zmx_ctx* SharedContext() {
+  if (g_ctx) return g_ctx;
+  int device = 0;
+  if (const char* e = std::getenv("ZOPFLI_AMD_DEVICE")) device = std::atoi(e);
+  else if (const char* r = std::getenv("LOCAL_RANK")) device = std::atoi(r);
+  if (zmx_ctx_create(device, &g_ctx) != 0) Die("no usable gfx950 device (there is no CPU fallback)");
+  return g_ctx;
+}
+
+size_t PartsPerBatch() {
+  static const size_t n = [] {
+    if (const char* e = std::getenv("ZOPFLI_AMD_PARTS_PER_BATCH")) {
+      const long v = std::atol(e);
+      if (v > 0) return static_cast<size_t>(v);
+    }
+    return static_cast<size_t>(256);  // ~40 MB of tables per 1 MB master block
+  }();
+  return n;
+}
+
+std::vector<zamd::Part> MasterBlocks(size_t insize, size_t first_mb, size_t last_mb, bool final) {
+  // deflate.c:916-923: do { ... } while (i < insize), so an empty input still
+  // yields one (empty) part.
+  std::vector<zamd::Part> parts;
+  size_t i = 0, mb = 0;
+  do {
+    const bool masterfinal = i + kMasterBlock >= insize;
+    const size_t size = masterfinal ? insize - i : kMasterBlock;
+    if (mb >= first_mb && mb < last_mb) parts.push_back({i, i + size, final && masterfinal});
+    i += size;
+    ++mb;
+  } while (i < insize);
+  return parts;
+}
+
+int RunParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const std::vector<zamd::Part>& parts,
+             std::vector<zamd::Chunk>* chunks) {
+  const size_t step = PartsPerBatch();
+  for (size_t a = 0; a < parts.size(); a += step) {
+    const size_t b = a + step < parts.size() ? a + step : parts.size();
+    std::vector<zamd::Part> group(parts.begin() + a, parts.begin() + b);
+    const int rc = zamd::DeflateParts(ctx, options, btype, group, chunks);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+// Appends merged chunks at (*out, *outsize, *bp), reference conventions.
+void EmitChunks(const std::vector<zamd::Chunk>& chunks, const unsigned char* in, unsigned char* bp,
+                unsigned char** out, size_t* outsize) {
+  zamd::BitStream bs;
+  bs.bp = *bp & 7;
+  if (bs.bp != 0 && *outsize > 0) bs.bytes.push_back((*out)[*outsize - 1]);
+  else bs.bp = 0;
+  const bool shared_byte = !bs.bytes.empty();
+  zamd::MergeChunks(chunks, in, &bs);
+  if (shared_byte) {
+    (*out)[*outsize - 1] = bs.bytes[0];
+    zamd::AppendToOutput(bs.bytes.data() + 1, bs.bytes.size() - 1, out, outsize);
+  } else {
+    zamd::AppendToOutput(bs.bytes.data(), bs.bytes.size(), out, outsize);
+  }
+  *bp = static_cast<unsigned char>(bs.bp);
+}
+
+void ResetTiming() {
+  zamd::ThreadTiming() = zamd::Timing();
+  double a, b;
+  zmx_internal_kernel_stats(&a, &b, 1);
+}
+
+void PushByte(unsigned v, unsigned char** out, size_t* outsize) {
+  const uint8_t b = static_cast<uint8_t>(v);
+  zamd::AppendToOutput(&b, 1, out, outsize);
+}
+
+// CRC-32 (poly 0xedb88320), slicing-by-8; same value as gzip_container.c:75.
+uint32_t Crc32(const unsigned char* data, size_t size) {
+  static uint32_t table[8][256];
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+      table[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i) {
+      for (int t = 1; t < 8; ++t) table[t][i] = table[0][table[t - 1][i] & 255] ^ (table[t - 1][i] >> 8);
+    }
+  });
+  uint32_t c = 0xffffffffu;
+  while (size >= 8) {
+    uint32_t lo, hi;
+    std::memcpy(&lo, data, 4);
+    std::memcpy(&hi, data + 4, 4);
+    lo ^= c;
+    c = table[7][lo & 255] ^ table[6][(lo >> 8) & 255] ^ table[5][(lo >> 16) & 255] ^ table[4][lo >> 24] ^
+        table[3][hi & 255] ^ table[2][(hi >> 8) & 255] ^ table[1][(hi >> 16) & 255] ^ table[0][hi >> 24];
+    data += 8;
+    size -= 8;
+  }
+  for (; size; --size) c = table[0][(c ^ *data++) & 255] ^ (c >> 8);
+  return c ^ 0xffffffffu;
+}
+
+// Adler-32 (zlib_container.c:29)
+uint32_t Adler32(const unsigned char* data, size_t size) {
+  uint32_t s1 = 1, s2 = 0;
+  while (size > 0) {
+    size_t n = size > 5550 ? 5550 : size;
+    size -= n;
+    for (; n; --n) {
+      s1 += *data++;
+      s2 += s1;
+    }
+    s1 %= 65521;
+    s2 %= 65521;
+  }
+  return (s2 << 16) | s1;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ZopfliInitOptions(ZopfliOptions* options) {
+  options->verbose = 0;
+  options->verbose_more = 0;
+  options->numiterations = 15;
+  options->blocksplitting = 1;
+  options->blocksplittinglast = 0;
+  options->blocksplittingmax = 15;
+}
+
+void ZopfliDeflatePart(const ZopfliOptions* options, int btype, int final, const unsigned char* in,
+                       size_t instart, size_t inend, unsigned char* bp, unsigned char** out,
+                       size_t* outsize) {
+  std::lock_guard<std::mutex> lock(g_mutex);
+  zmx_ctx* ctx = SharedContext();
+  ResetTiming();
+  // only in[windowstart, inend) is read (lz77.c:551-552); make that the resident input
+  const size_t base = instart > zamd::kWindow ? instart - zamd::kWindow : 0;
+  if (zmx_set_input(ctx, in + base, inend - base) != 0) Die("zmx_set_input");
+  std::vector<zamd::Part> parts{{instart - base, inend - base, final != 0}};
+  std::vector<zamd::Chunk> chunks;
+  if (RunParts(ctx, *options, btype, parts, &chunks) != 0) Die("device error");
+  EmitChunks(chunks, in + base, bp, out, outsize);
+}
+
+void ZopfliDeflate(const ZopfliOptions* options, int btype, int final, const unsigned char* in,
+                   size_t insize, unsigned char* bp, unsigned char** out, size_t* outsize) {
+  const size_t offset = *outsize;
+  {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    zmx_ctx* ctx = SharedContext();
+    ResetTiming();
+    if (zmx_set_input(ctx, in, insize) != 0) Die("zmx_set_input");
+    const std::vector<zamd::Part> parts = MasterBlocks(insize, 0, static_cast<size_t>(-1), final != 0);
+    std::vector<zamd::Chunk> chunks;
+    if (RunParts(ctx, *options, btype, parts, &chunks) != 0) Die("device error");
+    EmitChunks(chunks, in, bp, out, outsize);
+  }
+  if (options->verbose) {
+    std::fprintf(stderr, "Original Size: %lu, Deflate: %lu, Compression: %f%% Removed\n",
+                 static_cast<unsigned long>(insize), static_cast<unsigned long>(*outsize - offset),
+                 100.0 * static_cast<double>(insize - (*outsize - offset)) / static_cast<double>(insize));
+  }
+}
+
+void ZopfliGzipCompress(const ZopfliOptions* options, const unsigned char* in, size_t insize,
+                        unsigned char** out, size_t* outsize) {
+  // the checksum does not depend on the device work: overlap it
+  uint32_t crc = 0;
+  std::thread crc_thread([&] { crc = Crc32(in, insize); });
+  unsigned char bp = 0;
+  static const unsigned char header[10] = {31, 139, 8, 0, 0, 0, 0, 0, 2, 3};  // gzip_container.c:90-101
+  zamd::AppendToOutput(header, 10, out, outsize);
+  ZopfliDeflate(options, 2, 1, in, insize, &bp, out, outsize);
+  crc_thread.join();
+  for (int i = 0; i < 4; ++i) PushByte((crc >> (8 * i)) & 255, out, outsize);
+  for (int i = 0; i < 4; ++i) PushByte((insize >> (8 * i)) & 255, out, outsize);
+  if (options->verbose) {
+    std::fprintf(stderr, "Original Size: %d, Gzip: %d, Compression: %f%% Removed\n", static_cast<int>(insize),
+                 static_cast<int>(*outsize), 100.0 * static_cast<double>(insize - *outsize) / static_cast<double>(insize));
+  }
+}
+
+void ZopfliZlibCompress(const ZopfliOptions* options, const unsigned char* in, size_t insize,
+                        unsigned char** out, size_t* outsize) {
+  uint32_t checksum = 0;
+  // the reference truncates the size to unsigned here (zlib_container.c:54)
+  std::thread sum_thread([&] { checksum = Adler32(in, static_cast<unsigned>(insize)); });
+  unsigned char bp = 0;
+  const unsigned cmf = 120, flevel = 3, fdict = 0;  // CM 8, CINFO 7
+  unsigned cmfflg = 256 * cmf + fdict * 32 + flevel * 64;
+  cmfflg += 31 - cmfflg % 31;
+  PushByte(cmfflg / 256, out, outsize);
+  PushByte(cmfflg % 256, out, outsize);
+  ZopfliDeflate(options, 2, 1, in, insize, &bp, out, outsize);
+  sum_thread.join();
+  for (int i = 3; i >= 0; --i) PushByte((checksum >> (8 * i)) & 255, out, outsize);
+  if (options->verbose) {
+    std::fprintf(stderr, "Original Size: %d, Zlib: %d, Compression: %f%% Removed\n", static_cast<int>(insize),
+                 static_cast<int>(*outsize), 100.0 * static_cast<double>(insize - *outsize) / static_cast<double>(insize));
+  }
+}
+
+void ZopfliCompress(const ZopfliOptions* options, ZopfliFormat output_type, const unsigned char* in,
+                    size_t insize, unsigned char** out, size_t* outsize) {
+  if (output_type == ZOPFLI_FORMAT_GZIP) {
+    ZopfliGzipCompress(options, in, insize, out, outsize);
+  } else if (output_type == ZOPFLI_FORMAT_ZLIB) {
+    ZopfliZlibCompress(options, in, insize, out, outsize);
+  } else if (output_type == ZOPFLI_FORMAT_DEFLATE) {
+    unsigned char bp = 0;
+    ZopfliDeflate(options, 2, 1, in, insize, &bp, out, outsize);
+  } else {
+    std::fprintf(stderr, "zopfli_amd: invalid ZopfliFormat %d\n", static_cast<int>(output_type));
+    std::abort();  // the reference asserts (zopfli_lib.c:40)
+  }
+}
+
+int zmx_deflate_master_blocks(zmx_ctx* ctx, const ZopfliOptions* options, size_t first_mb, size_t last_mb,
+                              int final, unsigned char** blob, size_t* blobsize) {
+  ResetTiming();
+  const size_t insize = zmx_internal_input_size(ctx);
+  const std::vector<zamd::Part> parts = MasterBlocks(insize, first_mb, last_mb, final != 0);
+  std::vector<zamd::Chunk> chunks;
+  const int rc = RunParts(ctx, *options, 2, parts, &chunks);
+  if (rc) return rc;
+  const std::vector<uint8_t> v = zamd::SerializeChunks(chunks);
+  *blob = static_cast<unsigned char*>(std::malloc(v.size() ? v.size() : 1));
+  if (!*blob) return -1;
+  std::memcpy(*blob, v.data(), v.size());
+  *blobsize = v.size();
+  return 0;
+}
+
+int zmx_chunks_merge(const unsigned char* const* blobs, const size_t* blobsizes, size_t nblobs,
+                     const unsigned char* in, unsigned char* bp, unsigned char** out, size_t* outsize) {
+  std::vector<zamd::Chunk> chunks;
+  for (size_t i = 0; i < nblobs; ++i) {
+    if (!zamd::DeserializeChunks(blobs[i], blobsizes[i], &chunks)) return -1;
+  }
+  EmitChunks(chunks, in, bp, out, outsize);
+  return 0;
+}
+
+int zmx_last_timing(double* out8) {
+  const zamd::Timing& t = zamd::ThreadTiming();
+  out8[0] = t.tables;
+  out8[1] = t.greedy;
+  out8[2] = t.squeeze;
+  out8[3] = t.cost_model;
+  out8[4] = t.split;
+  out8[5] = t.encode;
+  zmx_internal_kernel_stats(&out8[6], &out8[7], 0);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,48 @@
+// Deflate driver: master blocks -> block split -> optimal parse (device) ->
+// second split attempt -> block type choice -> bit chunks.
+//
+// Same decisions as ZopfliDeflatePart / AddLZ77BlockAutoType of the reference
+// (deflate.c:811-906, :747-800), reorganised so that every device call is
+// batched over all master blocks of a request and every host step is a
+// parallel loop over independent master blocks.  Compressed blocks are
+// produced as position-independent bit chunks; only stored blocks depend on
+// the running bit pointer, so they are materialised at merge time.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "bit_writer.h"
+#include "zopfli_amd.h"
+
+namespace zamd {
+
+struct Chunk {
+  enum Kind : uint8_t { kBits = 0, kStored = 1 };
+  Kind kind = kBits;
+  bool final_block = false;     // kStored only: BFINAL of its last piece
+  std::vector<uint8_t> bits;    // kBits: packed from bit 0
+  size_t nbits = 0;
+  size_t start = 0, end = 0;    // kStored: raw input range
+};
+
+struct Part {
+  size_t instart, inend;
+  bool final_part;  // last deflate block of this part carries BFINAL
+};
+
+// Compresses each part independently (one ZopfliDeflatePart each); chunks come
+// out in stream order.  Positions refer to the input resident in `ctx`.
+int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const std::vector<Part>& parts,
+                 std::vector<Chunk>* chunks);
+
+// Appends chunks to a (bytes, bp) stream; `in` is the base of the resident input.
+void MergeChunks(const std::vector<Chunk>& chunks, const unsigned char* in, BitStream* stream);
+
+std::vector<uint8_t> SerializeChunks(const std::vector<Chunk>& chunks);
+bool DeserializeChunks(const unsigned char* blob, size_t size, std::vector<Chunk>* chunks);
+
+// Appends `n` bytes to a reference-style growable array (util.h:135-155).
+void AppendToOutput(const uint8_t* data, size_t n, unsigned char** out, size_t* outsize);
+
+}  // namespace zamd

@@ -1,0 +1,38 @@
+// Host-side iteration control of the optimal parse, batched over blocks.
+//
+// The device runs the O(bytes x iterations) work (match tables, greedy parse,
+// squeeze DP, traceback, follow-path, histograms); everything here is the
+// cheap, order-sensitive control flow the reference keeps per block in
+// ZopfliLZ77Optimal (squeeze.c:446-526): statistics, libm entropy, exact block
+// cost, best-so-far tracking and the RNG perturbation.  All blocks of a batch
+// advance in lock-step, one device launch per iteration.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "zopfli_amd.h"
+
+namespace zamd {
+
+struct SymbolRun {
+  std::vector<uint16_t> litlens, dists;  // lz77.h:44-49 convention
+};
+
+struct Timing {
+  double tables = 0, greedy = 0, squeeze = 0, cost_model = 0, split = 0, encode = 0;
+};
+Timing& ThreadTiming();
+
+// ZopfliLZ77Greedy (lz77.c:544) for each block.
+int Lz77GreedyBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks, std::vector<SymbolRun>* out);
+
+// ZopfliLZ77Optimal (squeeze.c:446) for each block: best of `numiterations`
+// cost-model iterations seeded by a greedy parse.
+int Lz77OptimalBatch(zmx_ctx* ctx, const ZopfliOptions& options, const std::vector<zmx_block>& blocks,
+                     std::vector<SymbolRun>* out);
+
+// ZopfliLZ77OptimalFixed (squeeze.c:528): one DP run with the fixed-tree costs.
+int Lz77OptimalFixedBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks,
+                          std::vector<SymbolRun>* out);
+
+}  // namespace zamd

@@ -1,0 +1,253 @@
+"""bench.py — zopfli hot path on MI355X.
+
+One step = one pass of the hot path over the workload: ZopfliCompress(gzip) semantics on an
+input that is already resident in HBM (H2D is outside the timed region), i.e. match tables,
+greedy seeds, numiterations squeeze runs, host cost model, block choice, encoding, merge.
+
+Workload at N=1 (BASELINE.json configs[1]): 100 000 000 bytes of the seeded text-like class T
+(enwik8 stand-in), numiterations=15, blocksplitting=0 (one deflate block per 1 MB
+master block).  At N>1 every rank compresses its own 100 MB shard of an N x 100 MB input
+(weak scaling): the shards are consecutive ranges of master blocks of ONE stream, rank r works
+on master blocks [100 r, 100 r + 100) with the preceding 32 KiB as dictionary, the chunk blobs
+are gathered to rank 0 over RCCL and merged into one gzip stream.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import gzip
+import hashlib
+import json
+import os
+import sys
+import threading
+import time
+import zlib
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MB = 1000000
+WINDOW = 32768
+
+
+def crc32_combine(crc1, crc2, len2):
+    """zlib's crc32_combine (GF(2) matrix method)."""
+    def times(mat, vec):
+        s, i = 0, 0
+        while vec:
+            if vec & 1:
+                s ^= mat[i]
+            vec >>= 1
+            i += 1
+        return s
+
+    def square(mat):
+        return [times(mat, mat[n]) for n in range(32)]
+
+    if len2 <= 0:
+        return crc1
+    odd = [0xedb88320] + [1 << n for n in range(31)]
+    even = square(odd)
+    odd = square(even)
+    while True:
+        even = square(odd)
+        if len2 & 1:
+            crc1 = times(even, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+        odd = square(even)
+        if len2 & 1:
+            crc1 = times(odd, crc1)
+        len2 >>= 1
+        if not len2:
+            break
+    return crc1 ^ crc2
+
+
+def cpu_baseline(sample, options):
+    """The real reference (oracle/_ref, -O3 -DNDEBUG) on one host core, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    if not ol.have_ref():
+        return None
+    t0 = time.perf_counter()
+    out = ol.ref_compress(sample, 0, options.numiterations, options.blocksplitting, options.blocksplittingmax)
+    dt = time.perf_counter() - t0
+    return {"value": round(len(sample) / MB / dt, 4), "unit": "MB/s", "cores": 1, "kind": "reference",
+            "sample": f"first {len(sample)} bytes of the workload, same ZopfliOptions, gzip, "
+                      f"oracle/_ref/libzopfli_ref.so (gcc -O3 -DNDEBUG), {dt:.1f} s, {len(out)} bytes out"}, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=100 * MB, help="bytes per GPU (default: the 100 MB workload)")
+    ap.add_argument("--blocksplitting", type=int, default=0, help="0 = configs[1] (default), 1 = configs[2]")
+    ap.add_argument("--numiterations", type=int, default=15)
+    ap.add_argument("--cpu-sample", type=int, default=8 * MB)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    import torch
+    import torch.distributed as dist
+
+    from zopfli_amd import Context, ZopfliOptions, api, generate
+
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
+
+    lib = api.library()
+    options = ZopfliOptions(args.numiterations, args.blocksplitting, 15)
+    size = args.size
+    assert size % MB == 0 or world == 1, "shards must be whole master blocks"
+
+    # ---- synthetic input: shard r = class T, seed 1 + r
+    shard = generate("T", size, seed=1 + rank)
+    prefix = b""
+    if rank > 0:
+        prefix = generate("T", size, seed=rank)[-WINDOW:]  # tail of the previous shard = dictionary
+    resident = prefix + shard
+    ctx = Context(local_rank, lib)
+    ctx.set_input(resident)  # H2D, outside the timed region
+    instart, inend = len(prefix), len(resident)
+    final = 1 if rank == world - 1 else 0
+    header = bytes([31, 139, 8, 0, 0, 0, 0, 0, 2, 3])
+
+    def gather_blobs(blob):
+        if world == 1:
+            return [blob]
+        n = torch.tensor([len(blob)], dtype=torch.int64, device=device)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+        dist.all_gather(sizes, n)
+        cap = int(max(int(s.item()) for s in sizes))
+        buf = torch.zeros(cap, dtype=torch.uint8, device=device)
+        buf[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+        out = [torch.empty(cap, dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
+        dist.gather(buf, out, dst=0)
+        if rank != 0:
+            return None
+        return [out[r][:int(sizes[r].item())].cpu().numpy().tobytes() for r in range(world)]
+
+    def gather_crc(crc):
+        if world == 1:
+            return [crc]
+        t = torch.tensor([crc], dtype=torch.int64, device=device)
+        outs = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+        dist.all_gather(outs, t)
+        return [int(o.item()) for o in outs]
+
+    timing_acc = {}
+
+    def step():
+        crc_box = [0]
+        th = threading.Thread(target=lambda: crc_box.__setitem__(0, zlib.crc32(shard)))
+        th.start()  # the checksum does not depend on the device work
+        blob = ctx.deflate_range(options, instart, inend, final)
+        for k, v in api.last_timing(lib).items():
+            timing_acc[k] = timing_acc.get(k, 0.0) + v
+        th.join()
+        blobs = gather_blobs(blob)
+        crcs = gather_crc(crc_box[0])
+        if rank != 0:
+            return None
+        stream = ctx.merge(blobs, header)
+        crc = crcs[0]
+        for c in crcs[1:]:
+            crc = crc32_combine(crc, c, size)
+        total = size * world
+        return stream + crc.to_bytes(4, "little") + (total & 0xffffffff).to_bytes(4, "little")
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timing_acc.clear()
+    sync()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        total = size * world
+        ms = dt / args.steps * 1e3
+        value = total / MB / (dt / args.steps)
+        # ---- correctness of the measured output (outside the timed region)
+        bitexact = None
+        roundtrip = None
+        if world == 1:
+            roundtrip = gzip.decompress(out) == shard
+            sha = hashlib.sha256(out).hexdigest()
+            for name in ("vectors_big.json", "vectors.json"):
+                p = os.path.join(ROOT, "tests", "golden", name)
+                if os.path.exists(p):
+                    for c in json.load(open(p)):
+                        if (c["input"].get("cls") == "T" and c["input"].get("seed") in (None, 1)
+                                and c["insize"] == size and c["format"] == 0
+                                and c["numiterations"] == args.numiterations
+                                and c["blocksplitting"] == args.blocksplitting and c["blocksplittingmax"] == 15):
+                            bitexact = (sha == c["sha256"])
+        else:
+            d = zlib.decompressobj(31)
+            n = len(d.decompress(out)) + len(d.flush())
+            roundtrip = (n == total)
+        # ---- roofline of the dominant kernel (k_squeeze): algorithmic bytes = 31 B per position
+        #      per launch (28 B match record + 1 B literal + 2 B length_array)
+        launches = timing_acc.get("squeeze_launches", 0.0)
+        ksec = timing_acc.get("squeeze_kernel", 0.0)
+        roofline = None
+        if launches > 0 and ksec > 0:
+            per_launch_bytes = 31.0 * size
+            achieved = per_launch_bytes / (ksec / launches) / 1e9
+            roofline = {"bound": "hbm", "kernel": "k_squeeze", "achieved": round(achieved, 3), "peak": 8000.0,
+                        "unit": "GB/s", "frac": round(achieved / 8000.0, 6), "traffic": None,
+                        "avg_launch_ms": round(ksec / launches * 1e3, 3), "launches_per_step": launches / args.steps}
+        line = {
+            "metric": "input MB/s at numiterations=15 (gzip, bit-exact vs reference)",
+            "value": round(value, 4), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 (f32/f64 cost DP)", "data": "synthetic",
+            "config": {"workload": f"class-T text-like {size} B per GPU (enwik8 stand-in), numiterations="
+                                   f"{args.numiterations}, blocksplitting={args.blocksplitting}, gzip, "
+                                   f"{'configs[1]' if args.blocksplitting == 0 else 'configs[2]'}",
+                       "total_bytes": total, "master_blocks": (total + MB - 1) // MB,
+                       "sharding": "master blocks, contiguous per rank, RCCL gather of bit chunks"},
+            "output_bytes": len(out), "roundtrip_ok": roundtrip, "bitexact_vs_reference": bitexact,
+            "roofline": roofline,
+            "breakdown_s_per_step": {k: round(v / args.steps, 4) for k, v in timing_acc.items()
+                                     if k != "squeeze_launches"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sample = shard[:min(args.cpu_sample, size)]
+            res = cpu_baseline(sample, options)
+            if res:
+                line["cpu_baseline"] = res[0]
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -135,20 +135,24 @@ int zmx_length_array_download(zmx_ctx* ctx, zmx_tables* tables, size_t block, ui
 
 /* -------- whole-stream entry points on a resident input (bench, multi-GPU) */
 
-/* ZopfliDeflate of master blocks [first_mb, last_mb) of the resident input
- * (master block = 1 000 000 bytes, util.h:60), serialised as position
- * independent bit chunks; see zmx_chunks_merge.  `final` marks the very last
- * block of the stream.  *blob is malloc'ed; caller frees. */
-int zmx_deflate_master_blocks(zmx_ctx* ctx, const ZopfliOptions* options, size_t first_mb,
-                              size_t last_mb, int final, unsigned char** blob, size_t* blobsize);
+/* ZopfliDeflate (deflate.c:908) of bytes [instart, inend) of the resident input,
+ * cut into 1 000 000-byte master blocks counted from instart (util.h:60), bytes
+ * before instart serving as dictionary — i.e. the consecutive ZopfliDeflatePart
+ * calls of deflate.c:916-923 for that range.  The result is serialised as
+ * position-independent chunks (compressed blocks as bit strings, stored blocks
+ * as raw bytes) so that ranges compressed on different GPUs can be joined by
+ * zmx_chunks_merge.  `final` marks the last block of the range as BFINAL.
+ * *blob is malloc'ed; caller frees. */
+int zmx_deflate_range(zmx_ctx* ctx, const ZopfliOptions* options, size_t instart, size_t inend,
+                      int final, unsigned char** blob, size_t* blobsize);
 
 /* Concatenates chunk blobs (in stream order) into a deflate bit stream appended
- * to (*out,*outsize) at bit pointer *bp, exactly as consecutive
- * ZopfliDeflatePart calls would. */
+ * to (*out,*outsize) at bit pointer *bp, exactly as the consecutive
+ * ZopfliDeflatePart calls would have produced it. */
 int zmx_chunks_merge(const unsigned char* const* blobs, const size_t* blobsizes, size_t nblobs,
-                     const unsigned char* in, unsigned char* bp, unsigned char** out, size_t* outsize);
+                     unsigned char* bp, unsigned char** out, size_t* outsize);
 
-/* Timing breakdown of the last Zopfli* / zmx_deflate_master_blocks call on this
+/* Timing breakdown of the last Zopfli* / zmx_deflate_range call on this
  * thread: seconds spent in [0] match tables [1] greedy [2] squeeze runs
  * [3] host cost model [4] block split [5] encode [6] kernel-only squeeze time
  * (HIP events) [7] squeeze launches.  For bench.py's roofline object. */

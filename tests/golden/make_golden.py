@@ -1,0 +1,90 @@
+"""Generates tests/golden/vectors.json from the REAL reference (oracle/_ref/libzopfli_ref.so,
+compiled from /root/reference by oracle/Makefile).  Run in the build container:
+
+    python tests/golden/make_golden.py [--big]
+
+Each vector: synthetic class / size / seed (zopfli_amd.datagen) or a literal input, the
+ZopfliOptions used, the format, and the SHA-256 + length of the reference's output.
+--big adds the bench workloads (20 MB and 100 MB, minutes of CPU each)."""
+import hashlib
+import json
+import multiprocessing as mp
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+LITERALS = {
+    "empty": b"",
+    "a": b"a",
+    "gotest": b"compressthis" + b"_foobar" * 1000 + b"$",  # go/zopfli/zopfli_test.go:37
+    "zeros300k": bytes(300000),
+}
+
+
+def make_input(spec):
+    from zopfli_amd import generate
+    if spec["kind"] == "literal":
+        return LITERALS[spec["name"]]
+    return generate(spec["cls"], spec["size"], spec.get("seed"))
+
+
+def run(case):
+    import oracle_lib as ol
+    data = make_input(case["input"])
+    out = ol.ref_compress(data, case["format"], case["numiterations"], case["blocksplitting"],
+                          case["blocksplittingmax"])
+    case = dict(case)
+    case["sha256"] = hashlib.sha256(out).hexdigest()
+    case["outsize"] = len(out)
+    case["insize"] = len(data)
+    return case
+
+
+def cases(big):
+    cs = []
+
+    def add(inp, fmt=0, n=15, split=1, smax=15):
+        cs.append({"input": inp, "format": fmt, "numiterations": n, "blocksplitting": split,
+                   "blocksplittingmax": smax})
+
+    for name in LITERALS:
+        for fmt in (0, 1, 2):
+            add({"kind": "literal", "name": name}, fmt)
+    add({"kind": "class", "cls": "T", "size": 65536}, 0, 1)  # BASELINE config 1
+    for cls in "TXRZBPM":
+        add({"kind": "class", "cls": cls, "size": 65536})
+        add({"kind": "class", "cls": cls, "size": 65536}, 2, 5, 0)
+    for cls in "TXRZ":
+        add({"kind": "class", "cls": cls, "size": 1000000})
+        add({"kind": "class", "cls": cls, "size": 1000000}, 0, 15, 0)
+    add({"kind": "class", "cls": "B", "size": 200000})
+    add({"kind": "class", "cls": "M", "size": 2500000})
+    add({"kind": "class", "cls": "T", "size": 4000000})
+    add({"kind": "class", "cls": "T", "size": 4000000}, 0, 15, 0)
+    if big:
+        add({"kind": "class", "cls": "T", "size": 20000000}, 0, 15, 0)
+        add({"kind": "class", "cls": "T", "size": 20000000})
+        add({"kind": "class", "cls": "T", "size": 100000000}, 0, 15, 0)  # BASELINE config 2
+        add({"kind": "class", "cls": "T", "size": 100000000})             # BASELINE config 3
+    return cs
+
+
+def main():
+    big = "--big" in sys.argv
+    path = os.path.join(HERE, "vectors_big.json" if big else "vectors.json")
+    cs = cases(big)
+    if big:
+        cs = [c for c in cs if c["input"].get("size", 0) >= 20000000]
+    with mp.Pool(min(8, len(cs))) as pool:
+        done = pool.map(run, cs, chunksize=1)
+    with open(path, "w") as f:
+        json.dump(done, f, indent=1)
+    print("wrote", path, len(done), "vectors")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,179 @@
+"""Parity of the HIP kernels against the CPU oracle / the real reference, through the C ABI of
+libzopfli_amd.so on a real MI355X.  Bit-exact: everything on this path is integer work or
+IEEE double/float arithmetic in a fixed order (no tolerance)."""
+import gzip
+import hashlib
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from zopfli_amd import ZopfliOptions, api, generate
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "vectors.json")
+
+# (class, total size, blocks [(instart, inend), ...])
+TABLE_CASES = [
+    ("T", 70000, [(0, 70000)]),
+    ("X", 50000, [(0, 20000), (20000, 50000)]),
+    ("Z", 90000, [(0, 45001), (45001, 90000)]),        # runs crossing a block end
+    ("B", 40000, [(0, 40000)]),                        # chain cap + hash switch
+    ("R", 30000, [(0, 30000)]),
+    ("P", 66000, [(33000, 66000)]),                    # window before instart
+    ("M", 150000, [(0, 3), (3, 5), (5, 5), (5, 100000), (100000, 150000)]),  # tiny / empty blocks
+]
+
+
+def _ids(c):
+    return f"{c[0]}{c[1]}x{len(c[2])}"
+
+
+def _first_diff(a, b):
+    n = min(len(a), len(b))
+    idx = np.nonzero(np.asarray(a[:n]) != np.asarray(b[:n]))[0]
+    return int(idx[0]) if len(idx) else n
+
+
+@pytest.mark.parametrize("case", TABLE_CASES, ids=_ids)
+def test_match_table(gpu_ctx, case):
+    """k_same + k_chain + k_match == ZopfliFindLongestMatch at every position (lz77.c:407)."""
+    cls, n, blocks = case
+    data = generate(cls, n)
+    gpu_ctx.set_input(data)
+    t = gpu_ctx.build_tables(blocks)
+    try:
+        for b, (s, e) in enumerate(blocks):
+            o = ol.OracleTable(data, s, e)
+            bad = []
+            for pos in range(s, e):
+                gl, gd, gsub = t.find_longest_match(b, pos)
+                ol_, od, osub = o.find_longest_match(pos)
+                same = (gl == ol_ and gd == od) if ol_ >= 3 else (gl < 3 and ol_ < 3)
+                if same and ol_ >= 3:
+                    same = np.array_equal(gsub[3:ol_ + 1], osub[3:ol_ + 1])
+                if not same:
+                    bad.append((pos, (gl, gd), (ol_, od)))
+                    if len(bad) >= 5:
+                        break
+            assert not bad, f"block {b} [{s},{e}): first mismatches (pos, gpu, oracle) {bad}"
+    finally:
+        t.free()
+
+
+@pytest.mark.parametrize("case", TABLE_CASES, ids=_ids)
+def test_greedy(gpu_ctx, case):
+    """k_greedy == ZopfliLZ77Greedy (lz77.c:544) + its histogram."""
+    cls, n, blocks = case
+    data = generate(cls, n)
+    gpu_ctx.set_input(data)
+    t = gpu_ctx.build_tables(blocks)
+    try:
+        nsym, hist = t.greedy(0)
+        for b, (s, e) in enumerate(blocks):
+            oll, odd = ol.OracleTable(data, s, e).greedy()
+            gll, gdd = t.store(b, 0, nsym[b])
+            assert nsym[b] == len(oll), f"block {b}: nsym {nsym[b]} vs {len(oll)}"
+            assert np.array_equal(gll, oll) and np.array_equal(gdd, odd), \
+                f"block {b}: first diff at symbol {min(_first_diff(gll, oll), _first_diff(gdd, odd))}"
+            assert np.array_equal(hist[b], ol.histogram(oll, odd)), f"block {b}: histogram"
+    finally:
+        t.free()
+
+
+@pytest.mark.parametrize("case", TABLE_CASES, ids=_ids)
+def test_squeeze_runs(gpu_ctx, case):
+    """k_squeeze == GetBestLengths + TraceBackwards + FollowPath (squeeze.c:217,317,338): three
+    chained runs (greedy statistics, then each run's own statistics) and one fixed-tree run."""
+    cls, n, blocks = case
+    data = generate(cls, n)
+    gpu_ctx.set_input(data)
+    t = gpu_ctx.build_tables(blocks)
+    try:
+        nb = len(blocks)
+        nsym, hist = t.greedy(0)
+        tables = [ol.OracleTable(data, s, e) for (s, e) in blocks]
+        fixed_ll = np.array([8] * 144 + [9] * 112 + [7] * 24 + [8] * 8, dtype=np.float64)
+        fixed_d = np.full(32, 5.0)
+        for it in range(4):
+            cost = np.zeros((nb, 320))
+            mincost = np.zeros(nb)
+            for b in range(nb):
+                if it == 3:
+                    ll, d = fixed_ll, fixed_d
+                else:
+                    ll, d = ol.entropy_costs(hist[b])
+                cost[b, :288], cost[b, 288:] = ll, d
+                mincost[b] = ol.model_min_cost(ll, d)
+            slot = np.full(nb, it & 1, dtype=np.int32)
+            nsym, hist = t.squeeze_run(cost, mincost, slot)
+            for b, (s, e) in enumerate(blocks):
+                la, oll, odd = tables[b].squeeze_run(cost[b, :288], cost[b, 288:], mincost[b])
+                if e > s:
+                    gla = t.length_array(b)
+                    assert np.array_equal(gla[1:], la[1:]), \
+                        f"iter {it} block {b}: length_array first diff at {1 + _first_diff(gla[1:], la[1:])}"
+                gll, gdd = t.store(b, it & 1, nsym[b])
+                assert nsym[b] == len(oll), f"iter {it} block {b}: nsym {nsym[b]} vs {len(oll)}"
+                assert np.array_equal(gll, oll) and np.array_equal(gdd, odd), f"iter {it} block {b}: store"
+                assert np.array_equal(hist[b], ol.histogram(oll, odd)), f"iter {it} block {b}: histogram"
+    finally:
+        t.free()
+
+
+def _golden(lo, hi):
+    with open(GOLDEN) as f:
+        return [c for c in json.load(f) if lo <= c["insize"] <= hi]
+
+
+def _input(spec):
+    if spec["kind"] == "literal":
+        from golden.make_golden import LITERALS
+        return LITERALS[spec["name"]]
+    return generate(spec["cls"], spec["size"], spec.get("seed"))
+
+
+def _gid(c):
+    return (f"{c['input'].get('name', c['input'].get('cls'))}-{c['insize']}-f{c['format']}-n{c['numiterations']}"
+            f"-s{c['blocksplitting']}")
+
+
+@pytest.mark.parametrize("case", _golden(0, 4000000), ids=_gid)
+def test_stream_golden(gpu_lib, case):
+    """ZopfliCompress through libzopfli_amd.so == the reference's bytes (SHA-256 of the output of
+    oracle/_ref, committed in tests/golden/vectors.json)."""
+    data = _input(case["input"])
+    opt = ZopfliOptions(case["numiterations"], case["blocksplitting"], case["blocksplittingmax"])
+    out = api.compress(data, case["format"], opt, lib=gpu_lib)
+    if case["format"] == 0:
+        assert gzip.decompress(out) == data
+    assert len(out) == case["outsize"]
+    assert hashlib.sha256(out).hexdigest() == case["sha256"]
+
+
+@pytest.mark.parametrize("btype", [0, 1, 2])
+def test_deflate_part_vs_reference(gpu_lib, btype):
+    """ZopfliDeflatePart with a dictionary, forced block types (deflate.c:811-842)."""
+    if not ol.have_ref():
+        pytest.skip("oracle/_ref not shipped")
+    data = generate("M", 90000)
+    a = api.deflate_part(data, 40000, 90000, btype, 1, ZopfliOptions(5), lib=gpu_lib)
+    b = ol.ref_deflate_part(data, 40000, 90000, btype, 1, 5)
+    assert a == b
+
+
+def test_full_size_round_trip(gpu_lib):
+    """BASELINE config-2 shape at 20 MB (20 master blocks, numiterations 15, blocksplitting 0):
+    round trip through zlib + the reference's SHA-256 when the big golden file is present."""
+    data = generate("T", 20000000)
+    out = api.compress(data, 0, ZopfliOptions(15, 0), lib=gpu_lib)
+    assert gzip.decompress(out) == data
+    big = os.path.join(os.path.dirname(__file__), "golden", "vectors_big.json")
+    if os.path.exists(big):
+        with open(big) as f:
+            for c in json.load(f):
+                if c["insize"] == 20000000 and c["blocksplitting"] == 0 and c["format"] == 0:
+                    assert hashlib.sha256(out).hexdigest() == c["sha256"]

@@ -1,0 +1,241 @@
+"""ctypes mirror of include/zopfli_amd.h (reference names and argument meaning)."""
+import ctypes
+import os
+
+from ._build import LIB
+
+FORMAT_GZIP, FORMAT_ZLIB, FORMAT_DEFLATE = 0, 1, 2  # zopfli.h:70-74
+ZMX_HIST = 320
+
+
+class ZopfliOptions(ctypes.Structure):
+    """zopfli.h:33-64; defaults as ZopfliInitOptions (util.c:28)."""
+    _fields_ = [("verbose", ctypes.c_int), ("verbose_more", ctypes.c_int), ("numiterations", ctypes.c_int),
+                ("blocksplitting", ctypes.c_int), ("blocksplittinglast", ctypes.c_int),
+                ("blocksplittingmax", ctypes.c_int)]
+
+    def __init__(self, numiterations=15, blocksplitting=1, blocksplittingmax=15, verbose=0, verbose_more=0):
+        super().__init__(verbose, verbose_more, numiterations, blocksplitting, 0, blocksplittingmax)
+
+
+class ZmxBlock(ctypes.Structure):
+    _fields_ = [("instart", ctypes.c_uint64), ("inend", ctypes.c_uint64)]
+
+
+_lib = None
+_libc = ctypes.CDLL(None)
+_libc.free.argtypes = [ctypes.c_void_p]
+_u8p = ctypes.POINTER(ctypes.c_ubyte)
+
+
+def bind(lib):
+    """Declares the prototypes of include/zopfli_amd.h on a loaded library."""
+    P, sz, vp = ctypes.POINTER, ctypes.c_size_t, ctypes.c_void_p
+    opt = P(ZopfliOptions)
+    lib.ZopfliInitOptions.argtypes = [opt]
+    lib.ZopfliInitOptions.restype = None
+    lib.ZopfliCompress.argtypes = [opt, ctypes.c_int, ctypes.c_char_p, sz, P(_u8p), P(sz)]
+    lib.ZopfliCompress.restype = None
+    for name in ("ZopfliGzipCompress", "ZopfliZlibCompress"):
+        f = getattr(lib, name)
+        f.argtypes = [opt, ctypes.c_char_p, sz, P(_u8p), P(sz)]
+        f.restype = None
+    lib.ZopfliDeflate.argtypes = [opt, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, sz, P(ctypes.c_ubyte), P(_u8p),
+                                  P(sz)]
+    lib.ZopfliDeflate.restype = None
+    lib.ZopfliDeflatePart.argtypes = [opt, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, sz, sz, P(ctypes.c_ubyte),
+                                      P(_u8p), P(sz)]
+    lib.ZopfliDeflatePart.restype = None
+    lib.zmx_device_count.restype = ctypes.c_int
+    lib.zmx_last_error.restype = ctypes.c_char_p
+    lib.zmx_ctx_create.argtypes = [ctypes.c_int, P(vp)]
+    lib.zmx_ctx_destroy.argtypes = [vp]
+    lib.zmx_ctx_destroy.restype = None
+    lib.zmx_set_input.argtypes = [vp, ctypes.c_char_p, sz]
+    lib.zmx_tables_build.argtypes = [vp, P(ZmxBlock), sz, P(vp)]
+    lib.zmx_tables_free.argtypes = [vp, vp]
+    lib.zmx_tables_free.restype = None
+    lib.zmx_lz77_greedy.argtypes = [vp, vp, ctypes.c_int, P(ctypes.c_uint32), P(ctypes.c_uint32)]
+    lib.zmx_squeeze_run.argtypes = [vp, vp, P(ctypes.c_double), P(ctypes.c_double), P(ctypes.c_int32),
+                                    P(ctypes.c_uint32), P(ctypes.c_uint32)]
+    lib.zmx_store_download.argtypes = [vp, vp, sz, ctypes.c_int, P(ctypes.c_uint16), P(ctypes.c_uint16), sz]
+    lib.zmx_find_longest_match.argtypes = [vp, vp, sz, sz, P(ctypes.c_uint16), P(ctypes.c_uint16),
+                                           P(ctypes.c_uint16)]
+    lib.zmx_length_array_download.argtypes = [vp, vp, sz, P(ctypes.c_uint16)]
+    lib.zmx_deflate_range.argtypes = [vp, opt, sz, sz, ctypes.c_int, P(_u8p), P(sz)]
+    lib.zmx_chunks_merge.argtypes = [P(ctypes.c_char_p), P(sz), sz, P(ctypes.c_ubyte), P(_u8p), P(sz)]
+    lib.zmx_last_timing.argtypes = [P(ctypes.c_double)]
+    return lib
+
+
+def library(path=None):
+    """Loads libzopfli_amd.so (built in-tree by __graft_entry__.build()).  No fallback."""
+    global _lib
+    if path is not None:
+        return bind(ctypes.CDLL(path))
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise RuntimeError(f"{LIB} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                               "zopfli_amd has no CPU fallback")
+        _lib = bind(ctypes.CDLL(LIB))
+    return _lib
+
+
+def _take(out, size):
+    data = ctypes.string_at(out, size.value)
+    _libc.free(out)
+    return data
+
+
+def compress(data, fmt=FORMAT_GZIP, options=None, lib=None):
+    """ZopfliCompress (zopfli_lib.c:28)."""
+    lib = lib or library()
+    options = options or ZopfliOptions()
+    out, size = _u8p(), ctypes.c_size_t(0)
+    lib.ZopfliCompress(ctypes.byref(options), fmt, data, len(data), ctypes.byref(out), ctypes.byref(size))
+    return _take(out, size)
+
+
+def deflate(data, btype=2, final=1, options=None, lib=None):
+    """ZopfliDeflate (deflate.c:908) from bp = 0; returns (bytes, bp)."""
+    lib = lib or library()
+    options = options or ZopfliOptions()
+    out, size, bp = _u8p(), ctypes.c_size_t(0), ctypes.c_ubyte(0)
+    lib.ZopfliDeflate(ctypes.byref(options), btype, final, data, len(data), ctypes.byref(bp), ctypes.byref(out),
+                      ctypes.byref(size))
+    return _take(out, size), bp.value
+
+
+def deflate_part(data, instart, inend, btype=2, final=1, options=None, lib=None):
+    """ZopfliDeflatePart (deflate.c:811) from bp = 0; returns (bytes, bp)."""
+    lib = lib or library()
+    options = options or ZopfliOptions()
+    out, size, bp = _u8p(), ctypes.c_size_t(0), ctypes.c_ubyte(0)
+    lib.ZopfliDeflatePart(ctypes.byref(options), btype, final, data, instart, inend, ctypes.byref(bp),
+                          ctypes.byref(out), ctypes.byref(size))
+    return _take(out, size), bp.value
+
+
+def last_timing(lib=None):
+    lib = lib or library()
+    t = (ctypes.c_double * 8)()
+    lib.zmx_last_timing(t)
+    keys = ["tables", "greedy", "squeeze", "cost_model", "split", "encode", "squeeze_kernel", "squeeze_launches"]
+    return dict(zip(keys, list(t)))
+
+
+class Context:
+    """The zmx_* device layer: one HIP device with a resident input."""
+
+    def __init__(self, device=0, lib=None):
+        self.lib = lib or library()
+        self.handle = ctypes.c_void_p()
+        self._input = None
+        if self.lib.zmx_ctx_create(device, ctypes.byref(self.handle)) != 0:
+            raise RuntimeError("zmx_ctx_create: " + self.error())
+
+    def error(self):
+        return (self.lib.zmx_last_error() or b"").decode()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self.error()}")
+
+    def close(self):
+        if self.handle:
+            self.lib.zmx_ctx_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def set_input(self, data):
+        self._input = data
+        self._check(self.lib.zmx_set_input(self.handle, data, len(data)), "zmx_set_input")
+
+    def build_tables(self, blocks):
+        arr = (ZmxBlock * len(blocks))(*[ZmxBlock(s, e) for s, e in blocks])
+        t = ctypes.c_void_p()
+        self._check(self.lib.zmx_tables_build(self.handle, arr, len(blocks), ctypes.byref(t)), "zmx_tables_build")
+        return Tables(self, t, list(blocks))
+
+    def deflate_range(self, options, instart, inend, final=1):
+        """zmx_deflate_range: serialised chunks of ZopfliDeflate over resident bytes [instart, inend)."""
+        blob, size = _u8p(), ctypes.c_size_t(0)
+        self._check(self.lib.zmx_deflate_range(self.handle, ctypes.byref(options), instart, inend, final,
+                                               ctypes.byref(blob), ctypes.byref(size)), "zmx_deflate_range")
+        return _take(blob, size)
+
+    def merge(self, blobs, prefix=b""):
+        """zmx_chunks_merge after `prefix` (e.g. a gzip header); returns prefix + deflate stream."""
+        n = len(blobs)
+        arr = (ctypes.c_char_p * n)(*blobs)
+        sizes = (ctypes.c_size_t * n)(*[len(b) for b in blobs])
+        out, size, bp = _u8p(), ctypes.c_size_t(0), ctypes.c_ubyte(0)
+        self._check(self.lib.zmx_chunks_merge(arr, sizes, n, ctypes.byref(bp), ctypes.byref(out),
+                                              ctypes.byref(size)), "zmx_chunks_merge")
+        return prefix + _take(out, size)
+
+
+class Tables:
+    def __init__(self, ctx, handle, blocks):
+        self.ctx, self.handle, self.blocks = ctx, handle, blocks
+
+    def free(self):
+        if self.handle:
+            self.ctx.lib.zmx_tables_free(self.ctx.handle, self.handle)
+            self.handle = None
+
+    def greedy(self, slot=0):
+        import numpy as np
+        nb = len(self.blocks)
+        nsym = np.zeros(nb, dtype=np.uint32)
+        hist = np.zeros((nb, ZMX_HIST), dtype=np.uint32)
+        self.ctx._check(self.ctx.lib.zmx_lz77_greedy(self.ctx.handle, self.handle, slot,
+                                                     nsym.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                                                     hist.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))),
+                        "zmx_lz77_greedy")
+        return nsym, hist
+
+    def squeeze_run(self, cost, mincost, slot):
+        import numpy as np
+        nb = len(self.blocks)
+        cost = np.ascontiguousarray(cost, dtype=np.float64)
+        mincost = np.ascontiguousarray(mincost, dtype=np.float64)
+        slot = np.ascontiguousarray(slot, dtype=np.int32)
+        nsym = np.zeros(nb, dtype=np.uint32)
+        hist = np.zeros((nb, ZMX_HIST), dtype=np.uint32)
+        self.ctx._check(self.ctx.lib.zmx_squeeze_run(self.ctx.handle, self.handle,
+                                                     cost.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                     mincost.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                     slot.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                                     nsym.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                                                     hist.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))),
+                        "zmx_squeeze_run")
+        return nsym, hist
+
+    def store(self, block, slot, nsym):
+        import numpy as np
+        ll = np.zeros(max(int(nsym), 1), dtype=np.uint16)
+        dd = np.zeros(max(int(nsym), 1), dtype=np.uint16)
+        self.ctx._check(self.ctx.lib.zmx_store_download(self.ctx.handle, self.handle, block, slot,
+                                                        ll.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)),
+                                                        dd.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), int(nsym)),
+                        "zmx_store_download")
+        return ll[:int(nsym)], dd[:int(nsym)]
+
+    def find_longest_match(self, block, pos):
+        import numpy as np
+        sub = np.zeros(259, dtype=np.uint16)
+        d, l = ctypes.c_uint16(0), ctypes.c_uint16(0)
+        self.ctx._check(self.ctx.lib.zmx_find_longest_match(self.ctx.handle, self.handle, block, pos,
+                                                            sub.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)),
+                                                            ctypes.byref(d), ctypes.byref(l)),
+                        "zmx_find_longest_match")
+        return l.value, d.value, sub
+
+    def length_array(self, block):
+        import numpy as np
+        s, e = self.blocks[block]
+        la = np.zeros(e - s + 1, dtype=np.uint16)
+        self.ctx._check(self.ctx.lib.zmx_length_array_download(self.ctx.handle, self.handle, block,
+                                                               la.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16))),
+                        "zmx_length_array_download")
+        return la

@@ -1,0 +1,428 @@
+// Device layer of libzopfli_amd.so (C ABI part 2 of include/zopfli_amd.h):
+// HBM residency, launch orchestration and the parity probes.  The kernels are
+// in zmx_kernels.h.  gfx950 only; there is no host fallback — every entry
+// point reports an error if the device or a launch fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "zmx_kernels.h"
+#include "zopfli_amd.h"
+
+namespace {
+
+std::string g_err;
+std::mutex g_stats_mutex;
+double g_squeeze_seconds = 0, g_squeeze_launches = 0;
+
+int Fail(const char* what, hipError_t e, const char* file, int line) {
+  char buf[512];
+  std::snprintf(buf, sizeof(buf), "%s: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+  g_err = buf;
+  return -1;
+}
+int FailMsg(const std::string& m) {
+  g_err = m;
+  return -1;
+}
+
+#define HIPCHK(expr)                                                  \
+  do {                                                                \
+    hipError_t e_ = (expr);                                           \
+    if (e_ != hipSuccess) return Fail(#expr, e_, __FILE__, __LINE__); \
+  } while (0)
+
+constexpr u32 kMatchGrid = 1024;  // persistent workgroups: 256 CUs x 4 (LDS-limited)
+constexpr size_t kInputPad = 4096;
+
+template <typename T>
+hipError_t DevAlloc(T** p, size_t n) {
+  return hipMalloc(reinterpret_cast<void**>(p), (n ? n : 1) * sizeof(T));
+}
+
+}  // namespace
+
+struct zmx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  u8* d_in = nullptr;
+  size_t insize = 0, in_cap = 0;
+  const unsigned char* h_in = nullptr;  // caller's buffer (borrowed until the next zmx_set_input)
+  u32* d_scratch = nullptr;  // k_match per-lane overflow change points
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+struct zmx_tables {
+  size_t nb = 0;
+  std::vector<BlockDesc> blocks;
+  std::vector<u32> bsize;
+  std::vector<u32> store_begin[2];  // first valid entry of each block's store slot
+  size_t total_b = 0, total_l = 0;
+  BlockDesc* d_blocks = nullptr;
+  u32* d_tile_off = nullptr;
+  u16* d_same16 = nullptr;
+  ushort4* d_links = nullptr;
+  u32* d_recs = nullptr;
+  u32* d_pool = nullptr;
+  u32 pool_cap = 0;
+  u16* d_la = nullptr;
+  u32* d_store[2] = {nullptr, nullptr};
+  u32* d_hist = nullptr;
+  u32* d_nsym = nullptr;
+  double* d_cost = nullptr;
+  double* d_mincost = nullptr;
+  int* d_slot = nullptr;
+  u32* d_counters = nullptr;  // 16 words, see MatchParams
+  u32* d_flags = nullptr;     // 4 words
+  // host cache for the parity probe
+  std::vector<std::vector<u32>> probe_recs;
+  std::vector<u32> probe_pool;
+  bool probe_pool_ready = false;
+};
+
+extern "C" {
+
+int zmx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* zmx_last_error(void) { return g_err.c_str(); }
+
+size_t zmx_internal_input_size(zmx_ctx* ctx) { return ctx->insize; }
+const unsigned char* zmx_internal_input_host(zmx_ctx* ctx) { return ctx->h_in; }
+
+void zmx_internal_kernel_stats(double* squeeze_seconds, double* squeeze_launches, int reset) {
+  std::lock_guard<std::mutex> lock(g_stats_mutex);
+  *squeeze_seconds = g_squeeze_seconds;
+  *squeeze_launches = g_squeeze_launches;
+  if (reset) g_squeeze_seconds = g_squeeze_launches = 0;
+}
+
+int zmx_ctx_create(int device, zmx_ctx** out) {
+  int n = 0;
+  HIPCHK(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) return FailMsg("zmx_ctx_create: no such HIP device");
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    return FailMsg(std::string("zmx_ctx_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+  }
+  zmx_ctx* c = new zmx_ctx();
+  c->device = device;
+  HIPCHK(hipStreamCreate(&c->stream));
+  HIPCHK(hipEventCreate(&c->ev0));
+  HIPCHK(hipEventCreate(&c->ev1));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             CH_LDS_BYTES));
+  *out = c;
+  return 0;
+}
+
+void zmx_ctx_destroy(zmx_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipFree(c->d_in);
+  (void)hipFree(c->d_scratch);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int zmx_set_input(zmx_ctx* c, const unsigned char* in, size_t insize) {
+  HIPCHK(hipSetDevice(c->device));
+  if (insize + kInputPad > c->in_cap) {
+    if (c->d_in) HIPCHK(hipFree(c->d_in));
+    c->d_in = nullptr;
+    c->in_cap = insize + kInputPad;
+    HIPCHK(DevAlloc(&c->d_in, c->in_cap));
+  }
+  if (insize) HIPCHK(hipMemcpyAsync(c->d_in, in, insize, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(c->d_in + insize, 0, kInputPad, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->insize = insize;
+  c->h_in = in;
+  return 0;
+}
+
+void zmx_tables_free(zmx_ctx* c, zmx_tables* t) {
+  if (!t) return;
+  if (c) (void)hipSetDevice(c->device);
+  (void)hipFree(t->d_blocks);
+  (void)hipFree(t->d_tile_off);
+  (void)hipFree(t->d_same16);
+  (void)hipFree(t->d_links);
+  (void)hipFree(t->d_recs);
+  (void)hipFree(t->d_pool);
+  (void)hipFree(t->d_la);
+  (void)hipFree(t->d_store[0]);
+  (void)hipFree(t->d_store[1]);
+  (void)hipFree(t->d_hist);
+  (void)hipFree(t->d_nsym);
+  (void)hipFree(t->d_cost);
+  (void)hipFree(t->d_mincost);
+  (void)hipFree(t->d_slot);
+  (void)hipFree(t->d_counters);
+  (void)hipFree(t->d_flags);
+  delete t;
+}
+
+static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_tables* t) {
+  t->nb = nb;
+  t->blocks.resize(nb);
+  t->bsize.resize(nb);
+  t->store_begin[0].assign(nb, 0);
+  t->store_begin[1].assign(nb, 0);
+  std::vector<u32> tile_off(nb + 1, 0);
+  u64 pos_off = 0, reg_off = 0, la_off = 0, max_l = 0;
+  for (size_t b = 0; b < nb; ++b) {
+    if (blocks[b].inend < blocks[b].instart || blocks[b].inend > c->insize) {
+      return FailMsg("zmx_tables_build: block outside the resident input");
+    }
+    BlockDesc& d = t->blocks[b];
+    d.instart = blocks[b].instart;
+    d.inend = blocks[b].inend;
+    d.ws = d.instart > ZMX_WINDOW ? d.instart - ZMX_WINDOW : 0;
+    d.pos_off = pos_off;
+    d.reg_off = reg_off;
+    d.la_off = la_off;
+    const u64 B = d.inend - d.instart, L = d.inend - d.ws;
+    if (B > 0x7fffffffull) return FailMsg("zmx_tables_build: block too large");
+    t->bsize[b] = static_cast<u32>(B);
+    pos_off += B;
+    reg_off += (L + 7) & ~7ull;
+    la_off += (B + 1 + 7) & ~7ull;
+    max_l = std::max(max_l, L);
+    tile_off[b + 1] = tile_off[b] + static_cast<u32>((B + MT - 1) / MT);
+  }
+  t->total_b = pos_off;
+  t->total_l = reg_off;
+  if (nb == 0) return 0;
+
+  HIPCHK(DevAlloc(&t->d_blocks, nb));
+  HIPCHK(DevAlloc(&t->d_tile_off, nb + 1));
+  HIPCHK(DevAlloc(&t->d_same16, reg_off));
+  HIPCHK(DevAlloc(&t->d_links, reg_off));
+  HIPCHK(DevAlloc(&t->d_recs, pos_off * 8));
+  HIPCHK(DevAlloc(&t->d_la, la_off));
+  HIPCHK(DevAlloc(&t->d_store[0], pos_off));
+  HIPCHK(DevAlloc(&t->d_store[1], pos_off));
+  HIPCHK(DevAlloc(&t->d_hist, nb * ZMX_HIST));
+  HIPCHK(DevAlloc(&t->d_nsym, nb));
+  HIPCHK(DevAlloc(&t->d_cost, nb * ZMX_HIST));
+  HIPCHK(DevAlloc(&t->d_mincost, nb));
+  HIPCHK(DevAlloc(&t->d_slot, nb));
+  HIPCHK(DevAlloc(&t->d_counters, 16));
+  HIPCHK(DevAlloc(&t->d_flags, 4));
+  HIPCHK(hipMemcpyAsync(t->d_blocks, t->blocks.data(), nb * sizeof(BlockDesc), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(t->d_tile_off, tile_off.data(), (nb + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(t->d_flags, 0, 4 * sizeof(u32), c->stream));
+
+  if (max_l > 0) {
+    const dim3 g1(static_cast<unsigned>((max_l + 256 * SAME_CH - 1) / (256 * SAME_CH)), static_cast<unsigned>(nb));
+    hipLaunchKernelGGL(k_same, g1, dim3(256), 0, c->stream, c->d_in, t->d_blocks, t->d_same16);
+    HIPCHK(hipGetLastError());
+    const dim3 g2(static_cast<unsigned>((max_l + CH_EMIT - 1) / CH_EMIT), static_cast<unsigned>(nb), 2);
+    hipLaunchKernelGGL(k_chain, g2, dim3(64), CH_LDS_BYTES, c->stream, c->d_in, t->d_blocks, t->d_same16, t->d_links);
+    HIPCHK(hipGetLastError());
+  }
+
+  if (!c->d_scratch) HIPCHK(DevAlloc(&c->d_scratch, static_cast<size_t>(kMatchGrid) * MATCH_THREADS * SCRATCH_CPS));
+
+  // Change points beyond the 8 inline ones go to a pool; start with 4 entries per
+  // position and grow on overflow (worst case 256 per position).
+  u64 per_pos = 4;
+  for (;;) {
+    u64 cap = std::max<u64>(pos_off * per_pos, 1u << 16);
+    if (cap > 0xfffffff0ull) cap = 0xfffffff0ull;
+    if (t->d_pool) HIPCHK(hipFree(t->d_pool));
+    t->d_pool = nullptr;
+    HIPCHK(DevAlloc(&t->d_pool, cap));
+    t->pool_cap = static_cast<u32>(cap);
+    HIPCHK(hipMemsetAsync(t->d_counters, 0, 16 * sizeof(u32), c->stream));
+    MatchParams mp;
+    mp.in = c->d_in;
+    mp.blocks = t->d_blocks;
+    mp.tile_off = t->d_tile_off;
+    mp.nb = static_cast<u32>(nb);
+    mp.total_tiles = tile_off[nb];
+    mp.links = t->d_links;
+    mp.recs = t->d_recs;
+    mp.pool = t->d_pool;
+    mp.pool_cap = t->pool_cap;
+    mp.counters = t->d_counters;
+    mp.scratch = c->d_scratch;
+    if (mp.total_tiles > 0) {
+      hipLaunchKernelGGL(k_match, dim3(kMatchGrid), dim3(MATCH_THREADS), 0, c->stream, mp);
+      HIPCHK(hipGetLastError());
+    }
+    u32 counters[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(counters, t->d_counters, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if ((counters[1] & 1u) == 0) break;
+    if (per_pos >= 256) return FailMsg("zmx_tables_build: change-point pool overflow");
+    per_pos *= 8;
+  }
+  return 0;
+}
+
+int zmx_tables_build(zmx_ctx* c, const zmx_block* blocks, size_t nblocks, zmx_tables** out) {
+  HIPCHK(hipSetDevice(c->device));
+  zmx_tables* t = new zmx_tables();
+  const int rc = BuildTables(c, blocks, nblocks, t);
+  if (rc) {
+    zmx_tables_free(c, t);
+    return rc;
+  }
+  *out = t;
+  return 0;
+}
+
+static int CheckFlags(zmx_ctx* c, zmx_tables* t, const char* where) {
+  u32 flags[4];
+  HIPCHK(hipMemcpyAsync(flags, t->d_flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (flags[1]) {
+    char buf[128];
+    std::snprintf(buf, sizeof(buf), "%s: device consistency flags 0x%x", where, flags[1]);
+    return FailMsg(buf);
+  }
+  return 0;
+}
+
+int zmx_lz77_greedy(zmx_ctx* c, zmx_tables* t, int slot, uint32_t* nsym, uint32_t* hist) {
+  if (t->nb == 0) return 0;
+  if (slot != 0 && slot != 1) return FailMsg("zmx_lz77_greedy: slot must be 0 or 1");
+  HIPCHK(hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_greedy, dim3(static_cast<unsigned>(t->nb)), dim3(64), 0, c->stream, t->d_blocks, t->d_recs,
+                     t->d_store[slot], t->d_hist, t->d_nsym);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(nsym, t->d_nsym, t->nb * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(hist, t->d_hist, t->nb * ZMX_HIST * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (size_t b = 0; b < t->nb; ++b) t->store_begin[slot][b] = 0;
+  return 0;
+}
+
+int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double* mincost, const int32_t* slot,
+                    uint32_t* nsym, uint32_t* hist) {
+  if (t->nb == 0) return 0;
+  HIPCHK(hipSetDevice(c->device));
+  for (size_t b = 0; b < t->nb; ++b) {
+    if (slot[b] != 0 && slot[b] != 1) return FailMsg("zmx_squeeze_run: slot must be 0 or 1");
+  }
+  HIPCHK(hipMemcpyAsync(t->d_cost, cost, t->nb * ZMX_HIST * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(t->d_mincost, mincost, t->nb * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(t->d_slot, slot, t->nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  SqueezeParams sp;
+  sp.blocks = t->d_blocks;
+  sp.recs = t->d_recs;
+  sp.pool = t->d_pool;
+  sp.cost = t->d_cost;
+  sp.mincost = t->d_mincost;
+  sp.slot = t->d_slot;
+  sp.la = t->d_la;
+  sp.store0 = t->d_store[0];
+  sp.store1 = t->d_store[1];
+  sp.hist_out = t->d_hist;
+  sp.nsym_out = t->d_nsym;
+  sp.flags = t->d_flags;
+  HIPCHK(hipEventRecord(c->ev0, c->stream));
+  hipLaunchKernelGGL(k_squeeze, dim3(static_cast<unsigned>(t->nb)), dim3(64), 0, c->stream, sp);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(c->ev1, c->stream));
+  HIPCHK(hipMemcpyAsync(nsym, t->d_nsym, t->nb * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(hist, t->d_hist, t->nb * ZMX_HIST * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  const int rc = CheckFlags(c, t, "zmx_squeeze_run");
+  if (rc) return rc;
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  {
+    std::lock_guard<std::mutex> lock(g_stats_mutex);
+    g_squeeze_seconds += ms * 1e-3;
+    g_squeeze_launches += 1;
+  }
+  for (size_t b = 0; b < t->nb; ++b) t->store_begin[slot[b]][b] = t->bsize[b] - nsym[b];
+  return 0;
+}
+
+int zmx_store_download(zmx_ctx* c, zmx_tables* t, size_t block, int slot, uint16_t* litlens, uint16_t* dists,
+                       size_t nsym) {
+  if (block >= t->nb || (slot != 0 && slot != 1)) return FailMsg("zmx_store_download: bad block or slot");
+  if (nsym == 0) return 0;
+  const u32 begin = t->store_begin[slot][block];
+  if (begin + nsym > t->bsize[block]) return FailMsg("zmx_store_download: nsym exceeds the store");
+  HIPCHK(hipSetDevice(c->device));
+  std::vector<u32> tmp(nsym);
+  HIPCHK(hipMemcpyAsync(tmp.data(), t->d_store[slot] + t->blocks[block].pos_off + begin, nsym * sizeof(u32),
+                        hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (size_t i = 0; i < nsym; ++i) {
+    litlens[i] = static_cast<uint16_t>(tmp[i] & 0xffffu);
+    dists[i] = static_cast<uint16_t>(tmp[i] >> 16);
+  }
+  return 0;
+}
+
+int zmx_find_longest_match(zmx_ctx* c, zmx_tables* t, size_t block, size_t pos, uint16_t* sublen,
+                           uint16_t* distance, uint16_t* length) {
+  if (block >= t->nb) return FailMsg("zmx_find_longest_match: bad block");
+  const BlockDesc& d = t->blocks[block];
+  if (pos < d.instart || pos >= d.inend) return FailMsg("zmx_find_longest_match: pos outside the block");
+  HIPCHK(hipSetDevice(c->device));
+  if (t->probe_recs.empty()) t->probe_recs.resize(t->nb);
+  std::vector<u32>& recs = t->probe_recs[block];
+  if (recs.empty()) {
+    recs.resize(static_cast<size_t>(t->bsize[block]) * 8);
+    HIPCHK(hipMemcpy(recs.data(), t->d_recs + d.pos_off * 8, recs.size() * sizeof(u32), hipMemcpyDeviceToHost));
+  }
+  const u32* r = &recs[(pos - d.instart) * 8];
+  *length = static_cast<uint16_t>(r[0] & 0xffffu);
+  *distance = static_cast<uint16_t>(r[0] >> 16);
+  if (!sublen) return 0;
+  const u32 ncpf = r[1] >> 24;
+  unsigned prev = 2;  // sublen[3..] only; the reference also fills sublen[2] for 2-byte hits, which nobody reads
+  if (ncpf != 0xffu) {
+    const u8* bytes = reinterpret_cast<const u8*>(r) + 8;
+    for (u32 e = 0; e < ncpf; ++e) {
+      const unsigned len = bytes[3 * e] + 3u, dist = bytes[3 * e + 1] | (bytes[3 * e + 2] << 8);
+      for (unsigned l = prev + 1; l <= len; ++l) sublen[l] = static_cast<uint16_t>(dist);
+      prev = len;
+    }
+  } else {
+    if (!t->probe_pool_ready) {
+      u32 used = 0;
+      HIPCHK(hipMemcpy(&used, t->d_counters, sizeof(u32), hipMemcpyDeviceToHost));
+      t->probe_pool.resize(used);
+      if (used) HIPCHK(hipMemcpy(t->probe_pool.data(), t->d_pool, used * sizeof(u32), hipMemcpyDeviceToHost));
+      t->probe_pool_ready = true;
+    }
+    const u32 off = r[2], n = r[3] & 0xffffu;
+    for (u32 e = 0; e < n; ++e) {
+      const u32 x = t->probe_pool[off + e];
+      const unsigned len = x & 0xffffu, dist = x >> 16;
+      for (unsigned l = prev + 1; l <= len; ++l) sublen[l] = static_cast<uint16_t>(dist);
+      prev = len;
+    }
+  }
+  return 0;
+}
+
+int zmx_length_array_download(zmx_ctx* c, zmx_tables* t, size_t block, uint16_t* out) {
+  if (block >= t->nb) return FailMsg("zmx_length_array_download: bad block");
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipMemcpy(out, t->d_la + t->blocks[block].la_off, (static_cast<size_t>(t->bsize[block]) + 1) * sizeof(u16),
+                   hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // extern "C"

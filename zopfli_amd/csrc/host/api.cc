@@ -18,6 +18,8 @@
 extern "C" void zmx_internal_kernel_stats(double* squeeze_seconds, double* squeeze_launches, int reset);
 // implemented by the device layer: size of the resident input
 extern "C" size_t zmx_internal_input_size(zmx_ctx* ctx);
+// implemented by the device layer: the caller's host copy of the resident input (borrowed)
+extern "C" const unsigned char* zmx_internal_input_host(zmx_ctx* ctx);
 
 namespace {
 
@@ -53,17 +55,16 @@ size_t PartsPerBatch() {
   return n;
 }
 
-std::vector<zamd::Part> MasterBlocks(size_t insize, size_t first_mb, size_t last_mb, bool final) {
+std::vector<zamd::Part> MasterBlocks(size_t insize, bool final) {
   // deflate.c:916-923: do { ... } while (i < insize), so an empty input still
   // yields one (empty) part.
   std::vector<zamd::Part> parts;
-  size_t i = 0, mb = 0;
+  size_t i = 0;
   do {
     const bool masterfinal = i + kMasterBlock >= insize;
     const size_t size = masterfinal ? insize - i : kMasterBlock;
-    if (mb >= first_mb && mb < last_mb) parts.push_back({i, i + size, final && masterfinal});
+    parts.push_back({i, i + size, final && masterfinal});
     i += size;
-    ++mb;
   } while (i < insize);
   return parts;
 }
@@ -190,7 +191,7 @@ void ZopfliDeflate(const ZopfliOptions* options, int btype, int final, const uns
     zmx_ctx* ctx = SharedContext();
     ResetTiming();
     if (zmx_set_input(ctx, in, insize) != 0) Die("zmx_set_input");
-    const std::vector<zamd::Part> parts = MasterBlocks(insize, 0, static_cast<size_t>(-1), final != 0);
+    const std::vector<zamd::Part> parts = MasterBlocks(insize, final != 0);
     std::vector<zamd::Chunk> chunks;
     if (RunParts(ctx, *options, btype, parts, &chunks) != 0) Die("device error");
     EmitChunks(chunks, in, bp, out, outsize);
@@ -255,15 +256,23 @@ void ZopfliCompress(const ZopfliOptions* options, ZopfliFormat output_type, cons
   }
 }
 
-int zmx_deflate_master_blocks(zmx_ctx* ctx, const ZopfliOptions* options, size_t first_mb, size_t last_mb,
-                              int final, unsigned char** blob, size_t* blobsize) {
+int zmx_deflate_range(zmx_ctx* ctx, const ZopfliOptions* options, size_t instart, size_t inend, int final,
+                      unsigned char** blob, size_t* blobsize) {
   ResetTiming();
-  const size_t insize = zmx_internal_input_size(ctx);
-  const std::vector<zamd::Part> parts = MasterBlocks(insize, first_mb, last_mb, final != 0);
+  if (inend < instart || inend > zmx_internal_input_size(ctx)) return -1;
+  // deflate.c:916-923 on [instart, inend)
+  std::vector<zamd::Part> parts;
+  size_t i = instart;
+  do {
+    const bool masterfinal = i + kMasterBlock >= inend;
+    const size_t size = masterfinal ? inend - i : kMasterBlock;
+    parts.push_back({i, i + size, final != 0 && masterfinal});
+    i += size;
+  } while (i < inend);
   std::vector<zamd::Chunk> chunks;
   const int rc = RunParts(ctx, *options, 2, parts, &chunks);
   if (rc) return rc;
-  const std::vector<uint8_t> v = zamd::SerializeChunks(chunks);
+  const std::vector<uint8_t> v = zamd::SerializeChunks(chunks, zmx_internal_input_host(ctx));
   *blob = static_cast<unsigned char*>(std::malloc(v.size() ? v.size() : 1));
   if (!*blob) return -1;
   std::memcpy(*blob, v.data(), v.size());
@@ -272,12 +281,12 @@ int zmx_deflate_master_blocks(zmx_ctx* ctx, const ZopfliOptions* options, size_t
 }
 
 int zmx_chunks_merge(const unsigned char* const* blobs, const size_t* blobsizes, size_t nblobs,
-                     const unsigned char* in, unsigned char* bp, unsigned char** out, size_t* outsize) {
+                     unsigned char* bp, unsigned char** out, size_t* outsize) {
   std::vector<zamd::Chunk> chunks;
   for (size_t i = 0; i < nblobs; ++i) {
     if (!zamd::DeserializeChunks(blobs[i], blobsizes[i], &chunks)) return -1;
   }
-  EmitChunks(chunks, in, bp, out, outsize);
+  EmitChunks(chunks, nullptr, bp, out, outsize);
   return 0;
 }
 

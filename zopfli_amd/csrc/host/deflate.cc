@@ -234,6 +234,7 @@ void MergeChunks(const std::vector<Chunk>& chunks, const unsigned char* in, BitS
     }
     // AddNonCompressedBlock (deflate.c:625-665): pieces of at most 65535 bytes,
     // each byte-aligned after its 3 header bits.
+    const unsigned char* src = c.raw.empty() ? in : c.raw.data() - c.start;
     size_t pos = c.start;
     for (;;) {
       size_t piece = 65535;
@@ -248,7 +249,7 @@ void MergeChunks(const std::vector<Chunk>& chunks, const unsigned char* in, BitS
       stream->AppendByteAligned(static_cast<uint8_t>(len >> 8));
       stream->AppendByteAligned(static_cast<uint8_t>(nlen & 255));
       stream->AppendByteAligned(static_cast<uint8_t>(nlen >> 8));
-      stream->bytes.insert(stream->bytes.end(), in + pos, in + pos + piece);
+      stream->bytes.insert(stream->bytes.end(), src + pos, src + pos + piece);
       if (last) break;
       pos += piece;
     }
@@ -266,10 +267,10 @@ uint64_t GetU64(const unsigned char* p) {
 }
 }  // namespace
 
-// Blob layout: u64 count, then per chunk: u8 kind, u8 final, u64 a, u64 b and,
-// for bit chunks (a = nbits, b = nbytes), b payload bytes; stored chunks carry
-// only their input range (a = start, b = end).
-std::vector<uint8_t> SerializeChunks(const std::vector<Chunk>& chunks) {
+// Blob layout: u64 count, then per chunk: u8 kind, u8 final, u64 a, u64 b and a
+// payload: bit chunks a = nbits, b = payload bytes; stored chunks a = 0,
+// b = payload bytes (the raw input bytes of the block).
+std::vector<uint8_t> SerializeChunks(const std::vector<Chunk>& chunks, const unsigned char* in) {
   std::vector<uint8_t> blob;
   PutU64(&blob, chunks.size());
   for (const Chunk& c : chunks) {
@@ -280,8 +281,10 @@ std::vector<uint8_t> SerializeChunks(const std::vector<Chunk>& chunks) {
       PutU64(&blob, c.bits.size());
       blob.insert(blob.end(), c.bits.begin(), c.bits.end());
     } else {
-      PutU64(&blob, c.start);
-      PutU64(&blob, c.end);
+      PutU64(&blob, 0);
+      PutU64(&blob, c.end - c.start);
+      const unsigned char* src = c.raw.empty() ? in + c.start : c.raw.data();
+      blob.insert(blob.end(), src, src + (c.end - c.start));
     }
   }
   return blob;
@@ -304,8 +307,12 @@ bool DeserializeChunks(const unsigned char* blob, size_t size, std::vector<Chunk
       c.bits.assign(blob + off, blob + off + b);
       off += b;
     } else if (c.kind == Chunk::kStored) {
-      c.start = a;
+      if (off + b > size) return false;
+      c.start = 0;
       c.end = b;
+      c.raw.assign(blob + off, blob + off + b);
+      if (b == 0) c.raw.clear();
+      off += b;
     } else {
       return false;
     }

@@ -23,7 +23,8 @@ struct Chunk {
   bool final_block = false;     // kStored only: BFINAL of its last piece
   std::vector<uint8_t> bits;    // kBits: packed from bit 0
   size_t nbits = 0;
-  size_t start = 0, end = 0;    // kStored: raw input range
+  size_t start = 0, end = 0;    // kStored: raw input range ...
+  std::vector<uint8_t> raw;     // ... or, after (de)serialisation, the bytes themselves
 };
 
 struct Part {
@@ -39,7 +40,8 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
 // Appends chunks to a (bytes, bp) stream; `in` is the base of the resident input.
 void MergeChunks(const std::vector<Chunk>& chunks, const unsigned char* in, BitStream* stream);
 
-std::vector<uint8_t> SerializeChunks(const std::vector<Chunk>& chunks);
+// Stored chunks are serialised with their raw bytes (taken from `in`).
+std::vector<uint8_t> SerializeChunks(const std::vector<Chunk>& chunks, const unsigned char* in);
 bool DeserializeChunks(const unsigned char* blob, size_t size, std::vector<Chunk>* chunks);
 
 // Appends `n` bytes to a reference-style growable array (util.h:135-155).

@@ -212,15 +212,15 @@ def main():
             d = zlib.decompressobj(31)
             n = len(d.decompress(out)) + len(d.flush())
             roundtrip = (n == total)
-        # ---- roofline of the dominant kernel (k_squeeze): algorithmic bytes = 31 B per position
-        #      per launch (28 B match record + 1 B literal + 2 B length_array)
+        # ---- roofline of the dominant kernel (k_dp, the serial DP chain): algorithmic bytes = 31 B per
+        #      position per launch (28 B match record + 1 B literal + 2 B length_array)
         launches = timing_acc.get("squeeze_launches", 0.0)
-        ksec = timing_acc.get("squeeze_kernel", 0.0)
+        ksec = timing_acc.get("dp_kernel", 0.0)
         roofline = None
         if launches > 0 and ksec > 0:
             per_launch_bytes = 31.0 * size
             achieved = per_launch_bytes / (ksec / launches) / 1e9
-            roofline = {"bound": "hbm", "kernel": "k_squeeze", "achieved": round(achieved, 3), "peak": 8000.0,
+            roofline = {"bound": "hbm", "kernel": "k_dp", "achieved": round(achieved, 3), "peak": 8000.0,
                         "unit": "GB/s", "frac": round(achieved / 8000.0, 6), "traffic": None,
                         "avg_launch_ms": round(ksec / launches * 1e3, 3), "launches_per_step": launches / args.steps}
         line = {

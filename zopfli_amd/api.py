@@ -65,6 +65,7 @@ def bind(lib):
     lib.zmx_deflate_range.argtypes = [vp, opt, sz, sz, ctypes.c_int, P(_u8p), P(sz)]
     lib.zmx_chunks_merge.argtypes = [P(ctypes.c_char_p), P(sz), sz, P(ctypes.c_ubyte), P(_u8p), P(sz)]
     lib.zmx_last_timing.argtypes = [P(ctypes.c_double)]
+    lib.zmx_last_kernel_timing.argtypes = [P(ctypes.c_double)]
     return lib
 
 
@@ -120,8 +121,12 @@ def last_timing(lib=None):
     lib = lib or library()
     t = (ctypes.c_double * 8)()
     lib.zmx_last_timing(t)
-    keys = ["tables", "greedy", "squeeze", "cost_model", "split", "encode", "squeeze_kernel", "squeeze_launches"]
-    return dict(zip(keys, list(t)))
+    keys = ["tables", "greedy", "squeeze", "cost_model", "split", "encode", "dp_kernel", "squeeze_launches"]
+    d = dict(zip(keys, list(t)))
+    k = (ctypes.c_double * 4)()
+    lib.zmx_last_kernel_timing(k)
+    d["edges_kernel"], d["trace_kernel"] = k[0], k[2]
+    return d
 
 
 class Context:

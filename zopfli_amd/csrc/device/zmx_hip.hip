@@ -19,7 +19,8 @@ namespace {
 
 std::string g_err;
 std::mutex g_stats_mutex;
-double g_squeeze_seconds = 0, g_squeeze_launches = 0;
+double g_kernel_seconds[3] = {0, 0, 0};  // k_edges, k_dp, k_trace (HIP events)
+double g_squeeze_launches = 0;
 
 int Fail(const char* what, hipError_t e, const char* file, int line) {
   char buf[512];
@@ -55,7 +56,9 @@ struct zmx_ctx {
   size_t insize = 0, in_cap = 0;
   const unsigned char* h_in = nullptr;  // caller's buffer (borrowed until the next zmx_set_input)
   u32* d_scratch = nullptr;  // k_match per-lane overflow change points
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double* d_rows = nullptr;  // DP edge costs of the blocks of one k_edges/k_dp launch (grow-only)
+  size_t rows_cap = 0;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 struct zmx_tables {
@@ -78,8 +81,16 @@ struct zmx_tables {
   double* d_cost = nullptr;
   double* d_mincost = nullptr;
   int* d_slot = nullptr;
+  uint2* d_dph = nullptr;         // per position: DP row offset, kend | shortcut flag (k_rowscan)
+  u64* d_block_edges = nullptr;   // per block: DP edges
+  u64* d_row_base = nullptr;      // per block: first slot in ctx->d_rows for its launch range
+  std::vector<u64> block_edges;
+  std::vector<u32> tile_off;
+  std::vector<std::pair<u32, u32>> ranges;  // blocks [first, last) squeezed together (row budget)
+  u64 max_range_rows = 0;
   u32* d_counters = nullptr;  // 16 words, see MatchParams
   u32* d_flags = nullptr;     // 4 words
+  u64* d_prof = nullptr;      // nb * 8 cycle counters when ZOPFLI_AMD_PROF is set
   // host cache for the parity probe
   std::vector<std::vector<u32>> probe_recs;
   std::vector<u32> probe_pool;
@@ -99,11 +110,14 @@ const char* zmx_last_error(void) { return g_err.c_str(); }
 size_t zmx_internal_input_size(zmx_ctx* ctx) { return ctx->insize; }
 const unsigned char* zmx_internal_input_host(zmx_ctx* ctx) { return ctx->h_in; }
 
-void zmx_internal_kernel_stats(double* squeeze_seconds, double* squeeze_launches, int reset) {
+void zmx_internal_kernel_stats(double* seconds3, double* squeeze_launches, int reset) {
   std::lock_guard<std::mutex> lock(g_stats_mutex);
-  *squeeze_seconds = g_squeeze_seconds;
+  for (int i = 0; i < 3; ++i) seconds3[i] = g_kernel_seconds[i];
   *squeeze_launches = g_squeeze_launches;
-  if (reset) g_squeeze_seconds = g_squeeze_launches = 0;
+  if (reset) {
+    g_kernel_seconds[0] = g_kernel_seconds[1] = g_kernel_seconds[2] = 0;
+    g_squeeze_launches = 0;
+  }
 }
 
 int zmx_ctx_create(int device, zmx_ctx** out) {
@@ -119,8 +133,7 @@ int zmx_ctx_create(int device, zmx_ctx** out) {
   zmx_ctx* c = new zmx_ctx();
   c->device = device;
   HIPCHK(hipStreamCreate(&c->stream));
-  HIPCHK(hipEventCreate(&c->ev0));
-  HIPCHK(hipEventCreate(&c->ev1));
+  for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
                              CH_LDS_BYTES));
   *out = c;
@@ -132,8 +145,8 @@ void zmx_ctx_destroy(zmx_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipFree(c->d_in);
   (void)hipFree(c->d_scratch);
-  if (c->ev0) (void)hipEventDestroy(c->ev0);
-  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  (void)hipFree(c->d_rows);
+  for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -171,8 +184,12 @@ void zmx_tables_free(zmx_ctx* c, zmx_tables* t) {
   (void)hipFree(t->d_cost);
   (void)hipFree(t->d_mincost);
   (void)hipFree(t->d_slot);
+  (void)hipFree(t->d_dph);
+  (void)hipFree(t->d_block_edges);
+  (void)hipFree(t->d_row_base);
   (void)hipFree(t->d_counters);
   (void)hipFree(t->d_flags);
+  (void)hipFree(t->d_prof);
   delete t;
 }
 
@@ -196,7 +213,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     d.reg_off = reg_off;
     d.la_off = la_off;
     const u64 B = d.inend - d.instart, L = d.inend - d.ws;
-    if (B > 0x7fffffffull) return FailMsg("zmx_tables_build: block too large");
+    if (B > 16000000ull) return FailMsg("zmx_tables_build: block too large (DP row offsets are 32-bit)");
     t->bsize[b] = static_cast<u32>(B);
     pos_off += B;
     reg_off += (L + 7) & ~7ull;
@@ -206,6 +223,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   }
   t->total_b = pos_off;
   t->total_l = reg_off;
+  t->tile_off = tile_off;
   if (nb == 0) return 0;
 
   HIPCHK(DevAlloc(&t->d_blocks, nb));
@@ -221,6 +239,9 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   HIPCHK(DevAlloc(&t->d_cost, nb * ZMX_HIST));
   HIPCHK(DevAlloc(&t->d_mincost, nb));
   HIPCHK(DevAlloc(&t->d_slot, nb));
+  HIPCHK(DevAlloc(&t->d_dph, pos_off));
+  HIPCHK(DevAlloc(&t->d_block_edges, nb));
+  HIPCHK(DevAlloc(&t->d_row_base, nb));
   HIPCHK(DevAlloc(&t->d_counters, 16));
   HIPCHK(DevAlloc(&t->d_flags, 4));
   HIPCHK(hipMemcpyAsync(t->d_blocks, t->blocks.data(), nb * sizeof(BlockDesc), hipMemcpyHostToDevice, c->stream));
@@ -272,6 +293,41 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     if (per_pos >= 256) return FailMsg("zmx_tables_build: change-point pool overflow");
     per_pos *= 8;
   }
+
+  // DP row layout (k_rowscan) and the launch ranges that fit the row budget
+  RowScanParams rp;
+  rp.blocks = t->d_blocks;
+  rp.recs = t->d_recs;
+  rp.dph = t->d_dph;
+  rp.block_edges = t->d_block_edges;
+  hipLaunchKernelGGL(k_rowscan, dim3(static_cast<unsigned>(nb)), dim3(1024), 0, c->stream, rp);
+  HIPCHK(hipGetLastError());
+  t->block_edges.resize(nb);
+  HIPCHK(hipMemcpyAsync(t->block_edges.data(), t->d_block_edges, nb * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  static const u64 budget = [] {
+    u64 gb = 96;
+    if (const char* e = std::getenv("ZOPFLI_AMD_ROW_BUDGET_GB")) gb = std::max<long>(1, std::atol(e));
+    return gb * (1ull << 30) / sizeof(double);
+  }();
+  std::vector<u64> row_base(nb, 0);
+  u64 cur = 0;
+  u32 first = 0;
+  for (size_t b = 0; b < nb; ++b) {
+    const u64 pad = ((t->block_edges[b] + 127) & ~127ull) + 128;
+    if (cur + pad > budget && b > first) {
+      t->ranges.emplace_back(first, static_cast<u32>(b));
+      t->max_range_rows = std::max(t->max_range_rows, cur);
+      first = static_cast<u32>(b);
+      cur = 0;
+    }
+    row_base[b] = cur;
+    cur += pad;
+  }
+  t->ranges.emplace_back(first, static_cast<u32>(nb));
+  t->max_range_rows = std::max(t->max_range_rows, cur);
+  HIPCHK(hipMemcpyAsync(t->d_row_base, row_base.data(), nb * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
 
@@ -323,35 +379,88 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   HIPCHK(hipMemcpyAsync(t->d_cost, cost, t->nb * ZMX_HIST * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(t->d_mincost, mincost, t->nb * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(t->d_slot, slot, t->nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  SqueezeParams sp;
-  sp.blocks = t->d_blocks;
-  sp.recs = t->d_recs;
-  sp.pool = t->d_pool;
-  sp.cost = t->d_cost;
-  sp.mincost = t->d_mincost;
-  sp.slot = t->d_slot;
-  sp.la = t->d_la;
-  sp.store0 = t->d_store[0];
-  sp.store1 = t->d_store[1];
-  sp.hist_out = t->d_hist;
-  sp.nsym_out = t->d_nsym;
-  sp.flags = t->d_flags;
-  HIPCHK(hipEventRecord(c->ev0, c->stream));
-  hipLaunchKernelGGL(k_squeeze, dim3(static_cast<unsigned>(t->nb)), dim3(64), 0, c->stream, sp);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipEventRecord(c->ev1, c->stream));
+  if (t->max_range_rows > c->rows_cap) {
+    if (c->d_rows) HIPCHK(hipFree(c->d_rows));
+    c->d_rows = nullptr;
+    c->rows_cap = 0;
+    HIPCHK(DevAlloc(&c->d_rows, t->max_range_rows));
+    c->rows_cap = t->max_range_rows;
+  }
+  static const bool want_prof = std::getenv("ZOPFLI_AMD_PROF") != nullptr;
+  if (want_prof && !t->d_prof) HIPCHK(DevAlloc(&t->d_prof, t->nb * 8));
+  EdgeParams ep;
+  ep.blocks = t->d_blocks;
+  ep.tile_off = t->d_tile_off;
+  ep.nb_total = static_cast<u32>(t->nb);
+  ep.recs = t->d_recs;
+  ep.pool = t->d_pool;
+  ep.dph = t->d_dph;
+  ep.cost = t->d_cost;
+  ep.rows = c->d_rows;
+  ep.row_base = t->d_row_base;
+  DpParams cp;
+  cp.blocks = t->d_blocks;
+  cp.dph = t->d_dph;
+  cp.cost = t->d_cost;
+  cp.mincost = t->d_mincost;
+  cp.rows = c->d_rows;
+  cp.row_base = t->d_row_base;
+  cp.block_edges = t->d_block_edges;
+  cp.la = t->d_la;
+  cp.prof = t->d_prof;
+  TraceParams tp;
+  tp.blocks = t->d_blocks;
+  tp.recs = t->d_recs;
+  tp.pool = t->d_pool;
+  tp.la = t->d_la;
+  tp.slot = t->d_slot;
+  tp.store0 = t->d_store[0];
+  tp.store1 = t->d_store[1];
+  tp.hist_out = t->d_hist;
+  tp.nsym_out = t->d_nsym;
+  tp.flags = t->d_flags;
+  double ksec[3] = {0, 0, 0};
+  for (const auto& r : t->ranges) {
+    const unsigned nblk = r.second - r.first;
+    const unsigned tiles = t->tile_off[r.second] - t->tile_off[r.first];
+    ep.tile0 = t->tile_off[r.first];
+    cp.block0 = r.first;
+    tp.block0 = r.first;
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    if (tiles) hipLaunchKernelGGL(k_edges, dim3(tiles), dim3(256), 0, c->stream, ep);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    hipLaunchKernelGGL(k_dp, dim3(nblk), dim3(64), 0, c->stream, cp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[2], c->stream));
+    hipLaunchKernelGGL(k_trace, dim3(nblk), dim3(64), 0, c->stream, tp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[3], c->stream));
+    HIPCHK(hipEventSynchronize(c->ev[3]));
+    for (int i = 0; i < 3; ++i) {
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+      ksec[i] += ms * 1e-3;
+    }
+  }
   HIPCHK(hipMemcpyAsync(nsym, t->d_nsym, t->nb * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(hist, t->d_hist, t->nb * ZMX_HIST * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
   const int rc = CheckFlags(c, t, "zmx_squeeze_run");
   if (rc) return rc;
-  float ms = 0;
-  HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
   {
     std::lock_guard<std::mutex> lock(g_stats_mutex);
-    g_squeeze_seconds += ms * 1e-3;
+    for (int i = 0; i < 3; ++i) g_kernel_seconds[i] += ksec[i];
     g_squeeze_launches += 1;
   }
   for (size_t b = 0; b < t->nb; ++b) t->store_begin[slot[b]][b] = t->bsize[b] - nsym[b];
+  if (t->d_prof) {
+    std::vector<u64> pr(t->nb * 8);
+    HIPCHK(hipMemcpy(pr.data(), t->d_prof, pr.size() * sizeof(u64), hipMemcpyDeviceToHost));
+    double a[5] = {0, 0, 0, 0, 0};
+    for (size_t b = 0; b < t->nb; ++b) for (int k = 0; k < 5; ++k) a[k] += static_cast<double>(pr[b * 8 + k]);
+    std::fprintf(stderr, "squeeze prof: edges %.2f ms chain %.2f ms trace %.2f ms; k_dp cycles/position stage %.1f chain %.1f; fast %.1f%% of %.0f positions\n",
+                 ksec[0] * 1e3, ksec[1] * 1e3, ksec[2] * 1e3, a[0] / a[4], a[1] / a[4], 100.0 * a[2] / (a[2] + a[3] + 1e-9), a[4]);
+  }
   return 0;
 }
 

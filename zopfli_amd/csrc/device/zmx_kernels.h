@@ -532,23 +532,565 @@ __global__ __launch_bounds__(64) void k_greedy(const BlockDesc* __restrict__ blo
 
 // ----------------------------------------------------------------------------
 // K4  one LZ77OptimalRun per block (squeeze.c:429): GetBestLengths forward DP
-//     (:217) + TraceBackwards (:317) + FollowPath (:338) + histogram.
-//     One wave per block; positions are sequential, lanes cover the match
-//     lengths k of the current position.  costs[] lives in a 1024-entry LDS
-//     ring (only cells j..j+516 are ever live), the symbol cost tables in LDS.
+//     (:217) + TraceBackwards (:317) + FollowPath (:338) + histogram, split
+//     by how each part parallelises:
+//
+//     k_rowscan (once per table build)  row layout of the DP edges: position j
+//         of a block owns the edges k = 1 (literal), 3..kend (matches,
+//         kend = min(leng, inend - i), squeeze.c:286); dph[j] = {roff, kend |
+//         shortcut flag << 16} with roff the exclusive prefix sum of the row
+//         lengths (k = 2 is a dead slot so that row[k-1] addresses edge k).
+//     k_edges   (every run, all CUs)    cost(k, sublen[k]) of every edge
+//         (squeeze.c:146-157; depends on the run's cost model, not on the DP
+//         state), one lane per edge, written as doubles to rows[] in HBM.
+//     k_dp   (every run, one wave per block)  the serial part: the chain
+//         through the float-rounded absolute costs.  The live cells
+//         costs[j .. j+258] stay in registers (lane l owns cells base + 64 s +
+//         l of the current 64-position group), the cost of the expanding
+//         position is a v_readlane, edge rows stream HBM -> LDS ring by
+//         LDS-DMA one ring ahead, and 8 positions of row values are preloaded
+//         into registers so that no memory latency sits on the chain.
+//     k_trace   (every run, one wave per block)  TraceBackwards + FollowPath +
+//         histogram from length_array and the match records.
 // ----------------------------------------------------------------------------
-#define RING 1024u
-#define RMASK 1023u
 #define TR_CHUNK 2048u
 
-struct SqueezeParams {
+// wave64 inclusive scans on the DPP network (row_shr 1/2/4/8, row_bcast 15/31)
+#define ZMX_WAVE_SCAN(NAME, OP, IDENT)                                                   \
+  __device__ __forceinline__ u32 NAME(u32 v) {                                           \
+    u32 t;                                                                               \
+    t = (u32)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x111, 0xf, 0xf, false); v = OP(v, t); \
+    t = (u32)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x112, 0xf, 0xf, false); v = OP(v, t); \
+    t = (u32)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x114, 0xf, 0xf, false); v = OP(v, t); \
+    t = (u32)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x118, 0xf, 0xf, false); v = OP(v, t); \
+    t = (u32)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x142, 0xa, 0xf, false); v = OP(v, t); \
+    t = (u32)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x143, 0xc, 0xf, false); v = OP(v, t); \
+    return v;                                                                            \
+  }
+__device__ __forceinline__ u32 zmx_addu(u32 a, u32 b) { return a + b; }
+__device__ __forceinline__ u32 zmx_maxu(u32 a, u32 b) { return a > b ? a : b; }
+ZMX_WAVE_SCAN(wave_scan_add, zmx_addu, 0u)
+ZMX_WAVE_SCAN(wave_scan_max, zmx_maxu, 0u)
+
+__device__ __forceinline__ u32 rdlane_u32(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ float rdlane_f32(float v, u32 l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)l));
+}
+// cross-lane hand-off through LDS inside ONE wave: the LDS queue is in order per
+// wave, only the compiler has to be kept from reordering
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ---------------------------------------------------------------- k_rowscan
+struct RowScanParams {
   const BlockDesc* blocks;
   const u32* recs;
+  uint2* dph;          // per block position: {roff, kend | shortcut << 16}
+  u64* block_edges;    // per block: total row length
+};
+
+__global__ __launch_bounds__(1024) void k_rowscan(RowScanParams P) {
+  __shared__ u32 s_wsum[16];
+  const BlockDesc bd = P.blocks[blockIdx.x];
+  const u32 B = (u32)(bd.inend - bd.instart);
+  const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const u32* rbase = P.recs + bd.pos_off * 8;
+  uint2* out = P.dph + bd.pos_off;
+  u32 carry = 0;
+  for (u32 t0 = 0; t0 < B; t0 += 1024) {
+    const u32 jj = t0 + tid;
+    const bool act = jj < B;
+    u32 kend = 0, sflag = 0;
+    if (act) {
+      const uint2 h = *reinterpret_cast<const uint2*>(rbase + (u64)jj * 8);
+      const u32 leng = h.x & 0xffffu, same_i = h.y & 0xffffu;
+      kend = leng < B - jj ? leng : B - jj;        // squeeze.c:286
+      if (kend < 3) kend = 1;
+      // long-run shortcut test (squeeze.c:251-258): i > instart + 259, i + 517 < inend
+      if (same_i > 2 * ZMX_MAX_MATCH && jj > ZMX_MAX_MATCH + 1 && jj + 2 * ZMX_MAX_MATCH + 1 < B) {
+        const u32 same_back = rbase[(u64)(jj - ZMX_MAX_MATCH) * 8 + 1] & 0xffffu;
+        sflag = same_back > ZMX_MAX_MATCH ? 1u : 0u;
+      }
+    }
+    const u32 incl = wave_scan_add(kend);
+    if (lane == 63) s_wsum[wid] = incl;
+    __syncthreads();
+    u32 woff = 0, tot = 0;
+#pragma unroll
+    for (u32 w = 0; w < 16; ++w) {
+      const u32 v = s_wsum[w];
+      if (w < wid) woff += v;
+      tot += v;
+    }
+    if (act) out[jj] = make_uint2(carry + woff + incl - kend, kend | (sflag << 16));
+    carry += tot;
+    __syncthreads();
+  }
+  if (tid == 0) P.block_edges[blockIdx.x] = carry;
+}
+
+// ------------------------------------------------------------------ k_edges
+#define EG_CAP 2048u   // edges expanded per wave at a time
+
+struct EdgeParams {
+  const BlockDesc* blocks;
+  const u32* tile_off;     // [nb_total + 1] cumulative 2048-position tiles
+  u32 nb_total;
+  u32 tile0;               // first tile of this launch
+  const u32* recs;
   const u32* pool;
-  const double* cost;      // [nb][320]
-  const double* mincost;   // [nb]
-  const int* slot;         // [nb]
+  const uint2* dph;
+  const double* cost;      // [nb_total][320]
+  double* rows;
+  const u64* row_base;     // [nb_total] first row slot of each block (in doubles)
+};
+
+__global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
+  __shared__ double s_ll[288];
+  __shared__ double s_d[32];
+  __shared__ double s_kll[260];              // ll[length symbol of k]
+  __shared__ u8 s_klb[260];                  // length extra bits of k
+  __shared__ u8 s_mark[4][EG_CAP];           // row starts, for the edge -> position map
+  __shared__ u32 s_hoff[4][64];              // row offset in the sub-chunk | literal << 16 | overflow << 24
+  __shared__ u32 s_hthr[4][64][2];           // 8 change-point thresholds (len - 3), ascending, 0xff padded
+  __shared__ u16 s_hdist[4][64][8];          // their distances
+  __shared__ u32 s_hpool[4][64][2];          // overflow records: pool offset, count
+
+  const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const u32 tile = P.tile0 + blockIdx.x;
+  u32 lo = 0, hi = P.nb_total;
+  while (hi - lo > 1) {
+    const u32 mid = (lo + hi) >> 1;
+    if (P.tile_off[mid] <= tile) lo = mid; else hi = mid;
+  }
+  const u32 b = lo;
+  const BlockDesc bd = P.blocks[b];
+  const u32 B = (u32)(bd.inend - bd.instart);
+  const u32 tp0 = (tile - P.tile_off[b]) * MT;
+  const u32* rbase = P.recs + bd.pos_off * 8;
+  const uint2* dbase = P.dph + bd.pos_off;
+  double* rows = P.rows + P.row_base[b];
+
+  for (u32 i = tid; i < 288; i += 256) s_ll[i] = P.cost[(u64)b * 320 + i];
+  if (tid < 32) s_d[tid] = P.cost[(u64)b * 320 + 288 + tid];
+  __syncthreads();
+  for (u32 k = tid; k < 260; k += 256) {
+    const bool ok = k >= 3 && k <= ZMX_MAX_MATCH;
+    s_kll[k] = ok ? s_ll[dev_length_symbol(k)] : 0.0;
+    s_klb[k] = ok ? (u8)dev_length_extra_bits(k) : (u8)0;
+  }
+  __syncthreads();
+  const double kInf = __longlong_as_double(0x7ff0000000000000ll);
+  u8* mark = s_mark[wid];
+
+  for (u32 g = wid; g < MT / 64; g += 4) {
+    const u32 base = tp0 + g * 64;
+    if (base >= B) break;
+    const u32 navail = (B - base < 64u) ? B - base : 64u;
+    const u32 jj = base + lane;
+    const bool act = lane < navail;
+    uint4 ra = make_uint4(0, 0, 0, 0), rb = make_uint4(0, 0, 0, 0);
+    uint2 dh = make_uint2(0, 0);
+    if (act) {
+      ra = *reinterpret_cast<const uint4*>(rbase + (u64)jj * 8);
+      rb = *reinterpret_cast<const uint4*>(rbase + (u64)jj * 8 + 4);
+      dh = dbase[jj];
+    }
+    const u32 lit = (ra.y >> 16) & 255u;
+    const u32 ncpf = ra.y >> 24;
+    const u32 kend = dh.y & 0xffffu;
+    const u32 off = dh.x;                       // block-relative row offset
+    const u32 offend = off + (act ? kend : 0u);
+    const u32 off0 = rdlane_u32(off, 0);
+
+    wave_lds_sync();  // the previous group's headers are dead
+    {
+      const bool ovf = ncpf == 0xffu;
+      s_hoff[wid][lane] = (off - off0) | (lit << 16) | ((ovf ? 1u : 0u) << 24);
+      if (ovf) {
+        s_hpool[wid][lane][0] = ra.z;
+        s_hpool[wid][lane][1] = ra.w & 0xffffu;
+        s_hthr[wid][lane][0] = 0xffffffffu;
+        s_hthr[wid][lane][1] = 0xffffffffu;
+      } else {
+        const u32 w[6] = {ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+        u32 t0 = 0, t1 = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const u32 bit = 24u * e;
+          const u32 lo32 = w[bit >> 5] >> (bit & 31);
+          const u32 v = (bit & 31) > 8 ? (lo32 | (w[(bit >> 5) + 1 > 5 ? 5 : (bit >> 5) + 1] << (32 - (bit & 31)))) : lo32;
+          const u32 thr = (u32)e < ncpf ? (v & 255u) : 255u;
+          if (e < 4) t0 |= thr << (8 * e); else t1 |= thr << (8 * (e - 4));
+          s_hdist[wid][lane][e] = (u16)((v >> 8) & 0xffffu);
+        }
+        s_hthr[wid][lane][0] = t0;
+        s_hthr[wid][lane][1] = t1;
+      }
+    }
+
+    u32 q = 0;
+    while (q < navail) {
+      const u32 off_q = rdlane_u32(off, q);
+      const u64 fit = __ballot(act && lane >= q && offend - off_q <= EG_CAP);
+      const u32 n = (u32)__popcll(fit);
+      const u32 E = rdlane_u32(offend, q + n - 1) - off_q;
+      wave_lds_sync();
+      for (u32 e = lane; e < (E + 3) / 4; e += 64) reinterpret_cast<u32*>(mark)[e] = 0;
+      wave_lds_sync();
+      if (lane >= q && lane < q + n) mark[off - off_q] = (u8)(lane + 1);
+      wave_lds_sync();
+      const u32 rel_q = off_q - off0;
+      u32 carry = q + 1;
+      u64 ovf_mask = __ballot(lane >= q && lane < q + n && ncpf == 0xffu);
+      for (u32 t0 = 0; t0 < E; t0 += 64) {
+        const u32 e = t0 + lane;
+        const u32 mk = e < E ? (u32)mark[e] : 0u;
+        u32 own = wave_scan_max(mk);
+        own = own > carry ? own : carry;
+        carry = rdlane_u32(own, 63);
+        if (e < E) {
+          const u32 p = own - 1;
+          const u32 h = s_hoff[wid][p];
+          const u32 k = e - ((h & 0xffffu) - rel_q) + 1;
+          double w;
+          if (k == 1) {
+            w = s_ll[(h >> 16) & 255u];            // literal edge, squeeze.c:278
+          } else if (k == 2 || (h >> 24)) {
+            w = kInf;                              // dead slot (overflow rows are filled below)
+          } else {
+            const u32 x = k - 3;
+            // first change point with len >= k: thresholds ascending, binary search over 8 bytes
+            const u32 tlo = s_hthr[wid][p][0], thi = s_hthr[wid][p][1];
+            u32 idx = ((tlo >> 24) < x) ? 4u : 0u;
+            u32 half = idx ? thi : tlo;
+            if (((half >> 8) & 255u) < x) { idx += 2; half >>= 16; }
+            if ((half & 255u) < x) idx += 1;
+            const u32 dist = s_hdist[wid][p][idx];
+            // squeeze.c:155: (lbits + dbits) as int, then + ll, then + d
+            w = ((double)((int)s_klb[k] + dev_dist_extra_bits(dist)) + s_kll[k]) + s_d[dev_dist_symbol(dist)];
+          }
+          rows[(u64)off_q + e] = w;
+        }
+      }
+      // rows of records with more than 8 change points (pool): whole wave per position
+      while (ovf_mask) {
+        const u32 p = (u32)__ffsll((long long)ovf_mask) - 1;
+        ovf_mask &= ovf_mask - 1;
+        const u32 roff_p = rdlane_u32(off, p);
+        const u32 ke = rdlane_u32(kend, p);
+        const u32 poff = s_hpool[wid][p][0], pn = s_hpool[wid][p][1];
+        for (u32 k = 3 + lane; k <= ke; k += 64) {
+          u32 plo = 0, phi = pn;   // first entry with len >= k (entries ascending in len)
+          while (plo < phi) {
+            const u32 mid = (plo + phi) >> 1;
+            if ((P.pool[poff + mid] & 0xffffu) < k) plo = mid + 1; else phi = mid;
+          }
+          const u32 dist = plo < pn ? P.pool[poff + plo] >> 16 : 1u;
+          rows[(u64)roff_p + k - 1] =
+              ((double)((int)s_klb[k] + dev_dist_extra_bits(dist)) + s_kll[k]) + s_d[dev_dist_symbol(dist)];
+        }
+      }
+      q += n;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ k_dp
+#define DP_RING 4096u                 // doubles in the LDS ring (32 KB)
+#define DP_PIECE 128u                 // doubles per LDS-DMA instruction (64 lanes x 16 B)
+#define DP_SPAN (DP_RING / 2 - 256u)  // row span of one sub-chunk: the next one is always resident too
+#define DP_XN 704u                    // long-run shortcut staging: 384 cells
+#define DP_FRONT 64u                  // slack before the ring: masked-off lanes address up to 64 slots back
+#define DP_MIRROR 384u                // the first 3 pieces are mirrored behind the ring: a row never wraps
+
+struct DpParams {
+  const BlockDesc* blocks;
+  u32 block0;              // first block of this launch
+  const uint2* dph;
+  const double* cost;      // [nb_total][320]
+  const double* mincost;   // [nb_total]
+  const double* rows;
+  const u64* row_base;
+  const u64* block_edges;
   u16* la;
+  u64* prof;               // optional [nb_total][8] cycle counters (ZOPFLI_AMD_PROF=1), else null
+};
+
+// One position of the chain on cell register `CS` (round S): the edge values `WV`
+// were preloaded, invalid lanes hold +inf.  MCL = mincost (or -inf on the literal
+// lane: squeeze.c:277-284 has no mincost test) so MCL + cj is mincostaddcostj.
+// "costs[j+k] > mincostaddcostj && newCost < costs[j+k]" (squeeze.c:293,298) as
+// one compare: max(newCost, mincostaddcostj) < costs[j+k] (no NaNs here).
+#define DP_RELAX(CS, LS, WV, MCL)                                           \
+  {                                                                         \
+    const double old_ = (double)(CS);                                       \
+    const double nc_ = (WV) + cj;                    /* squeeze.c:278,297 */ \
+    const bool upd_ = fmax(nc_, (MCL) + cj) < old_;                         \
+    CS = upd_ ? (float)nc_ : CS;                                            \
+    LS = upd_ ? src1 : LS;                                                  \
+  }
+
+// One 1 KiB piece HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: lane i moves 16 B to
+// M0 + 16 i).  Issued as asm so that the compiler does not order every later LDS read
+// behind it with vmcnt(0); the consumer side waits explicitly before a barrier.
+__device__ __forceinline__ void dp_dma_piece(const double* lane_src, u32 lds_byte_off) {
+  u32 keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(lane_src), "s"(lds_byte_off)
+      : "memory");
+}
+
+// Eight consecutive positions p0..p0+7 of a group, none with an edge beyond cell
+// register 1 (TWO) / 0 (!TWO): straight-line code.  The row values are fetched
+// first (one readlane + one ds_read per position and register), then the chain
+// runs on registers only.
+template <bool TWO>
+__device__ __forceinline__ void dp_fast_block(const double* ring0, u32 hdr_v, u32 p0, u32 lane, u32 base,
+                                              double mincost, float& c0, u32& l0, float& c1, u32& l1) {
+  const double kInf = __longlong_as_double(0x7ff0000000000000ll);
+  double w0[8], w1[8], mcl0[8];
+  u32 ke8[8];
+  const u32 d0 = lane - p0 - 1;                         // k - 1 of register 0 at u = 0
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const u32 h = rdlane_u32(hdr_v, p0 + u);
+    ke8[u] = h >> 16;
+    const double* row = ring0 + (h & 0xffffu) - (p0 + u + 1);   // row[lane] = edge k = lane - p
+    w0[u] = row[lane];
+    if (TWO) w1[u] = row[lane + 64];
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const u32 km1 = d0 - u;
+    w0[u] = km1 < ke8[u] ? w0[u] : kInf;
+    mcl0[u] = km1 == 0 ? -kInf : mincost;
+    if (TWO) w1[u] = km1 + 64 < ke8[u] ? w1[u] : kInf;
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const u32 p = p0 + u;
+    const double cj = (double)rdlane_f32(c0, p);
+    const u32 src1 = base + p + 1;
+    DP_RELAX(c0, l0, w0[u], mcl0[u])
+    if (TWO) {
+      const double mcl1 = lane + 63u == p ? -kInf : mincost;   // position 63's literal edge
+      DP_RELAX(c1, l1, w1[u], mcl1)
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_dp(DpParams P) {
+  __shared__ __align__(16) double s_ring[DP_FRONT + DP_RING + DP_MIRROR];
+  __shared__ float s_xc[DP_XN];
+  __shared__ u16 s_xl[DP_XN];
+
+  const u32 b = P.block0 + blockIdx.x;
+  const BlockDesc bd = P.blocks[b];
+  const u32 B = (u32)(bd.inend - bd.instart);
+  const u32 lane = threadIdx.x;
+  if (B == 0) return;
+  const uint2* dbase = P.dph + bd.pos_off;
+  u16* la = P.la + bd.la_off;
+  const double* rows = P.rows + P.row_base[b];
+  const u32 total_pad = (u32)((P.block_edges[b] + DP_PIECE - 1) & ~(u64)(DP_PIECE - 1));
+
+  const double mincost = P.mincost[b];
+  // squeeze.c:260: cost of (length 258, dist 1) = (0 + 0) + ll[285] + d[0]
+  const double symbolcost258 = (double)(0 + 0) + P.cost[(u64)b * 320 + 285] + P.cost[(u64)b * 320 + 288];
+  const double kInf = __longlong_as_double(0x7ff0000000000000ll);
+  const u32 ring_lds = (u32)(unsigned long)(__attribute__((address_space(3))) double*)s_ring;
+
+  u64 t_stage = 0, t_chain = 0, t_mark = 0, n_fast = 0, n_slow = 0;
+  const bool prof = P.prof != nullptr;
+#define DP_TICK() (prof ? (u64)__builtin_readcyclecounter() : 0ull)
+
+  // cost cells of the current group: c[s] of lane l = cell base + 64 s + l; l[s] = 1 + the
+  // position the cell was reached from (0 = never), so length_array = cell + 1 - l[s]
+  float c[6];
+  u32 l[6];
+#pragma unroll
+  for (int s = 0; s < 6; ++s) { c[s] = 1e30f; l[s] = 0; }
+  if (lane == 0) c[0] = 0.0f;
+
+  u32 base = 0;
+  u32 loaded_end = 0;          // rows [.., loaded_end) have been requested into the ring
+  bool noshort = false;        // the reference tests the shortcut once per loop iteration (squeeze.c:247-251)
+  u32 pf_base = 0xffffffffu;
+  uint2 pf_dh = make_uint2(0, 0);
+
+  while (base <= B) {
+    t_mark = DP_TICK();
+    const u32 navail = (B - base < 64u) ? B - base : 64u;
+    const u32 jj = base + lane;
+    const bool act = lane < navail;
+    uint2 dh = pf_dh;
+    if (pf_base != base) dh = dbase[jj < B ? jj : B - 1];   // first group, or a shortcut moved the group start
+    pf_base = base + 64;
+    pf_dh = dbase[jj + 64 < B ? jj + 64 : B - 1];            // next group, one group ahead (clamped, unconditional)
+
+    const u32 kend = act ? (dh.y & 0xffffu) : 0u;
+    const bool sflag = act && (dh.y >> 16) != 0;
+    const u32 roff = dh.x;
+    const u32 offend = roff + kend;
+    const u32 hdr_v = (roff & (DP_RING - 1)) | (kend << 16);
+    const u64 m_short = __ballot(sflag);
+    const u64 m_r1 = __ballot(kend + lane >= 64u);     // position needs cell register 1
+    const u64 m_r2 = __ballot(kend + lane >= 128u);    // ... and 2 or more: generic path
+
+    u32 q = 0;
+    bool regroup = false;
+    while (q < navail) {
+      // ---- sub-chunk: positions q .. q+n-1 whose rows span at most DP_SPAN from a_cur
+      const u32 off_q = rdlane_u32(roff, q);
+      const u32 a_cur = off_q & ~(DP_PIECE - 1);
+      const u64 fit = __ballot(act && lane >= q && offend - a_cur <= DP_SPAN);
+      const u32 n = (u32)__popcll(fit);
+      const u32 need_end = (rdlane_u32(offend, q + n - 1) + DP_PIECE - 1) & ~(DP_PIECE - 1);
+      // everything requested so far has landed; top the ring up to a_cur + DP_RING
+      // (the youngest VMEM op of a group's first sub-chunk is the dph prefetch: leave it in flight)
+      if (q == 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      {
+        const u32 lim = a_cur + DP_RING < total_pad ? a_cur + DP_RING : total_pad;
+        const bool cold = loaded_end < need_end;
+        while (loaded_end < lim) {
+          const u32 slot = loaded_end & (DP_RING - 1);
+          dp_dma_piece(rows + loaded_end + lane * 2, ring_lds + (DP_FRONT + slot) * 8);
+          if (slot < DP_MIRROR) dp_dma_piece(rows + loaded_end + lane * 2, ring_lds + (DP_FRONT + DP_RING + slot) * 8);
+          loaded_end += DP_PIECE;
+        }
+        if (cold) {  // first sub-chunk of the block (or a jump after a shortcut)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+        }
+      }
+      { const u64 t = DP_TICK(); t_stage += t - t_mark; t_mark = t; }
+
+      // ---- the serial chain over positions q .. q+n-1, 8 at a time
+      u32 p0 = q;
+      while (p0 < q + n) {
+        const bool full = p0 + 8 <= q + n;
+        const u32 sbits = (u32)(m_short >> p0) & 255u;
+        const u32 r2bits = (u32)(m_r2 >> p0) & 255u;
+        if (full && sbits == 0 && r2bits == 0) {
+          // ---- fast path: straight-line code, edge values preloaded
+          if (((u32)(m_r1 >> p0) & 255u) != 0) {
+            dp_fast_block<true>(s_ring + DP_FRONT, hdr_v, p0, lane, base, mincost, c[0], l[0], c[1], l[1]);
+          } else {
+            dp_fast_block<false>(s_ring + DP_FRONT, hdr_v, p0, lane, base, mincost, c[0], l[0], c[1], l[1]);
+          }
+          noshort = false;
+          n_fast += 8;
+          p0 += 8;
+          continue;
+        }
+        // ---- generic path (ragged tail, long matches, shortcut candidates)
+        const u32 pend = full ? p0 + 8 : q + n;
+        u32 p = p0;
+        for (; p < pend; ++p) {
+          if (((m_short >> p) & 1) && !noshort) { regroup = true; break; }
+          noshort = false;
+          const u32 ke = rdlane_u32(kend, p);
+          const u32 ro = rdlane_u32(roff, p);
+          const double cj = (double)rdlane_f32(c[0], p);
+          const u32 src1 = base + p + 1;
+          const u32 km1 = lane - p - 1;
+          const u32 smax = (ke + p) >> 6;
+#pragma unroll
+          for (int s = 0; s < 6; ++s) {
+            if ((u32)s <= smax) {
+              const u32 k1 = km1 + 64u * s;
+              if (k1 < ke) {
+                const double w = s_ring[DP_FRONT + ((ro + k1) & (DP_RING - 1))];
+                const double mcl = k1 == 0 ? -kInf : mincost;
+                DP_RELAX(c[s], l[s], w, mcl)
+              }
+            }
+          }
+        }
+        n_slow += p - p0;
+        p0 = p;
+        if (regroup) break;
+      }
+      { const u64 t = DP_TICK(); t_chain += t - t_mark; t_mark = t; }
+      if (regroup) {
+        // ---- long-run shortcut at position p0 of the group (squeeze.c:251-271)
+        const u32 p = p0;
+        const u32 j = base + p;
+        if (lane < p && base + lane >= 1) la[base + lane] = (u16)(l[0] ? base + lane + 1 - l[0] : 0u);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+          const u32 x = base + 64u * s + lane;
+          s_xc[64 * s + lane] = c[s];
+          s_xl[64 * s + lane] = (u16)(l[s] ? x + 1 - l[s] : 0u);
+        }
+        __syncthreads();
+        // costs[j+t+258] = costs[j+t] + symbolcost for t = 0..257, unconditionally; cells
+        // j..j+257 are consumed with the lengths they have now
+        float nc4[5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+          const u32 t = 64u * r + lane;
+          nc4[r] = 1e30f;
+          if (t < ZMX_MAX_MATCH) {
+            la[j + t] = s_xl[p + t];
+            nc4[r] = (float)((double)s_xc[p + t] + symbolcost258);
+          }
+        }
+        // new group at j + 258: cell j+258+t <- nc4 (reached from j+t), everything beyond is untouched
+#pragma unroll
+        for (int s = 0; s < 6; ++s) { c[s] = 1e30f; l[s] = 0; }
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+          const u32 t = 64u * r + lane;
+          if (t < ZMX_MAX_MATCH) { c[r] = nc4[r]; l[r] = j + t + 1; }
+        }
+        base = j + ZMX_MAX_MATCH;
+        noshort = true;   // squeeze.c:273 continues with the match query at the new i
+        // rows between the old and the new position are never read: restart the ring there
+        {
+          const u32 nb_ = base < B ? base : B - 1;
+          const u32 ro = dbase[nb_].x & ~(DP_PIECE - 1);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (ro > loaded_end) loaded_end = ro;
+        }
+        break;
+      }
+      q += n;
+    }
+    if (regroup) continue;
+
+    // ---- group done: cells base..base+63 are final
+    if (jj <= B && jj >= 1) la[jj] = (u16)(l[0] ? jj + 1 - l[0] : 0u);
+#pragma unroll
+    for (int s = 0; s < 5; ++s) { c[s] = c[s + 1]; l[s] = l[s + 1]; }
+    c[5] = 1e30f;
+    l[5] = 0;
+    base += 64;
+  }
+  if (lane == 0) la[0] = 0;
+  if (prof && lane == 0) {
+    u64* o = P.prof + (u64)b * 8;
+    o[0] = t_stage; o[1] = t_chain; o[2] = n_fast; o[3] = n_slow; o[4] = B;
+  }
+}
+
+// ------------------------------------------------------------------ k_trace
+struct TraceParams {
+  const BlockDesc* blocks;
+  u32 block0;
+  const u32* recs;
+  const u32* pool;
+  const u16* la;
+  const int* slot;         // [nb_total]
   u32* store0;
   u32* store1;
   u32* hist_out;
@@ -556,209 +1098,114 @@ struct SqueezeParams {
   u32* flags;              // [1] error bits
 };
 
-__global__ __launch_bounds__(64) void k_squeeze(SqueezeParams P) {
-  __shared__ double s_ll[288];
-  __shared__ double s_d[32];
-  __shared__ float s_cost[RING];
-  __shared__ u16 s_len[RING];
-  __shared__ u32 s_hist[320];
+__global__ __launch_bounds__(64) void k_trace(TraceParams P) {
   __shared__ u16 s_la[TR_CHUNK + 2];
-  __shared__ u32 s_bpos[64];
-  __shared__ u32 s_blen[64];
-  __shared__ u32 s_n, s_idx;
+  __shared__ u32 s_hist[320];
 
-  const u32 b = blockIdx.x;
+  const u32 b = P.block0 + blockIdx.x;
   const BlockDesc bd = P.blocks[b];
   const u32 B = (u32)(bd.inend - bd.instart);
   const u32 lane = threadIdx.x;
   const u32* rbase = P.recs + bd.pos_off * 8;
-  u16* la = P.la + bd.la_off;
+  const u16* la = P.la + bd.la_off;
   u32* sbase = (P.slot[b] ? P.store1 : P.store0) + bd.pos_off;
 
-  for (u32 i = lane; i < 288; i += 64) s_ll[i] = P.cost[(u64)b * 320 + i];
-  if (lane < 32) s_d[lane] = P.cost[(u64)b * 320 + 288 + lane];
-  for (u32 i = lane; i < RING; i += 64) { s_cost[i] = 1e30f; s_len[i] = 0; }
   for (u32 i = lane; i < 320; i += 64) s_hist[i] = 0;
   __syncthreads();
-  if (B == 0) {
-    for (u32 i = lane; i < 320; i += 64) P.hist_out[(u64)b * 320 + i] = 0;
-    if (lane == 0) P.nsym_out[b] = 0;
-    return;
-  }
-  if (lane == 0) { s_cost[0] = 0.0f; la[0] = 0; }
-  __syncthreads();
 
-  const double mincost = P.mincost[b];
-  // per-lane constants for k = 64 r + lane + 1 (k = 1 is the literal edge)
-  int k_lbits[5];
-  double k_ll[5];
-#pragma unroll
-  for (int r = 0; r < 5; ++r) {
-    const u32 k = 64u * r + lane + 1;
-    if (k >= 3 && k <= ZMX_MAX_MATCH) {
-      k_lbits[r] = dev_length_extra_bits(k);
-      k_ll[r] = s_ll[dev_length_symbol(k)];
-    } else {
-      k_lbits[r] = 0;
-      k_ll[r] = 0.0;
-    }
-  }
-  // squeeze.c:260: cost of (length 258, dist 1) = (0 + 0) + ll[285] + d[0]
-  const double symbolcost258 = (double)(0 + 0) + s_ll[285] + s_d[0];
+  // TraceBackwards (squeeze.c:317): the walk is a chain of dependent reads.  64 cells of
+  // length_array sit in one VGPR (lane i = cell wb + i), a step is v_readlane + s_sub, the
+  // symbol start goes to lane n of pos_v.  Every 64 symbols the lanes resolve
+  // FollowPath (squeeze.c:338: dist = sublen[length] of the match record, A.2-6) in
+  // parallel; the record loads of one batch are in flight while the next batch is walked.
+  u32 head = B, total = 0;
+  u32 lo = 0, hi = 0;             // cells [lo, hi] are staged in s_la
+  u32 wb = 0xffffffffu;           // window base
+  u32 la_v = 0;
+  // pending batch (records requested, not yet resolved)
+  u32 pend_n = 0, pend_total = 0, pend_pos = 0, pend_len = 0;
+  uint4 pend_ra = make_uint4(0, 0, 0, 0), pend_rb = make_uint4(0, 0, 0, 0);
+  bool bad = false;
 
-  u32 j = 0;
-  bool allow_shortcut = true;  // the reference tests the shortcut once per loop iteration (squeeze.c:247-251)
-  while (j < B) {
-    // record of position j (uniform address -> broadcast load)
-    const uint4 ra = *reinterpret_cast<const uint4*>(rbase + (u64)j * 8);
-    u32 leng = __builtin_amdgcn_readfirstlane(ra.x) & 0xffffu;
-    const u32 d1 = __builtin_amdgcn_readfirstlane(ra.y);
-    const u32 same_i = d1 & 0xffffu;
-
-    // ---- long-run shortcut (squeeze.c:251-271): i > instart + 259, i + 517 < inend
-    if (allow_shortcut && same_i > 2 * ZMX_MAX_MATCH && j > ZMX_MAX_MATCH + 1 && j + 2 * ZMX_MAX_MATCH + 1 < B) {
-      const u32 same_back = __builtin_amdgcn_readfirstlane(rbase[(u64)(j - ZMX_MAX_MATCH) * 8 + 1]) & 0xffffu;
-      if (same_back > ZMX_MAX_MATCH) {
-        // costs[j+t+258] = costs[j+t] + symbolcost for t = 0..257 (reads and writes are disjoint),
-        // cells j..j+257 are consumed: their lengths are final.
-        __syncthreads();
-        for (u32 t = lane; t < ZMX_MAX_MATCH; t += 64) {
-          const float c = s_cost[(j + t) & RMASK];
-          if (j + t >= 1) la[j + t] = s_len[(j + t) & RMASK];
-          s_cost[(j + t + ZMX_MAX_MATCH) & RMASK] = (float)((double)c + symbolcost258);
-          s_len[(j + t + ZMX_MAX_MATCH) & RMASK] = (u16)ZMX_MAX_MATCH;
+  for (;;) {
+    // ---- walk up to 64 symbols
+    u32 n = 0;
+    u32 pos_v = 0;
+    const u32 start_head = head;
+    while (n < 64 && head > 0 && !bad) {
+      if (wb == 0xffffffffu || head < wb) {
+        wb = head > 63 ? head - 63 : 0;
+        if (hi == 0 || wb < lo) {   // restage [lo, head]
+          lo = head > TR_CHUNK ? head - TR_CHUNK : 0;
+          hi = head;
+          __syncthreads();
+          for (u32 t = lane; t <= hi - lo; t += 64) s_la[t] = la[lo + t];
+          __syncthreads();
         }
-        __syncthreads();
-        for (u32 t = lane; t < ZMX_MAX_MATCH; t += 64) s_cost[(j + t) & RMASK] = 1e30f;  // slots recycle
-        __syncthreads();
-        j += ZMX_MAX_MATCH;
-        allow_shortcut = false;  // squeeze.c:273 continues with the match query at the new i
-        continue;
+        la_v = wb + lane <= hi ? (u32)s_la[wb + lane - lo] : 0u;
       }
-    }
-
-    // ---- cell j becomes final
-    const float cjf = s_cost[j & RMASK];
-    if (lane == 0 && j >= 1) la[j] = s_len[j & RMASK];
-    __syncthreads();
-    if (lane == 0) s_cost[j & RMASK] = 1e30f;
-    const double cj = (double)cjf;
-    const double mincostaddcostj = mincost + cj;     // squeeze.c:287
-    const u32 lit = (d1 >> 16) & 255u;
-    const u32 ncpf = d1 >> 24;
-    const uint4 rb = *reinterpret_cast<const uint4*>(rbase + (u64)j * 8 + 4);
-
-    // change points as uniform values
-    u32 w[6] = {ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
-    if (leng > B - j) leng = B - j;                  // squeeze.c:286 kend
-    const u32 rounds = leng < 3 ? 1u : (leng + 63u) / 64u;
-    for (u32 r = 0; r < rounds; ++r) {
-      const u32 k = 64u * r + lane + 1;
-      const bool is_lit = (k == 1);
-      const bool is_match = (k >= 3 && k <= leng);
-      if (is_lit || is_match) {
-        const u32 cell = (j + k) & RMASK;
-        const float oldf = s_cost[cell];
-        const double old = (double)oldf;
-        double newCost;
-        bool consider = true;
-        if (is_lit) {
-          newCost = s_ll[lit] + cj;                  // squeeze.c:278
-        } else {
-          if (old <= mincostaddcostj) consider = false;  // squeeze.c:293
-          // sublen[k]
-          u32 mydist = 0;
-          if (ncpf != 0xffu) {
-#pragma unroll
-            for (int e = 7; e >= 0; --e) {
-              if ((u32)e < ncpf) {
-                const u32 bit = 24u * e;
-                const u32 lo = w[bit >> 5] >> (bit & 31);
-                const u32 v = (bit & 31) > 8 ? (lo | (w[(bit >> 5) + ((bit >> 5) < 5 ? 1 : 0)] << (32 - (bit & 31)))) : lo;
-                const u32 clen = (v & 255u) + 3u;
-                const u32 cdist = (v >> 8) & 0xffffu;
-                if (k <= clen) mydist = cdist;
-              }
-            }
-          } else {
-            const u32 off = w[0], n = w[1] & 0xffffu;
-            for (u32 e = n; e-- > 0;) {
-              const u32 x = P.pool[off + e];
-              if (k <= (x & 0xffffu)) mydist = x >> 16;
-            }
-          }
-          int lb, rr = (int)r;
-          double kl;
-          // select per-round constants without dynamic register indexing
-          lb = rr == 0 ? k_lbits[0] : rr == 1 ? k_lbits[1] : rr == 2 ? k_lbits[2] : rr == 3 ? k_lbits[3] : k_lbits[4];
-          kl = rr == 0 ? k_ll[0] : rr == 1 ? k_ll[1] : rr == 2 ? k_ll[2] : rr == 3 ? k_ll[3] : k_ll[4];
-          // squeeze.c:155: (lbits + dbits) as int, then + ll, then + d
-          const double c = ((double)(lb + dev_dist_extra_bits(mydist)) + kl) + s_d[dev_dist_symbol(mydist)];
-          newCost = c + cj;                          // squeeze.c:297
-        }
-        if (consider && newCost < old) {
-          s_cost[cell] = (float)newCost;
-          s_len[cell] = (u16)k;
-        }
-      }
-    }
-    __syncthreads();
-    ++j;
-    allow_shortcut = true;
-  }
-  // cell B
-  if (lane == 0) la[B] = s_len[B & RMASK];
-  __threadfence();
-  __syncthreads();
-
-  // ---- TraceBackwards + FollowPath: walk length_array from the end in LDS
-  //      chunks; every 64 steps the lanes resolve distances in parallel and
-  //      write the symbols back to front.
-  u32 idx = B, total = 0;
-  u32 lo = 0;
-  bool have_chunk = false;
-  while (idx > 0) {
-    if (!have_chunk || (lo > 0 && idx < lo + ZMX_MAX_MATCH)) {
-      lo = idx > TR_CHUNK ? idx - TR_CHUNK : 0;
-      __syncthreads();
-      for (u32 t = lane; t <= idx - lo; t += 64) s_la[t] = la[lo + t];
-      have_chunk = true;
-      __syncthreads();
-    }
-    if (lane == 0) {
-      u32 n = 0, cur = idx;
-      while (n < 64 && cur > 0 && cur >= lo) {
-        const u32 len = s_la[cur - lo];
-        if (len == 0 || len > cur) { atomicOr(&P.flags[1], 2u); cur = 0; break; }
-        s_bpos[n] = cur - len;
-        s_blen[n] = len;
-        cur -= len;
+      while (n < 64 && head > 0 && head >= wb) {
+        const u32 len = rdlane_u32(la_v, head - wb);
+        if (len - 1 >= head) { bad = true; break; }    // 0 or longer than the prefix: corrupt
+        head -= len;
+        pos_v = lane == n ? head : pos_v;
         ++n;
       }
-      s_n = n;
-      s_idx = cur;
     }
-    __syncthreads();
-    const u32 n = s_n;
-    if (lane < n) {
-      const u32 pos = s_bpos[lane], len = s_blen[lane];
-      const u32* rec = rbase + (u64)pos * 8;
-      u32 e;
-      if (len >= 3) {
-        const u32 dist = rec_dist_for(rec, P.pool, len);
-        e = len | (dist << 16);
-        if (dist == 0) atomicOr(&P.flags[1], 4u);
-      } else {
-        e = (rec[1] >> 16) & 255u;
+    // ---- resolve the pending batch
+    if (pend_n) {
+      if (lane < pend_n) {
+        u32 e;
+        const u32 d1 = pend_ra.y;
+        if (pend_len >= 3) {
+          const u32 ncpf = d1 >> 24;
+          u32 dist = 0;
+          if (ncpf != 0xffu) {
+            const u32 w[6] = {pend_ra.z, pend_ra.w, pend_rb.x, pend_rb.y, pend_rb.z, pend_rb.w};
+#pragma unroll
+            for (int k = 7; k >= 0; --k) {
+              const u32 bit = 24u * k;
+              const u32 lo32 = w[bit >> 5] >> (bit & 31);
+              const u32 v = (bit & 31) > 8 ? (lo32 | (w[(bit >> 5) + 1 > 5 ? 5 : (bit >> 5) + 1] << (32 - (bit & 31)))) : lo32;
+              if ((u32)k < ncpf && (v & 255u) + 3u >= pend_len) dist = (v >> 8) & 0xffffu;
+            }
+          } else {
+            const u32 off = pend_ra.z, cnt = pend_ra.w & 0xffffu;
+            u32 plo = 0, phi = cnt;   // first entry with len >= pend_len
+            while (plo < phi) {
+              const u32 mid = (plo + phi) >> 1;
+              if ((P.pool[off + mid] & 0xffffu) < pend_len) plo = mid + 1; else phi = mid;
+            }
+            if (plo < cnt) dist = P.pool[off + plo] >> 16;
+          }
+          e = pend_len | (dist << 16);
+          if (dist == 0) atomicOr(&P.flags[1], 4u);
+        } else {
+          e = (d1 >> 16) & 255u;
+        }
+        sbase[B - 1 - (pend_total + lane)] = e;
+        hist_add_symbol(s_hist, e & 0xffffu, e >> 16);
       }
-      sbase[B - 1 - (total + lane)] = e;
-      hist_add_symbol(s_hist, e & 0xffffu, e >> 16);
+      pend_n = 0;
     }
-    total += n;
-    idx = s_idx;
-    __syncthreads();
-    if (n == 0) break;  // error path only
+    if (n == 0) break;
+    // ---- request the records of the batch just walked
+    {
+      u32 prev = __shfl_up(pos_v, 1);
+      if (lane == 0) prev = start_head;
+      pend_n = n;
+      pend_total = total;
+      pend_pos = pos_v;
+      pend_len = prev - pos_v;
+      if (lane < n) {
+        const u32* rec = rbase + (u64)pos_v * 8;
+        pend_ra = *reinterpret_cast<const uint4*>(rec);
+        pend_rb = *reinterpret_cast<const uint4*>(rec + 4);
+      }
+      total += n;
+    }
   }
+  if (bad && lane == 0) atomicOr(&P.flags[1], 2u);
   __syncthreads();
   for (u32 i = lane; i < 320; i += 64) P.hist_out[(u64)b * 320 + i] = s_hist[i];
   if (lane == 0) P.nsym_out[b] = total;

@@ -31,41 +31,6 @@ MB = 1000000
 WINDOW = 32768
 
 
-def crc32_combine(crc1, crc2, len2):
-    """zlib's crc32_combine (GF(2) matrix method)."""
-    def times(mat, vec):
-        s, i = 0, 0
-        while vec:
-            if vec & 1:
-                s ^= mat[i]
-            vec >>= 1
-            i += 1
-        return s
-
-    def square(mat):
-        return [times(mat, mat[n]) for n in range(32)]
-
-    if len2 <= 0:
-        return crc1
-    odd = [0xedb88320] + [1 << n for n in range(31)]
-    even = square(odd)
-    odd = square(even)
-    while True:
-        even = square(odd)
-        if len2 & 1:
-            crc1 = times(even, crc1)
-        len2 >>= 1
-        if not len2:
-            break
-        odd = square(even)
-        if len2 & 1:
-            crc1 = times(odd, crc1)
-        len2 >>= 1
-        if not len2:
-            break
-    return crc1 ^ crc2
-
-
 def cpu_baseline(sample, options):
     """The real reference (oracle/_ref, -O3 -DNDEBUG) on one host core, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -101,7 +66,8 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from zopfli_amd import Context, ZopfliOptions, api, generate
+    from zopfli_amd import Context, ZopfliOptions, api, generate, sharding
+    from zopfli_amd.sharding import crc32_combine
 
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -126,27 +92,11 @@ def main():
     header = bytes([31, 139, 8, 0, 0, 0, 0, 0, 2, 3])
 
     def gather_blobs(blob):
-        if world == 1:
-            return [blob]
-        n = torch.tensor([len(blob)], dtype=torch.int64, device=device)
-        sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-        dist.all_gather(sizes, n)
-        cap = int(max(int(s.item()) for s in sizes))
-        buf = torch.zeros(cap, dtype=torch.uint8, device=device)
-        buf[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
-        out = [torch.empty(cap, dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
-        dist.gather(buf, out, dst=0)
-        if rank != 0:
-            return None
-        return [out[r][:int(sizes[r].item())].cpu().numpy().tobytes() for r in range(world)]
+        return sharding.gather_bytes(blob, rank, world, device, dist)   # one RCCL gather over xGMI
 
     def gather_crc(crc):
-        if world == 1:
-            return [crc]
-        t = torch.tensor([crc], dtype=torch.int64, device=device)
-        outs = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-        dist.all_gather(outs, t)
-        return [int(o.item()) for o in outs]
+        parts = sharding.gather_bytes(crc.to_bytes(4, "little"), rank, world, device, dist)
+        return None if parts is None else [int.from_bytes(p, "little") for p in parts]
 
     timing_acc = {}
 

@@ -3,8 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
-typedef unsigned int u32;
-typedef unsigned long long u64;
+#include "../zopfli_amd/csrc/device/zmx_kernels.h"
 #define N 4096
 
 __global__ void k_add_f64(double* out, u64* cyc, double x) {
@@ -114,6 +113,100 @@ __global__ void k_add_f64_tp(double* out, u64* cyc, double x) {
   out[threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7; if (threadIdx.x == 0) cyc[0] = t1 - t0;
 }
 
+
+// the real fast block of k_dp on synthetic rows (ke = 8 everywhere): full / fetch only / chain only
+template <int MODE>
+__global__ void k_fast_block(float* out, u64* cyc, double mincost) {
+  __shared__ double ring[DP_FRONT + DP_RING + DP_MIRROR];
+  const u32 lane = threadIdx.x;
+  for (u32 i = lane; i < DP_FRONT + DP_RING + DP_MIRROR; i += 64) ring[i] = 3.0 + (i & 7);
+  __syncthreads();
+  const u32 hdr_v = ((lane * 8) & (DP_RING - 1)) | (8u << 16);
+  __shared__ uint2 tab[64];
+  tab[lane] = make_uint2((((lane * 8) & (DP_RING - 1)) - lane - 1) * 8u, 8u);
+  __syncthreads();
+  float c0 = lane == 0 ? 0.0f : 1e30f, c1 = 1e30f;
+  u32 l0 = 0, l1 = 0;
+  u64 t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < N / 8; ++it) {
+    const u32 p0 = (it & 7) * 8;
+    if (MODE == 0) {
+      dp_fast_block<false>(ring + DP_FRONT, tab, p0, lane, 0, mincost, c0, l0, c1, l1);
+    } else if (MODE == 1) {   // fetch + masks only
+      const double kInf = __longlong_as_double(0x7ff0000000000000ll);
+      double acc = 0;
+      const u32 d0 = lane - p0 - 1;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint2 t = tab[p0 + u];
+        const double* row = reinterpret_cast<const double*>(reinterpret_cast<const char*>(ring + DP_FRONT) + (int)t.x);
+        const u32 km1 = d0 - u;
+        const double w = km1 < t.y ? row[lane] : kInf;
+        const double m = km1 == 0 ? -kInf : mincost;
+        acc = fmax(acc, fmin(w, m));
+      }
+      c0 = (float)acc;
+    } else {                  // chain only
+      const double w = 3.5, m = mincost;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const u32 p = p0 + u;
+        const double cj = (double)rdlane_f32(c0, p);
+        const u32 src1 = p + 1;
+        DP_RELAX(c0, l0, w, m)
+      }
+    }
+  }
+  u64 t1 = __builtin_readcyclecounter();
+  out[lane] = c0 + c1 + (float)(l0 + l1); if (lane == 0) cyc[0] = t1 - t0;
+}
+// independent integer VALU ops (issue rate of a lone wave)
+__global__ void k_int_tp(u32* out, u64* cyc, u32 x) {
+  u32 a0 = out[threadIdx.x], a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  u64 t0 = __builtin_readcyclecounter();
+#pragma unroll 4
+  for (int i = 0; i < N / 8; ++i) { a0 = a0 * 3 + x; a1 = a1 * 3 + x; a2 = a2 * 3 + x; a3 = a3 * 3 + x; a4 = a4 * 3 + x; a5 = a5 * 3 + x; a6 = a6 * 3 + x; a7 = a7 * 3 + x; }
+  u64 t1 = __builtin_readcyclecounter();
+  out[threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7; if (threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+// independent readlanes feeding VALU
+__global__ void k_readlane_tp(u32* out, u64* cyc) {
+  u32 a = out[threadIdx.x], acc = 0;
+  u64 t0 = __builtin_readcyclecounter();
+#pragma unroll 8
+  for (int i = 0; i < N; ++i) acc += rdlane_u32(a, i & 63) ^ i;
+  u64 t1 = __builtin_readcyclecounter();
+  out[threadIdx.x] = acc; if (threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+// the consumer of k_dp2 on one ready-made tile (variant 0), alone on its CU
+__global__ void k_consumer(float* out, u64* cyc, double mincost) {
+  __shared__ double tile[16 * 64];
+  const u32 lane = threadIdx.x;
+  const double kInf = __longlong_as_double(0x7ff0000000000000ll);
+  for (u32 i = lane; i < 16 * 64; i += 64) tile[i] = (i & 63) > (i >> 6) && (i & 63) < (i >> 6) + 9 ? 3.0 + (i & 7) : kInf;
+  __syncthreads();
+  float c0 = lane == 0 ? 0.0f : 1e30f;
+  u32 l0 = 0;
+  u64 t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < N / 8; ++it) {
+    const u32 pg0 = (it & 7) * 8, base = it * 8;
+    double wv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) wv[u] = tile[u * 64 + lane];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const u32 p = pg0 + u;
+      const double cj = (double)rdlane_f32(c0, p);
+      const u32 src1 = base + p + 1;
+      const bool lit = __builtin_amdgcn_inverse_ballot_w64(2ull << p);
+      D2_RELAX(c0, l0, wv[u], lit)
+    }
+  }
+  u64 t1 = __builtin_readcyclecounter();
+  out[lane] = c0 + (float)l0; if (lane == 0) cyc[0] = t1 - t0;
+}
+
 int main() {
   double* d; float* f; u32* u; u64* cyc; double* w;
   hipMalloc(&d, 64 * 8); hipMalloc(&f, 64 * 4); hipMalloc(&u, 64 * 4); hipMalloc(&cyc, 8); hipMalloc(&w, 64 * 8);
@@ -139,5 +232,11 @@ int main() {
   RUN(k_step_v2, f, cyc, w, 2.0)
   RUN(k_lit_chain, d, cyc, w, 2.0)
   RUN(k_lds_chase, u, cyc)
+  RUN(k_int_tp, u, cyc, 5u)
+  RUN(k_readlane_tp, u, cyc)
+  RUN(k_fast_block<0>, f, cyc, 2.0)
+  RUN(k_fast_block<1>, f, cyc, 2.0)
+  RUN(k_fast_block<2>, f, cyc, 2.0)
+  RUN(k_consumer, f, cyc, 2.0)
   return 0;
 }

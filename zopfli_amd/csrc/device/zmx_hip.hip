@@ -10,6 +10,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "zmx_kernels.h"
@@ -58,6 +59,11 @@ struct zmx_ctx {
   u32* d_scratch = nullptr;  // k_match per-lane overflow change points
   double* d_rows = nullptr;  // DP edge costs of the blocks of one k_edges/k_dp launch (grow-only)
   size_t rows_cap = 0;
+  // table arrays are recycled between batches and calls: hipMalloc/hipFree of multi-GB arrays
+  // cost more than the kernels that fill them
+  std::unordered_map<void*, size_t> pool_live;
+  std::vector<std::pair<void*, size_t>> pool_free;
+  size_t pool_free_bytes = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -96,6 +102,61 @@ struct zmx_tables {
   std::vector<u32> probe_pool;
   bool probe_pool_ready = false;
 };
+
+namespace {
+
+constexpr size_t kPoolKeepBytes = 96ull << 30;
+
+hipError_t PoolAllocBytes(zmx_ctx* c, void** p, size_t bytes) {
+  if (bytes == 0) bytes = 1;
+  size_t best = c->pool_free.size();
+  for (size_t i = 0; i < c->pool_free.size(); ++i) {
+    const size_t cap = c->pool_free[i].second;
+    if (cap >= bytes && cap <= 2 * bytes + (1u << 20) && (best == c->pool_free.size() || cap < c->pool_free[best].second)) {
+      best = i;
+    }
+  }
+  if (best != c->pool_free.size()) {
+    *p = c->pool_free[best].first;
+    c->pool_live[*p] = c->pool_free[best].second;
+    c->pool_free_bytes -= c->pool_free[best].second;
+    c->pool_free.erase(c->pool_free.begin() + static_cast<long>(best));
+    return hipSuccess;
+  }
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess && !c->pool_free.empty()) {  // out of memory: drop the cache and retry
+    for (auto& f : c->pool_free) (void)hipFree(f.first);
+    c->pool_free.clear();
+    c->pool_free_bytes = 0;
+    e = hipMalloc(p, bytes);
+  }
+  if (e == hipSuccess) c->pool_live[*p] = bytes;
+  return e;
+}
+
+template <typename T>
+hipError_t PoolAlloc(zmx_ctx* c, T** p, size_t n) {
+  return PoolAllocBytes(c, reinterpret_cast<void**>(p), (n ? n : 1) * sizeof(T));
+}
+
+void PoolFree(zmx_ctx* c, void* p) {
+  if (!p) return;
+  if (c) {
+    auto it = c->pool_live.find(p);
+    if (it != c->pool_live.end()) {
+      const size_t cap = it->second;
+      c->pool_live.erase(it);
+      if (c->pool_free_bytes + cap <= kPoolKeepBytes) {
+        c->pool_free.emplace_back(p, cap);
+        c->pool_free_bytes += cap;
+        return;
+      }
+    }
+  }
+  (void)hipFree(p);
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -146,6 +207,8 @@ void zmx_ctx_destroy(zmx_ctx* c) {
   (void)hipFree(c->d_in);
   (void)hipFree(c->d_scratch);
   (void)hipFree(c->d_rows);
+  for (auto& f : c->pool_free) (void)hipFree(f.first);
+  for (auto& f : c->pool_live) (void)hipFree(f.first);
   for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -170,26 +233,26 @@ int zmx_set_input(zmx_ctx* c, const unsigned char* in, size_t insize) {
 void zmx_tables_free(zmx_ctx* c, zmx_tables* t) {
   if (!t) return;
   if (c) (void)hipSetDevice(c->device);
-  (void)hipFree(t->d_blocks);
-  (void)hipFree(t->d_tile_off);
-  (void)hipFree(t->d_same16);
-  (void)hipFree(t->d_links);
-  (void)hipFree(t->d_recs);
-  (void)hipFree(t->d_pool);
-  (void)hipFree(t->d_la);
-  (void)hipFree(t->d_store[0]);
-  (void)hipFree(t->d_store[1]);
-  (void)hipFree(t->d_hist);
-  (void)hipFree(t->d_nsym);
-  (void)hipFree(t->d_cost);
-  (void)hipFree(t->d_mincost);
-  (void)hipFree(t->d_slot);
-  (void)hipFree(t->d_dph);
-  (void)hipFree(t->d_block_edges);
-  (void)hipFree(t->d_row_base);
-  (void)hipFree(t->d_counters);
-  (void)hipFree(t->d_flags);
-  (void)hipFree(t->d_prof);
+  PoolFree(c, t->d_blocks);
+  PoolFree(c, t->d_tile_off);
+  PoolFree(c, t->d_same16);
+  PoolFree(c, t->d_links);
+  PoolFree(c, t->d_recs);
+  PoolFree(c, t->d_pool);
+  PoolFree(c, t->d_la);
+  PoolFree(c, t->d_store[0]);
+  PoolFree(c, t->d_store[1]);
+  PoolFree(c, t->d_hist);
+  PoolFree(c, t->d_nsym);
+  PoolFree(c, t->d_cost);
+  PoolFree(c, t->d_mincost);
+  PoolFree(c, t->d_slot);
+  PoolFree(c, t->d_dph);
+  PoolFree(c, t->d_block_edges);
+  PoolFree(c, t->d_row_base);
+  PoolFree(c, t->d_counters);
+  PoolFree(c, t->d_flags);
+  PoolFree(c, t->d_prof);
   delete t;
 }
 
@@ -226,24 +289,24 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   t->tile_off = tile_off;
   if (nb == 0) return 0;
 
-  HIPCHK(DevAlloc(&t->d_blocks, nb));
-  HIPCHK(DevAlloc(&t->d_tile_off, nb + 1));
-  HIPCHK(DevAlloc(&t->d_same16, reg_off));
-  HIPCHK(DevAlloc(&t->d_links, reg_off));
-  HIPCHK(DevAlloc(&t->d_recs, pos_off * 8));
-  HIPCHK(DevAlloc(&t->d_la, la_off));
-  HIPCHK(DevAlloc(&t->d_store[0], pos_off));
-  HIPCHK(DevAlloc(&t->d_store[1], pos_off));
-  HIPCHK(DevAlloc(&t->d_hist, nb * ZMX_HIST));
-  HIPCHK(DevAlloc(&t->d_nsym, nb));
-  HIPCHK(DevAlloc(&t->d_cost, nb * ZMX_HIST));
-  HIPCHK(DevAlloc(&t->d_mincost, nb));
-  HIPCHK(DevAlloc(&t->d_slot, nb));
-  HIPCHK(DevAlloc(&t->d_dph, pos_off));
-  HIPCHK(DevAlloc(&t->d_block_edges, nb));
-  HIPCHK(DevAlloc(&t->d_row_base, nb));
-  HIPCHK(DevAlloc(&t->d_counters, 16));
-  HIPCHK(DevAlloc(&t->d_flags, 4));
+  HIPCHK(PoolAlloc(c, &t->d_blocks, nb));
+  HIPCHK(PoolAlloc(c, &t->d_tile_off, nb + 1));
+  HIPCHK(PoolAlloc(c, &t->d_same16, reg_off));
+  HIPCHK(PoolAlloc(c, &t->d_links, reg_off));
+  HIPCHK(PoolAlloc(c, &t->d_recs, pos_off * 8));
+  HIPCHK(PoolAlloc(c, &t->d_la, la_off));
+  HIPCHK(PoolAlloc(c, &t->d_store[0], pos_off));
+  HIPCHK(PoolAlloc(c, &t->d_store[1], pos_off));
+  HIPCHK(PoolAlloc(c, &t->d_hist, nb * ZMX_HIST));
+  HIPCHK(PoolAlloc(c, &t->d_nsym, nb));
+  HIPCHK(PoolAlloc(c, &t->d_cost, nb * ZMX_HIST));
+  HIPCHK(PoolAlloc(c, &t->d_mincost, nb));
+  HIPCHK(PoolAlloc(c, &t->d_slot, nb));
+  HIPCHK(PoolAlloc(c, &t->d_dph, pos_off));
+  HIPCHK(PoolAlloc(c, &t->d_block_edges, nb));
+  HIPCHK(PoolAlloc(c, &t->d_row_base, nb));
+  HIPCHK(PoolAlloc(c, &t->d_counters, 16));
+  HIPCHK(PoolAlloc(c, &t->d_flags, 4));
   HIPCHK(hipMemcpyAsync(t->d_blocks, t->blocks.data(), nb * sizeof(BlockDesc), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(t->d_tile_off, tile_off.data(), (nb + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemsetAsync(t->d_flags, 0, 4 * sizeof(u32), c->stream));
@@ -265,9 +328,9 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   for (;;) {
     u64 cap = std::max<u64>(pos_off * per_pos, 1u << 16);
     if (cap > 0xfffffff0ull) cap = 0xfffffff0ull;
-    if (t->d_pool) HIPCHK(hipFree(t->d_pool));
+    PoolFree(c, t->d_pool);
     t->d_pool = nullptr;
-    HIPCHK(DevAlloc(&t->d_pool, cap));
+    HIPCHK(PoolAlloc(c, &t->d_pool, cap));
     t->pool_cap = static_cast<u32>(cap);
     HIPCHK(hipMemsetAsync(t->d_counters, 0, 16 * sizeof(u32), c->stream));
     MatchParams mp;
@@ -387,7 +450,7 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     c->rows_cap = t->max_range_rows;
   }
   static const bool want_prof = std::getenv("ZOPFLI_AMD_PROF") != nullptr;
-  if (want_prof && !t->d_prof) HIPCHK(DevAlloc(&t->d_prof, t->nb * 8));
+  if (want_prof && !t->d_prof) HIPCHK(PoolAlloc(c, &t->d_prof, t->nb * 16));
   EdgeParams ep;
   ep.blocks = t->d_blocks;
   ep.tile_off = t->d_tile_off;
@@ -419,6 +482,7 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   tp.hist_out = t->d_hist;
   tp.nsym_out = t->d_nsym;
   tp.flags = t->d_flags;
+  tp.prof = t->d_prof;
   double ksec[3] = {0, 0, 0};
   for (const auto& r : t->ranges) {
     const unsigned nblk = r.second - r.first;
@@ -430,7 +494,9 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     if (tiles) hipLaunchKernelGGL(k_edges, dim3(tiles), dim3(256), 0, c->stream, ep);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
-    hipLaunchKernelGGL(k_dp, dim3(nblk), dim3(64), 0, c->stream, cp);
+    static const bool old_dp = [] { const char* e = std::getenv("ZOPFLI_AMD_DP"); return e && e[0] == '1'; }();
+    if (old_dp) hipLaunchKernelGGL(k_dp, dim3(nblk), dim3(64), 0, c->stream, cp);   // single-wave chain (A/B reference)
+    else hipLaunchKernelGGL(k_dp2, dim3(nblk), dim3(64 * (D2_NP + 1)), 0, c->stream, cp);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
     hipLaunchKernelGGL(k_trace, dim3(nblk), dim3(64), 0, c->stream, tp);
@@ -454,12 +520,14 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   }
   for (size_t b = 0; b < t->nb; ++b) t->store_begin[slot[b]][b] = t->bsize[b] - nsym[b];
   if (t->d_prof) {
-    std::vector<u64> pr(t->nb * 8);
+    std::vector<u64> pr(t->nb * 16);
     HIPCHK(hipMemcpy(pr.data(), t->d_prof, pr.size() * sizeof(u64), hipMemcpyDeviceToHost));
-    double a[5] = {0, 0, 0, 0, 0};
-    for (size_t b = 0; b < t->nb; ++b) for (int k = 0; k < 5; ++k) a[k] += static_cast<double>(pr[b * 8 + k]);
-    std::fprintf(stderr, "squeeze prof: edges %.2f ms chain %.2f ms trace %.2f ms; k_dp cycles/position stage %.1f chain %.1f; fast %.1f%% of %.0f positions\n",
-                 ksec[0] * 1e3, ksec[1] * 1e3, ksec[2] * 1e3, a[0] / a[4], a[1] / a[4], 100.0 * a[2] / (a[2] + a[3] + 1e-9), a[4]);
+    double a[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t b = 0; b < t->nb; ++b) for (int k = 0; k < 12; ++k) a[k] += static_cast<double>(pr[b * 16 + k]);
+    std::fprintf(stderr, "squeeze prof: edges %.2f ms dp %.2f ms trace %.2f ms; k_dp cycles/position stage %.1f chain %.1f (inside fast blocks %.1f); fast %.1f%% (two-register %.1f%%) of %.0f positions; k_trace cycles/symbol walk %.1f resolve %.1f request %.1f (%.0f symbols)\n",
+                 ksec[0] * 1e3, ksec[1] * 1e3, ksec[2] * 1e3, a[0] / a[4], a[1] / a[4], a[5] / a[4],
+                 100.0 * a[2] / (a[2] + a[3] + 1e-9), 100.0 * a[6] / (a[2] + a[3] + 1e-9), a[4],
+                 a[8] / a[11], a[9] / a[11], a[10] / a[11], a[11]);
   }
   return 0;
 }

@@ -837,6 +837,7 @@ struct DpParams {
 // M0 + 16 i).  Issued as asm so that the compiler does not order every later LDS read
 // behind it with vmcnt(0); the consumer side waits explicitly before a barrier.
 __device__ __forceinline__ void dp_dma_piece(const double* lane_src, u32 lds_byte_off) {
+  lds_byte_off = (u32)__builtin_amdgcn_readfirstlane((int)lds_byte_off);   // wave-uniform by construction
   u32 keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -850,18 +851,20 @@ __device__ __forceinline__ void dp_dma_piece(const double* lane_src, u32 lds_byt
 // first (one readlane + one ds_read per position and register), then the chain
 // runs on registers only.
 template <bool TWO>
-__device__ __forceinline__ void dp_fast_block(const double* ring0, u32 hdr_v, u32 p0, u32 lane, u32 base,
+__device__ __forceinline__ void dp_fast_block(const double* ring0, const uint2* tab, u32 p0, u32 lane, u32 base,
                                               double mincost, float& c0, u32& l0, float& c1, u32& l1) {
   const double kInf = __longlong_as_double(0x7ff0000000000000ll);
   double w0[8], w1[8], mcl0[8];
   u32 ke8[8];
   const u32 d0 = lane - p0 - 1;                         // k - 1 of register 0 at u = 0
+  // tab[p] = {byte offset of row[0] from ring0, kend} (an LDS broadcast read: a v_readlane would
+  // cost an SGPR round trip of ~35 cycles per position on a lone wave)
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
-    const u32 h = rdlane_u32(hdr_v, p0 + u);
-    ke8[u] = h >> 16;
-    const double* row = ring0 + (h & 0xffffu) - (p0 + u + 1);   // row[lane] = edge k = lane - p
-    w0[u] = row[lane];
+    const uint2 t = tab[p0 + u];
+    ke8[u] = t.y;
+    const double* row = reinterpret_cast<const double*>(reinterpret_cast<const char*>(ring0) + (int)t.x);
+    w0[u] = row[lane];                                  // row[lane] = edge k = lane - p
     if (TWO) w1[u] = row[lane + 64];
   }
 #pragma unroll
@@ -888,6 +891,7 @@ __global__ __launch_bounds__(64) void k_dp(DpParams P) {
   __shared__ __align__(16) double s_ring[DP_FRONT + DP_RING + DP_MIRROR];
   __shared__ float s_xc[DP_XN];
   __shared__ u16 s_xl[DP_XN];
+  __shared__ uint2 s_tab[64];   // per position of the group: row byte offset from the ring start, kend
 
   const u32 b = P.block0 + blockIdx.x;
   const BlockDesc bd = P.blocks[b];
@@ -905,7 +909,7 @@ __global__ __launch_bounds__(64) void k_dp(DpParams P) {
   const double kInf = __longlong_as_double(0x7ff0000000000000ll);
   const u32 ring_lds = (u32)(unsigned long)(__attribute__((address_space(3))) double*)s_ring;
 
-  u64 t_stage = 0, t_chain = 0, t_mark = 0, n_fast = 0, n_slow = 0;
+  u64 t_stage = 0, t_chain = 0, t_mark = 0, n_fast = 0, n_slow = 0, t_fast = 0, n_two = 0;
   const bool prof = P.prof != nullptr;
 #define DP_TICK() (prof ? (u64)__builtin_readcyclecounter() : 0ull)
 
@@ -937,7 +941,8 @@ __global__ __launch_bounds__(64) void k_dp(DpParams P) {
     const bool sflag = act && (dh.y >> 16) != 0;
     const u32 roff = dh.x;
     const u32 offend = roff + kend;
-    const u32 hdr_v = (roff & (DP_RING - 1)) | (kend << 16);
+    __syncthreads();   // the previous group's table is dead
+    s_tab[lane] = make_uint2(((roff & (DP_RING - 1)) - lane - 1) * 8u, kend);
     const u64 m_short = __ballot(sflag);
     const u64 m_r1 = __ballot(kend + lane >= 64u);     // position needs cell register 1
     const u64 m_r2 = __ballot(kend + lane >= 128u);    // ... and 2 or more: generic path
@@ -980,11 +985,14 @@ __global__ __launch_bounds__(64) void k_dp(DpParams P) {
         const u32 r2bits = (u32)(m_r2 >> p0) & 255u;
         if (full && sbits == 0 && r2bits == 0) {
           // ---- fast path: straight-line code, edge values preloaded
+          const u64 tf0 = DP_TICK();
           if (((u32)(m_r1 >> p0) & 255u) != 0) {
-            dp_fast_block<true>(s_ring + DP_FRONT, hdr_v, p0, lane, base, mincost, c[0], l[0], c[1], l[1]);
+            dp_fast_block<true>(s_ring + DP_FRONT, s_tab, p0, lane, base, mincost, c[0], l[0], c[1], l[1]);
+            n_two += 8;
           } else {
-            dp_fast_block<false>(s_ring + DP_FRONT, hdr_v, p0, lane, base, mincost, c[0], l[0], c[1], l[1]);
+            dp_fast_block<false>(s_ring + DP_FRONT, s_tab, p0, lane, base, mincost, c[0], l[0], c[1], l[1]);
           }
+          t_fast += DP_TICK() - tf0;
           noshort = false;
           n_fast += 8;
           p0 += 8;
@@ -1078,8 +1086,373 @@ __global__ __launch_bounds__(64) void k_dp(DpParams P) {
   }
   if (lane == 0) la[0] = 0;
   if (prof && lane == 0) {
-    u64* o = P.prof + (u64)b * 8;
-    o[0] = t_stage; o[1] = t_chain; o[2] = n_fast; o[3] = n_slow; o[4] = B;
+    u64* o = P.prof + (u64)b * 16;
+    o[0] = t_stage; o[1] = t_chain; o[2] = n_fast; o[3] = n_slow; o[4] = B; o[5] = t_fast; o[6] = n_two;
+  }
+}
+
+// -------------------------------------------------------------------- k_dp2
+// The same chain as k_dp, with the work that is not on the chain moved to producer
+// waves of the same workgroup: a lone wave issues about one instruction per 5 cycles, and
+// in k_dp more than half of the instructions per position only fetch and mask row values.
+//
+//   wave 0 (consumer)      the chain: per position one v_readlane, one ds_read_b64 of a
+//                          ready-made 64-lane row, ~10 VALU.
+//   waves 1..D2_NP         per round each builds one tile: up to 8 positions / 16
+//                          register-rows (64 doubles each, +inf outside the row) copied out
+//                          of the LDS row ring, plus a header.  Producer 1 also keeps the
+//                          ring filled by LDS-DMA, one ring ahead.
+//   one s_barrier per round; tiles are double buffered (round r is built while round r-1
+//   is consumed).  A long-run shortcut or the end of the block ends a segment: the
+//   consumer publishes the new start in s_ctrl and everybody restarts there.
+#define D2_NP 3u
+#define D2_TILE_ROWS 16u
+#define D2_TILE_EDGES 384u   // edge cap per tile: the rows of three consecutive rounds (9 tiles) always fit in the ring
+#define D2_F_SHORTCUT 1u
+#define D2_F_END 2u
+
+// consumer: one position on cell register CS with the ready-made row value WV;
+// LIT = this lane's edge is the literal (no mincost test, squeeze.c:277-284).  All VALU:
+// a v_cmp -> s_and -> v_cndmask sequence would put two more SGPR round trips on the chain.
+#define D2_RELAX(CS, LS, WV, LIT)                                            \
+  {                                                                          \
+    const double old_ = (double)(CS);                                        \
+    const double nc_ = (WV) + cj;                    /* squeeze.c:278,297 */  \
+    const double mcl_ = (LIT) ? -kInf : mincost;                             \
+    const bool upd_ = fmax(nc_, mcl_ + cj) < old_;   /* :293, :298 */        \
+    CS = upd_ ? (float)nc_ : CS;                                             \
+    LS = upd_ ? src1 : LS;                                                   \
+  }
+
+__global__ __launch_bounds__(64 * (D2_NP + 1)) void k_dp2(DpParams P) {
+  __shared__ __align__(16) double s_ring[DP_FRONT + DP_RING + DP_MIRROR];
+  __shared__ __align__(16) double s_tile[2][D2_NP][D2_TILE_ROWS * 64];
+  __shared__ u32 s_thdr[2][D2_NP][12];     // [0] first position | n << 24 | variant << 28 | flags << 30 [1] two-register mask [4..11] rowidx | rows << 8
+  __shared__ uint4 s_ptab[D2_NP][8];       // producer scratch: ring index, kend, pg, rowidx | rows << 8
+  __shared__ u32 s_ctrl[2][2];             // per round parity: [0] 0 | 1 restart | 2 done [1] new segment start
+  __shared__ float s_xc[DP_XN];
+  __shared__ u16 s_xl[DP_XN];
+
+  const u32 tid = threadIdx.x;
+  const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const u32 lane = tid & 63;
+  const u32 b = P.block0 + blockIdx.x;
+  const BlockDesc bd = P.blocks[b];
+  const u32 B = (u32)(bd.inend - bd.instart);
+  if (B == 0) return;
+  const uint2* dbase = P.dph + bd.pos_off;
+  u16* la = P.la + bd.la_off;
+  const double* rows = P.rows + P.row_base[b];
+  const u32 total_pad = (u32)((P.block_edges[b] + DP_PIECE - 1) & ~(u64)(DP_PIECE - 1));
+  const double mincost = P.mincost[b];
+  // squeeze.c:260: cost of (length 258, dist 1) = (0 + 0) + ll[285] + d[0]
+  const double symbolcost258 = (double)(0 + 0) + P.cost[(u64)b * 320 + 285] + P.cost[(u64)b * 320 + 288];
+  const double kInf = __longlong_as_double(0x7ff0000000000000ll);
+  const u32 ring_lds = (u32)(unsigned long)(__attribute__((address_space(3))) double*)s_ring;
+
+
+  // consumer: cost cells of the current group (as in k_dp)
+  float c[6];
+  u32 l[6];
+#pragma unroll
+  for (int s = 0; s < 6; ++s) { c[s] = 1e30f; l[s] = 0; }
+  if (lane == 0) c[0] = 0.0f;
+
+  if (wave == 0) __builtin_amdgcn_s_setprio(3);   // the chain is the critical path of the workgroup
+  u32 seg_start = 0, my_ctrl = 0, my_start_next = 0;
+  bool exempt = false;   // the first position of a segment that follows a shortcut is not tested again (squeeze.c:273)
+  u64 t_cons = 0, t_wait = 0, n_fast = 0, n_gen = 0;
+  const bool prof = P.prof != nullptr && wave == 0;
+
+  for (;;) {   // ---- segments
+    // producer state
+    u32 next_pos = seg_start, win_m = 0, issued_end = 0;
+    bool stalled = false;
+    uint2 dhc = make_uint2(0, 0), dhn = make_uint2(0, 0);
+    if (wave != 0) {
+      const u32 q0 = seg_start + lane, q1 = seg_start + 32 + lane;
+      dhc = dbase[q0 < B ? q0 : B - 1];
+      dhn = dbase[q1 < B ? q1 : B - 1];
+      if (wave == 1) {   // prime the ring
+        const u32 a0 = rdlane_u32(dhc.x, 0) & ~(DP_PIECE - 1);
+        issued_end = a0;
+        const u32 lim = a0 + DP_RING < total_pad ? a0 + DP_RING : total_pad;
+        while (issued_end < lim) {
+          const u32 slot = issued_end & (DP_RING - 1);
+          dp_dma_piece(rows + issued_end + lane * 2, ring_lds + (DP_FRONT + slot) * 8);
+          if (slot < DP_MIRROR) dp_dma_piece(rows + issued_end + lane * 2, ring_lds + (DP_FRONT + DP_RING + slot) * 8);
+          issued_end += DP_PIECE;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+    __syncthreads();
+
+    u32 r = 0;
+    bool seg_over = false, done = false;
+    while (!seg_over) {
+      if (wave == 0) {
+        // =============================================================== consumer
+        const u64 tc0 = prof ? (u64)__builtin_readcyclecounter() : 0ull;
+        bool stop = false;
+        u32* ctrl = s_ctrl[r & 1];   // read by everybody after this round's barrier, rewritten two rounds later
+        if (lane == 0) ctrl[0] = 0;
+        my_ctrl = 0;
+        if (r > 0) {
+          // the headers of the whole round first: their LDS latency overlaps
+          u32 h0v[D2_NP];
+#pragma unroll
+          for (u32 w = 0; w < D2_NP; ++w) h0v[w] = s_thdr[(r - 1) & 1][w][0];
+#pragma unroll
+          for (u32 w = 0; w < D2_NP; ++w) {
+            if (stop) break;
+            const u32* hdr = s_thdr[(r - 1) & 1][w];
+            const double* tile = s_tile[(r - 1) & 1][w];
+            const u32 h0 = (u32)__builtin_amdgcn_readfirstlane((int)h0v[w]);
+            const u32 pos0 = h0 & 0xffffffu, n = (h0 >> 24) & 15u, variant = (h0 >> 28) & 3u, flags = h0 >> 30;
+            const u32 pg0 = (pos0 - seg_start) & 63u;
+            u32 base = pos0 - pg0;
+            const u64 th0 = prof ? (u64)__builtin_readcyclecounter() : 0ull;
+            if (n) {
+              if (variant == 0) {
+                double wv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wv[u] = tile[u * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                  const u32 p = pg0 + u;
+                  const double cj = (double)rdlane_f32(c[0], p);
+                  const u32 src1 = base + p + 1;
+                  const bool lit = __builtin_amdgcn_inverse_ballot_w64(2ull << p);   // lane p + 1
+                  D2_RELAX(c[0], l[0], wv[u], lit)
+                }
+                n_fast += 8;
+              } else if (variant == 1) {
+                const u32 two = (u32)__builtin_amdgcn_readfirstlane((int)hdr[1]);   // positions that reach register 1
+                double wv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) wv[u] = tile[u * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                  const u32 p = pg0 + u;
+                  const double cj = (double)rdlane_f32(c[0], p);
+                  const u32 src1 = base + p + 1;
+                  const bool lit0 = __builtin_amdgcn_inverse_ballot_w64(2ull << p);              // lane p + 1 (none for p = 63)
+                  D2_RELAX(c[0], l[0], wv[2 * u], lit0)
+                  if ((two >> u) & 1) {
+                    const bool lit1 = __builtin_amdgcn_inverse_ballot_w64((u64)((p + 1) >> 6));   // lane 0 of register 1 for p = 63
+                    D2_RELAX(c[1], l[1], wv[2 * u + 1], lit1)
+                  }
+                }
+                n_fast += 8;
+              } else {
+                for (u32 u = 0; u < n; ++u) {
+                  const u32 info = (u32)__builtin_amdgcn_readfirstlane((int)hdr[4 + u]);
+                  const u32 rowidx = info & 255u, nrows = info >> 8;
+                  const u32 p = pg0 + u;
+                  const double cj = (double)rdlane_f32(c[0], p);
+                  const u32 src1 = base + p + 1;
+#pragma unroll
+                  for (int s = 0; s < 6; ++s) {
+                    if ((u32)s < nrows) {
+                      const double wv = tile[(rowidx + s) * 64 + lane];
+                      const bool lit = lane + 64u * s == p + 1;
+                      D2_RELAX(c[s], l[s], wv, lit)
+                    }
+                  }
+                }
+                n_gen += n;
+              }
+              if (prof) t_wait += (u64)__builtin_readcyclecounter() - th0;
+              if (pg0 + n == 64) {   // group done: cells base..base+63 are final
+                const u32 jj = base + lane;
+                if (jj <= B && jj >= 1) la[jj] = (u16)(l[0] ? jj + 1 - l[0] : 0u);
+#pragma unroll
+                for (int s = 0; s < 5; ++s) { c[s] = c[s + 1]; l[s] = l[s + 1]; }
+                c[5] = 1e30f;
+                l[5] = 0;
+                base += 64;
+              }
+            }
+            if (flags & D2_F_SHORTCUT) {
+              // ---- long-run shortcut at the position after the tile (squeeze.c:251-271)
+              const u32 j = pos0 + n;
+              const u32 p = j - base;
+              if (lane < p && base + lane >= 1) la[base + lane] = (u16)(l[0] ? base + lane + 1 - l[0] : 0u);
+              wave_lds_sync();
+#pragma unroll
+              for (int s = 0; s < 6; ++s) {
+                const u32 x = base + 64u * s + lane;
+                s_xc[64 * s + lane] = c[s];
+                s_xl[64 * s + lane] = (u16)(l[s] ? x + 1 - l[s] : 0u);
+              }
+              wave_lds_sync();
+              float nc4[5];
+#pragma unroll
+              for (int q = 0; q < 5; ++q) {
+                const u32 t = 64u * q + lane;
+                nc4[q] = 1e30f;
+                if (t < ZMX_MAX_MATCH) {
+                  la[j + t] = s_xl[p + t];
+                  nc4[q] = (float)((double)s_xc[p + t] + symbolcost258);
+                }
+              }
+#pragma unroll
+              for (int s = 0; s < 6; ++s) { c[s] = 1e30f; l[s] = 0; }
+#pragma unroll
+              for (int q = 0; q < 5; ++q) {
+                const u32 t = 64u * q + lane;
+                if (t < ZMX_MAX_MATCH) { c[q] = nc4[q]; l[q] = j + t + 1; }
+              }
+              wave_lds_sync();
+              if (lane == 0) { ctrl[1] = j + ZMX_MAX_MATCH; ctrl[0] = 1; }
+              my_ctrl = 1;
+              my_start_next = j + ZMX_MAX_MATCH;
+              stop = true;
+            } else if (flags & D2_F_END) {
+              const u32 jj = base + lane;
+              if (jj <= B && jj >= 1) la[jj] = (u16)(l[0] ? jj + 1 - l[0] : 0u);
+              if (lane == 0) { la[0] = 0; ctrl[0] = 2; }
+              my_ctrl = 2;
+              stop = true;
+            }
+          }
+        }
+        if (prof) t_cons += (u64)__builtin_readcyclecounter() - tc0;
+      } else {
+        // =============================================================== producers
+        const u32 my = wave - 1;
+        while (((next_pos - seg_start) >> 5) > win_m) {   // slide the 64-position dph window by 32
+          ++win_m;
+          dhc = dhn;
+          const u32 qn = seg_start + 32 * (win_m + 1) + lane;
+          dhn = dbase[qn < B ? qn : B - 1];
+        }
+        const u32 ws = seg_start + 32 * win_m;
+        const u32 i0 = next_pos - ws;
+        const u32 q = ws + lane;
+        const bool inb = q < B;
+        const u32 ke = inb ? (dhc.y & 0xffffu) : 0u;
+        const bool sfl = inb && (dhc.y >> 16) != 0 && !(exempt && q == seg_start);
+        const u32 pg = (q - seg_start) & 63u;
+        const u32 rr = inb ? ((ke + pg) >> 6) + 1 : 0u;
+        const u64 stopmask = __ballot(sfl && lane >= i0);
+        const u32 istop = stopmask ? (u32)__ffsll((long long)stopmask) - 1 : 64u;
+        const u32 endi = B - ws < 64u ? B - ws : 64u;
+        const u32 lim = istop < endi ? istop : endi;
+        const u32 R = wave_scan_add(rr), E = wave_scan_add(ke);
+
+        if (wave == 1) {   // keep the ring one ring ahead of the first position of this round
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (i0 < endi) {
+            const u32 a_r = rdlane_u32(dhc.x, i0) & ~(DP_PIECE - 1);
+            const u32 dlim = a_r + DP_RING < total_pad ? a_r + DP_RING : total_pad;
+            while (issued_end < dlim) {
+              const u32 slot = issued_end & (DP_RING - 1);
+              dp_dma_piece(rows + issued_end + lane * 2, ring_lds + (DP_FRONT + slot) * 8);
+              if (slot < DP_MIRROR) dp_dma_piece(rows + issued_end + lane * 2, ring_lds + (DP_FRONT + DP_RING + slot) * 8);
+              issued_end += DP_PIECE;
+            }
+          }
+        }
+
+        // partition of the round into D2_NP tiles (every producer computes all of it)
+        u32 it = i0, my_start = 0, my_n = 0, my_flags = 0;
+        bool any_flag = false;
+#pragma unroll
+        for (u32 w = 0; w < D2_NP; ++w) {
+          u32 n = 0, fl = 0;
+          if (!stalled && !any_flag) {
+            if (it < lim) {
+              const u32 Rb = it ? rdlane_u32(R, it - 1) : 0u, Eb = it ? rdlane_u32(E, it - 1) : 0u;
+              const u32 pg_it = rdlane_u32(pg, it);
+              const u64 fit = __ballot(lane >= it && lane < lim && lane < it + 8 && R - Rb <= D2_TILE_ROWS &&
+                                       E - Eb <= D2_TILE_EDGES && pg >= pg_it);
+              n = (u32)__popcll(fit);
+            }
+            if (it + n == istop && istop < endi) fl = D2_F_SHORTCUT;
+            else if (it + n == endi && ws + endi == B) fl = D2_F_END;
+          }
+          if (w == my) { my_start = it; my_n = n; my_flags = fl; }
+          it += n;
+          if (fl) any_flag = true;
+        }
+        next_pos = ws + it;
+        if (any_flag) stalled = true;
+
+        // build my tile
+        double* tile = s_tile[r & 1][my];
+        u32* hdr = s_thdr[r & 1][my];
+        const bool mine = lane >= my_start && lane < my_start + my_n;
+        const bool all1 = __ballot(mine && rr != 1) == 0, all2 = __ballot(mine && rr > 2) == 0;
+        const u32 variant = (my_n == 8 && all1) ? 0u : (my_n == 8 && all2) ? 1u : 2u;
+        const u32 Rb = my_start ? rdlane_u32(R, my_start - 1) : 0u;
+        const u32 u_me = lane - my_start;
+        const u32 rowidx = variant == 0 ? u_me : variant == 1 ? 2 * u_me : (R - rr) - Rb;
+        wave_lds_sync();
+        if (mine) {
+          s_ptab[my][u_me] = make_uint4(dhc.x & (DP_RING - 1), ke, pg, rowidx | (rr << 8));
+          hdr[4 + u_me] = rowidx | ((variant == 1 ? 2u : rr) << 8);
+        }
+        const u32 twomask = (u32)(__ballot(mine && rr == 2) >> my_start) & 255u;
+        if (lane == 0) {
+          hdr[0] = (ws + my_start) | (my_n << 24) | (variant << 28) | (my_flags << 30);
+          hdr[1] = twomask;
+        }
+        wave_lds_sync();
+        if (variant != 2) {
+          // 8 positions, 1 or 2 rows each at fixed row indices: everything in flight at once
+          uint4 t[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[u] = s_ptab[my][u];   // broadcast reads
+          double v0[8], v1[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const u32 k1 = lane - t[u].z - 1;
+            v0[u] = s_ring[DP_FRONT + (k1 < t[u].y ? t[u].x + k1 : 0u)];
+            if (variant == 1) v1[u] = s_ring[DP_FRONT + (k1 + 64 < t[u].y ? t[u].x + k1 + 64 : 0u)];
+          }
+          if (variant == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tile[u * 64 + lane] = lane - t[u].z - 1 < t[u].y ? v0[u] : kInf;
+          } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const u32 k1 = lane - t[u].z - 1;
+              tile[(2 * u) * 64 + lane] = k1 < t[u].y ? v0[u] : kInf;
+              tile[(2 * u + 1) * 64 + lane] = k1 + 64 < t[u].y ? v1[u] : kInf;
+            }
+          }
+        } else {
+          for (u32 u = 0; u < my_n; ++u) {
+            const uint4 t = s_ptab[my][u];   // broadcast
+            const u32 nrows = t.w >> 8;
+            const u32 row0 = t.w & 255u;
+            for (u32 s = 0; s < nrows; ++s) {
+              const u32 k1 = lane - t.z - 1 + 64 * s;
+              const bool valid = k1 < t.y;
+              const double v = s_ring[DP_FRONT + (valid ? t.x + k1 : 0u)];
+              tile[(row0 + s) * 64 + lane] = valid ? v : kInf;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      // the consumer knows what it published; the producers read it
+      u32 c0v = my_ctrl, c1v = my_start_next;
+      if (wave != 0) {
+        c0v = (u32)__builtin_amdgcn_readfirstlane((int)s_ctrl[r & 1][0]);
+        if (c0v == 1) c1v = (u32)__builtin_amdgcn_readfirstlane((int)s_ctrl[r & 1][1]);
+      }
+      if (c0v == 2) { done = true; seg_over = true; }
+      else if (c0v == 1) { seg_start = c1v; exempt = true; seg_over = true; }
+      ++r;
+    }
+    if (done) break;
+  }
+  if (P.prof && tid == 0) {
+    u64* o = P.prof + (u64)b * 16;
+    o[0] = 0; o[1] = t_cons; o[2] = n_fast; o[3] = n_gen; o[4] = B; o[5] = t_wait; o[6] = 0;
   }
 }
 
@@ -1096,10 +1469,13 @@ struct TraceParams {
   u32* hist_out;
   u32* nsym_out;
   u32* flags;              // [1] error bits
+  u64* prof;               // optional [nb_total][16] cycle counters (slots 8..), else null
 };
 
 __global__ __launch_bounds__(64) void k_trace(TraceParams P) {
-  __shared__ u16 s_la[TR_CHUNK + 2];
+  __shared__ __align__(16) u16 s_la[TR_CHUNK];
+  __shared__ u32 s_sym[128];       // (start position, length) of walked symbols awaiting resolution
+  __shared__ u32 s_len[128];
   __shared__ u32 s_hist[320];
 
   const u32 b = P.block0 + blockIdx.x;
@@ -1113,46 +1489,69 @@ __global__ __launch_bounds__(64) void k_trace(TraceParams P) {
   for (u32 i = lane; i < 320; i += 64) s_hist[i] = 0;
   __syncthreads();
 
-  // TraceBackwards (squeeze.c:317): the walk is a chain of dependent reads.  64 cells of
-  // length_array sit in one VGPR (lane i = cell wb + i), a step is v_readlane + s_sub, the
-  // symbol start goes to lane n of pos_v.  Every 64 symbols the lanes resolve
-  // FollowPath (squeeze.c:338: dist = sublen[length] of the match record, A.2-6) in
-  // parallel; the record loads of one batch are in flight while the next batch is walked.
-  u32 head = B, total = 0;
+  // TraceBackwards (squeeze.c:317) is a chain of dependent reads.  64 cells of length_array
+  // sit in one VGPR (lane i = cell wb + i); a step is v_readlane + s_sub and sets the bit of
+  // the visited cell in an SGPR mask — the lane of a visited cell x holds everything about
+  // the symbol that ENDS there: length la[x], start x - la[x].  After a window the marked
+  // lanes are compacted (highest cell first = stream order from the back) into an LDS
+  // queue; every 64 queued symbols the lanes resolve FollowPath (squeeze.c:338:
+  // dist = sublen[length] of the match record) in parallel, with the record
+  // loads of one batch in flight while the next windows are walked.
+  const bool prof = P.prof != nullptr;
+  u64 t_walk = 0, t_res = 0, t_req = 0, t_mark = prof ? (u64)__builtin_readcyclecounter() : 0ull;
+#define TR_LAP(ACC) if (prof) { const u64 t_ = (u64)__builtin_readcyclecounter(); ACC += t_ - t_mark; t_mark = t_; }
+  u32 head = B;
+  u32 total = 0;                  // symbols resolved or queued for resolution
+  u32 queued = 0;                 // symbols in s_sym/s_len
   u32 lo = 0, hi = 0;             // cells [lo, hi] are staged in s_la
-  u32 wb = 0xffffffffu;           // window base
-  u32 la_v = 0;
-  // pending batch (records requested, not yet resolved)
-  u32 pend_n = 0, pend_total = 0, pend_pos = 0, pend_len = 0;
-  uint4 pend_ra = make_uint4(0, 0, 0, 0), pend_rb = make_uint4(0, 0, 0, 0);
   bool bad = false;
+  u32 pend_n = 0, pend_total = 0, pend_len = 0;
+  uint4 pend_ra = make_uint4(0, 0, 0, 0), pend_rb = make_uint4(0, 0, 0, 0);
 
   for (;;) {
-    // ---- walk up to 64 symbols
-    u32 n = 0;
-    u32 pos_v = 0;
-    const u32 start_head = head;
-    while (n < 64 && head > 0 && !bad) {
-      if (wb == 0xffffffffu || head < wb) {
-        wb = head > 63 ? head - 63 : 0;
-        if (hi == 0 || wb < lo) {   // restage [lo, head]
-          lo = head > TR_CHUNK ? head - TR_CHUNK : 0;
-          hi = head;
-          __syncthreads();
-          for (u32 t = lane; t <= hi - lo; t += 64) s_la[t] = la[lo + t];
-          __syncthreads();
+    // ---- walk windows until 64 symbols are queued or the start is reached
+    while (queued < 64 && head > 0 && !bad) {
+      const u32 wb = head > 63 ? head - 63 : 0;
+      if (hi == 0 || wb < lo) {   // restage [lo, head]: four 16-byte loads per lane, issued together
+        lo = head > TR_CHUNK - 8 ? (head - (TR_CHUNK - 8)) & ~7u : 0;
+        hi = head;
+        __syncthreads();
+        uint4 v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const u32 i8 = (lane + 64u * r) * 8;
+          v[r] = make_uint4(0, 0, 0, 0);
+          if (lo + i8 <= hi) v[r] = *reinterpret_cast<const uint4*>(la + lo + i8);   // la rows are padded to 8 entries
         }
-        la_v = wb + lane <= hi ? (u32)s_la[wb + lane - lo] : 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) reinterpret_cast<uint4*>(s_la)[lane + 64 * r] = v[r];
+        __syncthreads();
       }
-      while (n < 64 && head > 0 && head >= wb) {
-        const u32 len = rdlane_u32(la_v, head - wb);
-        if (len - 1 >= head) { bad = true; break; }    // 0 or longer than the prefix: corrupt
-        head -= len;
-        pos_v = lane == n ? head : pos_v;
-        ++n;
+      const u32 cell = wb + lane;
+      const u32 la_raw = cell <= head ? (u32)s_la[cell - lo] : 0u;
+      const u32 la_v = la_raw ? la_raw : 1u;        // never-reached cells hold 0: keep the walk moving,
+      u64 mask = 0;                                 // validity of the visited cells is checked below
+      int idx = (int)(head - wb);
+      const int lim = __builtin_amdgcn_readfirstlane(wb == 0 ? 1 : 0);   // cell 0 starts the block: not a symbol end
+      do {
+        const u32 len = rdlane_u32(la_v, (u32)idx);
+        mask |= 1ull << idx;
+        idx -= (int)len;
+      } while (idx >= lim);
+      if (__ballot(((mask >> lane) & 1) && (la_raw == 0 || la_raw > cell))) { bad = true; break; }   // corrupt length_array
+      head = (u32)((int)wb + idx);   // first cell below the window (or 0)
+      // compact: rank from the top of the window
+      const bool on = (mask >> lane) & 1;
+      const u32 above = (u32)__popcll(lane < 63 ? mask >> (lane + 1) : 0ull);
+      if (on) {
+        s_sym[queued + above] = cell - la_v;
+        s_len[queued + above] = la_v;
       }
+      queued += (u32)__popcll(mask);
+      __syncthreads();
     }
-    // ---- resolve the pending batch
+    TR_LAP(t_walk)
+    // ---- resolve the pending batch (its records were requested one round ago)
     if (pend_n) {
       if (lane < pend_n) {
         u32 e;
@@ -1188,22 +1587,36 @@ __global__ __launch_bounds__(64) void k_trace(TraceParams P) {
       }
       pend_n = 0;
     }
-    if (n == 0) break;
-    // ---- request the records of the batch just walked
+    TR_LAP(t_res)
+    if (queued == 0) break;
+    // ---- request the records of up to 64 queued symbols, keep the rest queued
     {
-      u32 prev = __shfl_up(pos_v, 1);
-      if (lane == 0) prev = start_head;
+      const u32 n = queued < 64 ? queued : 64;
       pend_n = n;
       pend_total = total;
-      pend_pos = pos_v;
-      pend_len = prev - pos_v;
+      u32 pos = 0;
       if (lane < n) {
-        const u32* rec = rbase + (u64)pos_v * 8;
+        pos = s_sym[lane];
+        pend_len = s_len[lane];
+        const u32* rec = rbase + (u64)pos * 8;
         pend_ra = *reinterpret_cast<const uint4*>(rec);
         pend_rb = *reinterpret_cast<const uint4*>(rec + 4);
       }
       total += n;
+      const u32 rest = queued - n;
+      __syncthreads();
+      u32 mv_s = 0, mv_l = 0;
+      if (lane < rest) { mv_s = s_sym[n + lane]; mv_l = s_len[n + lane]; }
+      __syncthreads();
+      if (lane < rest) { s_sym[lane] = mv_s; s_len[lane] = mv_l; }
+      queued = rest;
+      __syncthreads();
     }
+    TR_LAP(t_req)
+  }
+  if (prof && lane == 0) {
+    u64* o = P.prof + (u64)b * 16 + 8;
+    o[0] = t_walk; o[1] = t_res; o[2] = t_req; o[3] = total;
   }
   if (bad && lane == 0) atomicOr(&P.flags[1], 2u);
   __syncthreads();

@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 MB = 1000000
 WINDOW = 32768
+PMC_PROFILE = "r01_v2_bench100MB_pmc.json"
 
 
 def cpu_baseline(sample, options):
@@ -170,8 +171,19 @@ def main():
         if launches > 0 and ksec > 0:
             per_launch_bytes = 31.0 * size
             achieved = per_launch_bytes / (ksec / launches) / 1e9
+            # HBM bytes per k_dp launch from the rocprofv3 PMC passes of this exact workload
+            # (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md; tools/collect_profiles.sh): only
+            # reported when the committed profile was taken on the same configuration
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", PMC_PROFILE)
+            if (os.path.exists(pmc) and size == 100 * MB and args.numiterations == 15
+                    and args.blocksplitting == 0 and world == 1):
+                with open(pmc) as f:
+                    traffic = round(json.load(f).get("k_dp", {}).get("hbm_bytes", 0) / 1e9, 3) or None
             roofline = {"bound": "hbm", "kernel": "k_dp", "achieved": round(achieved, 3), "peak": 8000.0,
-                        "unit": "GB/s", "frac": round(achieved / 8000.0, 6), "traffic": None,
+                        "unit": "GB/s", "frac": round(achieved / 8000.0, 6), "traffic": traffic,
+                        "traffic_unit": "GB per launch (rocprofv3 PMC, profiles/" + PMC_PROFILE + ")",
+                        "algorithmic_gb_per_launch": round(per_launch_bytes / 1e9, 3),
                         "avg_launch_ms": round(ksec / launches * 1e3, 3), "launches_per_step": launches / args.steps}
         line = {
             "metric": "input MB/s at numiterations=15 (gzip, bit-exact vs reference)",

@@ -179,34 +179,6 @@ __global__ void k_readlane_tp(u32* out, u64* cyc) {
   out[threadIdx.x] = acc; if (threadIdx.x == 0) cyc[0] = t1 - t0;
 }
 
-// the consumer of k_dp2 on one ready-made tile (variant 0), alone on its CU
-__global__ void k_consumer(float* out, u64* cyc, double mincost) {
-  __shared__ double tile[16 * 64];
-  const u32 lane = threadIdx.x;
-  const double kInf = __longlong_as_double(0x7ff0000000000000ll);
-  for (u32 i = lane; i < 16 * 64; i += 64) tile[i] = (i & 63) > (i >> 6) && (i & 63) < (i >> 6) + 9 ? 3.0 + (i & 7) : kInf;
-  __syncthreads();
-  float c0 = lane == 0 ? 0.0f : 1e30f;
-  u32 l0 = 0;
-  u64 t0 = __builtin_readcyclecounter();
-  for (int it = 0; it < N / 8; ++it) {
-    const u32 pg0 = (it & 7) * 8, base = it * 8;
-    double wv[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) wv[u] = tile[u * 64 + lane];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const u32 p = pg0 + u;
-      const double cj = (double)rdlane_f32(c0, p);
-      const u32 src1 = base + p + 1;
-      const bool lit = __builtin_amdgcn_inverse_ballot_w64(2ull << p);
-      D2_RELAX(c0, l0, wv[u], lit)
-    }
-  }
-  u64 t1 = __builtin_readcyclecounter();
-  out[lane] = c0 + (float)l0; if (lane == 0) cyc[0] = t1 - t0;
-}
-
 int main() {
   double* d; float* f; u32* u; u64* cyc; double* w;
   hipMalloc(&d, 64 * 8); hipMalloc(&f, 64 * 4); hipMalloc(&u, 64 * 4); hipMalloc(&cyc, 8); hipMalloc(&w, 64 * 8);
@@ -237,6 +209,5 @@ int main() {
   RUN(k_fast_block<0>, f, cyc, 2.0)
   RUN(k_fast_block<1>, f, cyc, 2.0)
   RUN(k_fast_block<2>, f, cyc, 2.0)
-  RUN(k_consumer, f, cyc, 2.0)
   return 0;
 }

@@ -494,9 +494,7 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     if (tiles) hipLaunchKernelGGL(k_edges, dim3(tiles), dim3(256), 0, c->stream, ep);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
-    static const bool old_dp = [] { const char* e = std::getenv("ZOPFLI_AMD_DP"); return e && e[0] == '1'; }();
-    if (old_dp) hipLaunchKernelGGL(k_dp, dim3(nblk), dim3(64), 0, c->stream, cp);   // single-wave chain (A/B reference)
-    else hipLaunchKernelGGL(k_dp2, dim3(nblk), dim3(64 * (D2_NP + 1)), 0, c->stream, cp);
+    hipLaunchKernelGGL(k_dp, dim3(nblk), dim3(64), 0, c->stream, cp);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
     hipLaunchKernelGGL(k_trace, dim3(nblk), dim3(64), 0, c->stream, tp);
@@ -524,8 +522,8 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     HIPCHK(hipMemcpy(pr.data(), t->d_prof, pr.size() * sizeof(u64), hipMemcpyDeviceToHost));
     double a[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (size_t b = 0; b < t->nb; ++b) for (int k = 0; k < 12; ++k) a[k] += static_cast<double>(pr[b * 16 + k]);
-    std::fprintf(stderr, "squeeze prof: edges %.2f ms dp %.2f ms trace %.2f ms; k_dp cycles/position stage %.1f chain %.1f (inside fast blocks %.1f); fast %.1f%% (two-register %.1f%%) of %.0f positions; k_trace cycles/symbol walk %.1f resolve %.1f request %.1f (%.0f symbols)\n",
-                 ksec[0] * 1e3, ksec[1] * 1e3, ksec[2] * 1e3, a[0] / a[4], a[1] / a[4], a[5] / a[4],
+    std::fprintf(stderr, "squeeze prof: edges %.2f ms dp %.2f ms trace %.2f ms; k_dp cycles/position stage %.1f chain %.1f (inside fast blocks %.1f, two-register blocks %.1f/position); fast %.1f%% (two-register %.1f%%) of %.0f positions; k_trace cycles/symbol walk %.1f resolve %.1f request %.1f (%.0f symbols)\n",
+                 ksec[0] * 1e3, ksec[1] * 1e3, ksec[2] * 1e3, a[0] / a[4], a[1] / a[4], a[5] / a[4], a[7] / (a[6] + 1e-9),
                  100.0 * a[2] / (a[2] + a[3] + 1e-9), 100.0 * a[6] / (a[2] + a[3] + 1e-9), a[4],
                  a[8] / a[11], a[9] / a[11], a[10] / a[11], a[11]);
   }

@@ -909,7 +909,7 @@ __global__ __launch_bounds__(64) void k_dp(DpParams P) {
   const double kInf = __longlong_as_double(0x7ff0000000000000ll);
   const u32 ring_lds = (u32)(unsigned long)(__attribute__((address_space(3))) double*)s_ring;
 
-  u64 t_stage = 0, t_chain = 0, t_mark = 0, n_fast = 0, n_slow = 0, t_fast = 0, n_two = 0;
+  u64 t_stage = 0, t_chain = 0, t_mark = 0, n_fast = 0, n_slow = 0, t_fast = 0, n_two = 0, t_two = 0;
   const bool prof = P.prof != nullptr;
 #define DP_TICK() (prof ? (u64)__builtin_readcyclecounter() : 0ull)
 
@@ -989,6 +989,7 @@ __global__ __launch_bounds__(64) void k_dp(DpParams P) {
           if (((u32)(m_r1 >> p0) & 255u) != 0) {
             dp_fast_block<true>(s_ring + DP_FRONT, s_tab, p0, lane, base, mincost, c[0], l[0], c[1], l[1]);
             n_two += 8;
+            t_two += DP_TICK() - tf0;
           } else {
             dp_fast_block<false>(s_ring + DP_FRONT, s_tab, p0, lane, base, mincost, c[0], l[0], c[1], l[1]);
           }
@@ -1087,372 +1088,7 @@ __global__ __launch_bounds__(64) void k_dp(DpParams P) {
   if (lane == 0) la[0] = 0;
   if (prof && lane == 0) {
     u64* o = P.prof + (u64)b * 16;
-    o[0] = t_stage; o[1] = t_chain; o[2] = n_fast; o[3] = n_slow; o[4] = B; o[5] = t_fast; o[6] = n_two;
-  }
-}
-
-// -------------------------------------------------------------------- k_dp2
-// The same chain as k_dp, with the work that is not on the chain moved to producer
-// waves of the same workgroup: a lone wave issues about one instruction per 5 cycles, and
-// in k_dp more than half of the instructions per position only fetch and mask row values.
-//
-//   wave 0 (consumer)      the chain: per position one v_readlane, one ds_read_b64 of a
-//                          ready-made 64-lane row, ~10 VALU.
-//   waves 1..D2_NP         per round each builds one tile: up to 8 positions / 16
-//                          register-rows (64 doubles each, +inf outside the row) copied out
-//                          of the LDS row ring, plus a header.  Producer 1 also keeps the
-//                          ring filled by LDS-DMA, one ring ahead.
-//   one s_barrier per round; tiles are double buffered (round r is built while round r-1
-//   is consumed).  A long-run shortcut or the end of the block ends a segment: the
-//   consumer publishes the new start in s_ctrl and everybody restarts there.
-#define D2_NP 3u
-#define D2_TILE_ROWS 16u
-#define D2_TILE_EDGES 384u   // edge cap per tile: the rows of three consecutive rounds (9 tiles) always fit in the ring
-#define D2_F_SHORTCUT 1u
-#define D2_F_END 2u
-
-// consumer: one position on cell register CS with the ready-made row value WV;
-// LIT = this lane's edge is the literal (no mincost test, squeeze.c:277-284).  All VALU:
-// a v_cmp -> s_and -> v_cndmask sequence would put two more SGPR round trips on the chain.
-#define D2_RELAX(CS, LS, WV, LIT)                                            \
-  {                                                                          \
-    const double old_ = (double)(CS);                                        \
-    const double nc_ = (WV) + cj;                    /* squeeze.c:278,297 */  \
-    const double mcl_ = (LIT) ? -kInf : mincost;                             \
-    const bool upd_ = fmax(nc_, mcl_ + cj) < old_;   /* :293, :298 */        \
-    CS = upd_ ? (float)nc_ : CS;                                             \
-    LS = upd_ ? src1 : LS;                                                   \
-  }
-
-__global__ __launch_bounds__(64 * (D2_NP + 1)) void k_dp2(DpParams P) {
-  __shared__ __align__(16) double s_ring[DP_FRONT + DP_RING + DP_MIRROR];
-  __shared__ __align__(16) double s_tile[2][D2_NP][D2_TILE_ROWS * 64];
-  __shared__ u32 s_thdr[2][D2_NP][12];     // [0] first position | n << 24 | variant << 28 | flags << 30 [1] two-register mask [4..11] rowidx | rows << 8
-  __shared__ uint4 s_ptab[D2_NP][8];       // producer scratch: ring index, kend, pg, rowidx | rows << 8
-  __shared__ u32 s_ctrl[2][2];             // per round parity: [0] 0 | 1 restart | 2 done [1] new segment start
-  __shared__ float s_xc[DP_XN];
-  __shared__ u16 s_xl[DP_XN];
-
-  const u32 tid = threadIdx.x;
-  const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-  const u32 lane = tid & 63;
-  const u32 b = P.block0 + blockIdx.x;
-  const BlockDesc bd = P.blocks[b];
-  const u32 B = (u32)(bd.inend - bd.instart);
-  if (B == 0) return;
-  const uint2* dbase = P.dph + bd.pos_off;
-  u16* la = P.la + bd.la_off;
-  const double* rows = P.rows + P.row_base[b];
-  const u32 total_pad = (u32)((P.block_edges[b] + DP_PIECE - 1) & ~(u64)(DP_PIECE - 1));
-  const double mincost = P.mincost[b];
-  // squeeze.c:260: cost of (length 258, dist 1) = (0 + 0) + ll[285] + d[0]
-  const double symbolcost258 = (double)(0 + 0) + P.cost[(u64)b * 320 + 285] + P.cost[(u64)b * 320 + 288];
-  const double kInf = __longlong_as_double(0x7ff0000000000000ll);
-  const u32 ring_lds = (u32)(unsigned long)(__attribute__((address_space(3))) double*)s_ring;
-
-
-  // consumer: cost cells of the current group (as in k_dp)
-  float c[6];
-  u32 l[6];
-#pragma unroll
-  for (int s = 0; s < 6; ++s) { c[s] = 1e30f; l[s] = 0; }
-  if (lane == 0) c[0] = 0.0f;
-
-  if (wave == 0) __builtin_amdgcn_s_setprio(3);   // the chain is the critical path of the workgroup
-  u32 seg_start = 0, my_ctrl = 0, my_start_next = 0;
-  bool exempt = false;   // the first position of a segment that follows a shortcut is not tested again (squeeze.c:273)
-  u64 t_cons = 0, t_wait = 0, n_fast = 0, n_gen = 0;
-  const bool prof = P.prof != nullptr && wave == 0;
-
-  for (;;) {   // ---- segments
-    // producer state
-    u32 next_pos = seg_start, win_m = 0, issued_end = 0;
-    bool stalled = false;
-    uint2 dhc = make_uint2(0, 0), dhn = make_uint2(0, 0);
-    if (wave != 0) {
-      const u32 q0 = seg_start + lane, q1 = seg_start + 32 + lane;
-      dhc = dbase[q0 < B ? q0 : B - 1];
-      dhn = dbase[q1 < B ? q1 : B - 1];
-      if (wave == 1) {   // prime the ring
-        const u32 a0 = rdlane_u32(dhc.x, 0) & ~(DP_PIECE - 1);
-        issued_end = a0;
-        const u32 lim = a0 + DP_RING < total_pad ? a0 + DP_RING : total_pad;
-        while (issued_end < lim) {
-          const u32 slot = issued_end & (DP_RING - 1);
-          dp_dma_piece(rows + issued_end + lane * 2, ring_lds + (DP_FRONT + slot) * 8);
-          if (slot < DP_MIRROR) dp_dma_piece(rows + issued_end + lane * 2, ring_lds + (DP_FRONT + DP_RING + slot) * 8);
-          issued_end += DP_PIECE;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-    }
-    __syncthreads();
-
-    u32 r = 0;
-    bool seg_over = false, done = false;
-    while (!seg_over) {
-      if (wave == 0) {
-        // =============================================================== consumer
-        const u64 tc0 = prof ? (u64)__builtin_readcyclecounter() : 0ull;
-        bool stop = false;
-        u32* ctrl = s_ctrl[r & 1];   // read by everybody after this round's barrier, rewritten two rounds later
-        if (lane == 0) ctrl[0] = 0;
-        my_ctrl = 0;
-        if (r > 0) {
-          // the headers of the whole round first: their LDS latency overlaps
-          u32 h0v[D2_NP];
-#pragma unroll
-          for (u32 w = 0; w < D2_NP; ++w) h0v[w] = s_thdr[(r - 1) & 1][w][0];
-#pragma unroll
-          for (u32 w = 0; w < D2_NP; ++w) {
-            if (stop) break;
-            const u32* hdr = s_thdr[(r - 1) & 1][w];
-            const double* tile = s_tile[(r - 1) & 1][w];
-            const u32 h0 = (u32)__builtin_amdgcn_readfirstlane((int)h0v[w]);
-            const u32 pos0 = h0 & 0xffffffu, n = (h0 >> 24) & 15u, variant = (h0 >> 28) & 3u, flags = h0 >> 30;
-            const u32 pg0 = (pos0 - seg_start) & 63u;
-            u32 base = pos0 - pg0;
-            const u64 th0 = prof ? (u64)__builtin_readcyclecounter() : 0ull;
-            if (n) {
-              if (variant == 0) {
-                double wv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) wv[u] = tile[u * 64 + lane];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                  const u32 p = pg0 + u;
-                  const double cj = (double)rdlane_f32(c[0], p);
-                  const u32 src1 = base + p + 1;
-                  const bool lit = __builtin_amdgcn_inverse_ballot_w64(2ull << p);   // lane p + 1
-                  D2_RELAX(c[0], l[0], wv[u], lit)
-                }
-                n_fast += 8;
-              } else if (variant == 1) {
-                const u32 two = (u32)__builtin_amdgcn_readfirstlane((int)hdr[1]);   // positions that reach register 1
-                double wv[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) wv[u] = tile[u * 64 + lane];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                  const u32 p = pg0 + u;
-                  const double cj = (double)rdlane_f32(c[0], p);
-                  const u32 src1 = base + p + 1;
-                  const bool lit0 = __builtin_amdgcn_inverse_ballot_w64(2ull << p);              // lane p + 1 (none for p = 63)
-                  D2_RELAX(c[0], l[0], wv[2 * u], lit0)
-                  if ((two >> u) & 1) {
-                    const bool lit1 = __builtin_amdgcn_inverse_ballot_w64((u64)((p + 1) >> 6));   // lane 0 of register 1 for p = 63
-                    D2_RELAX(c[1], l[1], wv[2 * u + 1], lit1)
-                  }
-                }
-                n_fast += 8;
-              } else {
-                for (u32 u = 0; u < n; ++u) {
-                  const u32 info = (u32)__builtin_amdgcn_readfirstlane((int)hdr[4 + u]);
-                  const u32 rowidx = info & 255u, nrows = info >> 8;
-                  const u32 p = pg0 + u;
-                  const double cj = (double)rdlane_f32(c[0], p);
-                  const u32 src1 = base + p + 1;
-#pragma unroll
-                  for (int s = 0; s < 6; ++s) {
-                    if ((u32)s < nrows) {
-                      const double wv = tile[(rowidx + s) * 64 + lane];
-                      const bool lit = lane + 64u * s == p + 1;
-                      D2_RELAX(c[s], l[s], wv, lit)
-                    }
-                  }
-                }
-                n_gen += n;
-              }
-              if (prof) t_wait += (u64)__builtin_readcyclecounter() - th0;
-              if (pg0 + n == 64) {   // group done: cells base..base+63 are final
-                const u32 jj = base + lane;
-                if (jj <= B && jj >= 1) la[jj] = (u16)(l[0] ? jj + 1 - l[0] : 0u);
-#pragma unroll
-                for (int s = 0; s < 5; ++s) { c[s] = c[s + 1]; l[s] = l[s + 1]; }
-                c[5] = 1e30f;
-                l[5] = 0;
-                base += 64;
-              }
-            }
-            if (flags & D2_F_SHORTCUT) {
-              // ---- long-run shortcut at the position after the tile (squeeze.c:251-271)
-              const u32 j = pos0 + n;
-              const u32 p = j - base;
-              if (lane < p && base + lane >= 1) la[base + lane] = (u16)(l[0] ? base + lane + 1 - l[0] : 0u);
-              wave_lds_sync();
-#pragma unroll
-              for (int s = 0; s < 6; ++s) {
-                const u32 x = base + 64u * s + lane;
-                s_xc[64 * s + lane] = c[s];
-                s_xl[64 * s + lane] = (u16)(l[s] ? x + 1 - l[s] : 0u);
-              }
-              wave_lds_sync();
-              float nc4[5];
-#pragma unroll
-              for (int q = 0; q < 5; ++q) {
-                const u32 t = 64u * q + lane;
-                nc4[q] = 1e30f;
-                if (t < ZMX_MAX_MATCH) {
-                  la[j + t] = s_xl[p + t];
-                  nc4[q] = (float)((double)s_xc[p + t] + symbolcost258);
-                }
-              }
-#pragma unroll
-              for (int s = 0; s < 6; ++s) { c[s] = 1e30f; l[s] = 0; }
-#pragma unroll
-              for (int q = 0; q < 5; ++q) {
-                const u32 t = 64u * q + lane;
-                if (t < ZMX_MAX_MATCH) { c[q] = nc4[q]; l[q] = j + t + 1; }
-              }
-              wave_lds_sync();
-              if (lane == 0) { ctrl[1] = j + ZMX_MAX_MATCH; ctrl[0] = 1; }
-              my_ctrl = 1;
-              my_start_next = j + ZMX_MAX_MATCH;
-              stop = true;
-            } else if (flags & D2_F_END) {
-              const u32 jj = base + lane;
-              if (jj <= B && jj >= 1) la[jj] = (u16)(l[0] ? jj + 1 - l[0] : 0u);
-              if (lane == 0) { la[0] = 0; ctrl[0] = 2; }
-              my_ctrl = 2;
-              stop = true;
-            }
-          }
-        }
-        if (prof) t_cons += (u64)__builtin_readcyclecounter() - tc0;
-      } else {
-        // =============================================================== producers
-        const u32 my = wave - 1;
-        while (((next_pos - seg_start) >> 5) > win_m) {   // slide the 64-position dph window by 32
-          ++win_m;
-          dhc = dhn;
-          const u32 qn = seg_start + 32 * (win_m + 1) + lane;
-          dhn = dbase[qn < B ? qn : B - 1];
-        }
-        const u32 ws = seg_start + 32 * win_m;
-        const u32 i0 = next_pos - ws;
-        const u32 q = ws + lane;
-        const bool inb = q < B;
-        const u32 ke = inb ? (dhc.y & 0xffffu) : 0u;
-        const bool sfl = inb && (dhc.y >> 16) != 0 && !(exempt && q == seg_start);
-        const u32 pg = (q - seg_start) & 63u;
-        const u32 rr = inb ? ((ke + pg) >> 6) + 1 : 0u;
-        const u64 stopmask = __ballot(sfl && lane >= i0);
-        const u32 istop = stopmask ? (u32)__ffsll((long long)stopmask) - 1 : 64u;
-        const u32 endi = B - ws < 64u ? B - ws : 64u;
-        const u32 lim = istop < endi ? istop : endi;
-        const u32 R = wave_scan_add(rr), E = wave_scan_add(ke);
-
-        if (wave == 1) {   // keep the ring one ring ahead of the first position of this round
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (i0 < endi) {
-            const u32 a_r = rdlane_u32(dhc.x, i0) & ~(DP_PIECE - 1);
-            const u32 dlim = a_r + DP_RING < total_pad ? a_r + DP_RING : total_pad;
-            while (issued_end < dlim) {
-              const u32 slot = issued_end & (DP_RING - 1);
-              dp_dma_piece(rows + issued_end + lane * 2, ring_lds + (DP_FRONT + slot) * 8);
-              if (slot < DP_MIRROR) dp_dma_piece(rows + issued_end + lane * 2, ring_lds + (DP_FRONT + DP_RING + slot) * 8);
-              issued_end += DP_PIECE;
-            }
-          }
-        }
-
-        // partition of the round into D2_NP tiles (every producer computes all of it)
-        u32 it = i0, my_start = 0, my_n = 0, my_flags = 0;
-        bool any_flag = false;
-#pragma unroll
-        for (u32 w = 0; w < D2_NP; ++w) {
-          u32 n = 0, fl = 0;
-          if (!stalled && !any_flag) {
-            if (it < lim) {
-              const u32 Rb = it ? rdlane_u32(R, it - 1) : 0u, Eb = it ? rdlane_u32(E, it - 1) : 0u;
-              const u32 pg_it = rdlane_u32(pg, it);
-              const u64 fit = __ballot(lane >= it && lane < lim && lane < it + 8 && R - Rb <= D2_TILE_ROWS &&
-                                       E - Eb <= D2_TILE_EDGES && pg >= pg_it);
-              n = (u32)__popcll(fit);
-            }
-            if (it + n == istop && istop < endi) fl = D2_F_SHORTCUT;
-            else if (it + n == endi && ws + endi == B) fl = D2_F_END;
-          }
-          if (w == my) { my_start = it; my_n = n; my_flags = fl; }
-          it += n;
-          if (fl) any_flag = true;
-        }
-        next_pos = ws + it;
-        if (any_flag) stalled = true;
-
-        // build my tile
-        double* tile = s_tile[r & 1][my];
-        u32* hdr = s_thdr[r & 1][my];
-        const bool mine = lane >= my_start && lane < my_start + my_n;
-        const bool all1 = __ballot(mine && rr != 1) == 0, all2 = __ballot(mine && rr > 2) == 0;
-        const u32 variant = (my_n == 8 && all1) ? 0u : (my_n == 8 && all2) ? 1u : 2u;
-        const u32 Rb = my_start ? rdlane_u32(R, my_start - 1) : 0u;
-        const u32 u_me = lane - my_start;
-        const u32 rowidx = variant == 0 ? u_me : variant == 1 ? 2 * u_me : (R - rr) - Rb;
-        wave_lds_sync();
-        if (mine) {
-          s_ptab[my][u_me] = make_uint4(dhc.x & (DP_RING - 1), ke, pg, rowidx | (rr << 8));
-          hdr[4 + u_me] = rowidx | ((variant == 1 ? 2u : rr) << 8);
-        }
-        const u32 twomask = (u32)(__ballot(mine && rr == 2) >> my_start) & 255u;
-        if (lane == 0) {
-          hdr[0] = (ws + my_start) | (my_n << 24) | (variant << 28) | (my_flags << 30);
-          hdr[1] = twomask;
-        }
-        wave_lds_sync();
-        if (variant != 2) {
-          // 8 positions, 1 or 2 rows each at fixed row indices: everything in flight at once
-          uint4 t[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) t[u] = s_ptab[my][u];   // broadcast reads
-          double v0[8], v1[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const u32 k1 = lane - t[u].z - 1;
-            v0[u] = s_ring[DP_FRONT + (k1 < t[u].y ? t[u].x + k1 : 0u)];
-            if (variant == 1) v1[u] = s_ring[DP_FRONT + (k1 + 64 < t[u].y ? t[u].x + k1 + 64 : 0u)];
-          }
-          if (variant == 0) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) tile[u * 64 + lane] = lane - t[u].z - 1 < t[u].y ? v0[u] : kInf;
-          } else {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-              const u32 k1 = lane - t[u].z - 1;
-              tile[(2 * u) * 64 + lane] = k1 < t[u].y ? v0[u] : kInf;
-              tile[(2 * u + 1) * 64 + lane] = k1 + 64 < t[u].y ? v1[u] : kInf;
-            }
-          }
-        } else {
-          for (u32 u = 0; u < my_n; ++u) {
-            const uint4 t = s_ptab[my][u];   // broadcast
-            const u32 nrows = t.w >> 8;
-            const u32 row0 = t.w & 255u;
-            for (u32 s = 0; s < nrows; ++s) {
-              const u32 k1 = lane - t.z - 1 + 64 * s;
-              const bool valid = k1 < t.y;
-              const double v = s_ring[DP_FRONT + (valid ? t.x + k1 : 0u)];
-              tile[(row0 + s) * 64 + lane] = valid ? v : kInf;
-            }
-          }
-        }
-      }
-      __syncthreads();
-      // the consumer knows what it published; the producers read it
-      u32 c0v = my_ctrl, c1v = my_start_next;
-      if (wave != 0) {
-        c0v = (u32)__builtin_amdgcn_readfirstlane((int)s_ctrl[r & 1][0]);
-        if (c0v == 1) c1v = (u32)__builtin_amdgcn_readfirstlane((int)s_ctrl[r & 1][1]);
-      }
-      if (c0v == 2) { done = true; seg_over = true; }
-      else if (c0v == 1) { seg_start = c1v; exempt = true; seg_over = true; }
-      ++r;
-    }
-    if (done) break;
-  }
-  if (P.prof && tid == 0) {
-    u64* o = P.prof + (u64)b * 16;
-    o[0] = 0; o[1] = t_cons; o[2] = n_fast; o[3] = n_gen; o[4] = B; o[5] = t_wait; o[6] = 0;
+    o[0] = t_stage; o[1] = t_chain; o[2] = n_fast; o[3] = n_slow; o[4] = B; o[5] = t_fast; o[6] = n_two; o[7] = t_two;
   }
 }
 

@@ -1,10 +1,18 @@
-// Minimal fork-join helper for the host-side per-block work (exact block cost,
-// block splitting, encoding).  The reference is single-threaded; spreading the
-// order-insensitive host work over cores removes the Amdahl wall once the
+// Fork-join helper for the host-side per-block work (exact block cost, block
+// splitting, cost model, encoding).  The reference is single-threaded; spreading
+// the order-insensitive host work over cores removes the Amdahl wall once the
 // device owns the O(bytes x iterations) part.
+//
+// The workers are persistent: the per-run cost-model step is called 2 x
+// numiterations times per batch with ~20 us of work per block, and spawning a
+// thread per core per call cost more than the work itself.
 #pragma once
 #include <atomic>
+#include <condition_variable>
+#include <cstdint>
 #include <cstdlib>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -17,35 +25,99 @@ inline unsigned HostThreads() {
       if (v > 0) return static_cast<unsigned>(v);
     }
     const unsigned hc = std::thread::hardware_concurrency();
-    return hc ? hc : 1u;
+    const unsigned cap = 64;  // beyond this the wake-up cost outweighs the per-block work
+    return hc ? (hc < cap ? hc : cap) : 1u;
   }();
   return n;
 }
 
+class WorkerPool {
+ public:
+  static WorkerPool& Get() {
+    static WorkerPool* pool = new WorkerPool(HostThreads());  // leaked on purpose: no join at exit
+    return *pool;
+  }
+
+  // Runs body(i) for i in [0, n) on the workers and the calling thread; returns
+  // when all are done.  One job at a time (callers are serialised).
+  void Run(size_t n, const std::function<void(size_t)>& body) {
+    std::lock_guard<std::mutex> serial(run_mutex_);
+    {
+      std::lock_guard<std::mutex> lock(mutex_);
+      body_ = &body;
+      n_ = n;
+      next_.store(0, std::memory_order_relaxed);
+      pending_ = workers_.size();
+      ++generation_;
+    }
+    wake_.notify_all();
+    Drain(body);
+    std::unique_lock<std::mutex> lock(mutex_);
+    done_.wait(lock, [&] { return pending_ == 0; });
+    body_ = nullptr;
+  }
+
+ private:
+  explicit WorkerPool(unsigned threads) {
+    const unsigned extra = threads > 1 ? threads - 1 : 0;
+    workers_.reserve(extra);
+    for (unsigned t = 0; t < extra; ++t) workers_.emplace_back([this] { Loop(); });
+    for (auto& w : workers_) w.detach();
+  }
+
+  void Drain(const std::function<void(size_t)>& body) {
+    for (;;) {
+      const size_t i = next_.fetch_add(1, std::memory_order_relaxed);
+      if (i >= n_) break;
+      body(i);
+    }
+  }
+
+  void Loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(size_t)>* body;
+      {
+        std::unique_lock<std::mutex> lock(mutex_);
+        wake_.wait(lock, [&] { return generation_ != seen; });
+        seen = generation_;
+        body = body_;
+      }
+      if (body) Drain(*body);
+      {
+        std::lock_guard<std::mutex> lock(mutex_);
+        if (--pending_ == 0) done_.notify_one();
+      }
+    }
+  }
+
+  std::vector<std::thread> workers_;
+  std::mutex run_mutex_, mutex_;
+  std::condition_variable wake_, done_;
+  const std::function<void(size_t)>* body_ = nullptr;
+  size_t n_ = 0;
+  std::atomic<size_t> next_{0};
+  size_t pending_ = 0;
+  uint64_t generation_ = 0;
+};
+
+inline thread_local bool g_inside_parallel_for = false;
+
 // Calls fn(i) for i in [0, n), dynamically load-balanced.  Nested calls run inline.
 template <typename Fn>
 void ParallelFor(size_t n, Fn&& fn) {
-  static thread_local bool inside = false;
-  const unsigned want = static_cast<unsigned>(n < HostThreads() ? n : HostThreads());
-  if (want <= 1 || inside) {
+  bool& inside = g_inside_parallel_for;
+  if (n <= 1 || HostThreads() <= 1 || inside) {
     for (size_t i = 0; i < n; ++i) fn(i);
     return;
   }
-  std::atomic<size_t> next{0};
-  auto worker = [&] {
-    inside = true;
-    for (;;) {
-      const size_t i = next.fetch_add(1, std::memory_order_relaxed);
-      if (i >= n) break;
-      fn(i);
-    }
-    inside = false;
+  const std::function<void(size_t)> body = [&](size_t i) {
+    const bool was = g_inside_parallel_for;   // (thread-local of the executing thread)
+    g_inside_parallel_for = true;
+    fn(i);
+    g_inside_parallel_for = was;
   };
-  std::vector<std::thread> threads;
-  threads.reserve(want - 1);
-  for (unsigned t = 1; t < want; ++t) threads.emplace_back(worker);
-  worker();
-  for (auto& t : threads) t.join();
+  WorkerPool::Get().Run(n, body);
 }
 
 }  // namespace zamd

@@ -1,7 +1,7 @@
 """Generates tests/golden/vectors.json from the REAL reference (oracle/_ref/libzopfli_ref.so,
 compiled from /root/reference by oracle/Makefile).  Run in the build container:
 
-    python tests/golden/make_golden.py [--big]
+    python tests/golden/make_golden.py [--big | --extra]
 
 Each vector: synthetic class / size / seed (zopfli_amd.datagen) or a literal input, the
 ZopfliOptions used, the format, and the SHA-256 + length of the reference's output.
@@ -44,6 +44,29 @@ def run(case):
     return case
 
 
+def extra_cases():
+    """Shapes of the remaining BASELINE configs at sizes the reference finishes in minutes:
+    numiterations=50 on a mixed corpus (config 4), zopflipng's deflate call (config 5: raw
+    deflate of PNG-like scanlines, 15 / 5 iterations), other formats and split limits."""
+    cs = []
+
+    def add(inp, fmt=0, n=15, split=1, smax=15):
+        cs.append({"input": inp, "format": fmt, "numiterations": n, "blocksplitting": split,
+                   "blocksplittingmax": smax})
+
+    add({"kind": "class", "cls": "M", "size": 2500000}, 0, 50)
+    add({"kind": "class", "cls": "T", "size": 1000000}, 0, 50)
+    add({"kind": "class", "cls": "P", "size": 1000000}, 2, 15)
+    add({"kind": "class", "cls": "P", "size": 1000000}, 2, 5)
+    add({"kind": "class", "cls": "T", "size": 1000000}, 1, 15)
+    add({"kind": "class", "cls": "X", "size": 1000000}, 0, 15, 1, 5)
+    add({"kind": "class", "cls": "M", "size": 2500000}, 0, 5, 1, 0)
+    add({"kind": "class", "cls": "T", "size": 300000, "seed": 77}, 0, 1)
+    add({"kind": "class", "cls": "B", "size": 100000, "seed": 9}, 0, 15)
+    add({"kind": "class", "cls": "Z", "size": 2100000, "seed": 11}, 0, 15)
+    return cs
+
+
 def cases(big):
     cs = []
 
@@ -75,9 +98,10 @@ def cases(big):
 
 def main():
     big = "--big" in sys.argv
-    path = os.path.join(HERE, "vectors_big.json" if big else "vectors.json")
-    cs = cases(big)
-    if big:
+    extra = "--extra" in sys.argv
+    path = os.path.join(HERE, "vectors_extra.json" if extra else "vectors_big.json" if big else "vectors.json")
+    cs = extra_cases() if extra else cases(big)
+    if big and not extra:
         cs = [c for c in cs if c["input"].get("size", 0) >= 20000000]
     with mp.Pool(min(8, len(cs))) as pool:
         done = pool.map(run, cs, chunksize=1)

@@ -125,8 +125,13 @@ def test_squeeze_runs(gpu_ctx, case):
 
 
 def _golden(lo, hi):
-    with open(GOLDEN) as f:
-        return [c for c in json.load(f) if lo <= c["insize"] <= hi]
+    out = []
+    for name in ("vectors.json", "vectors_extra.json"):
+        path = os.path.join(os.path.dirname(GOLDEN), name)
+        if os.path.exists(path):
+            with open(path) as f:
+                out += [c for c in json.load(f) if lo <= c["insize"] <= hi]
+    return out
 
 
 def _input(spec):
@@ -138,7 +143,7 @@ def _input(spec):
 
 def _gid(c):
     return (f"{c['input'].get('name', c['input'].get('cls'))}-{c['insize']}-f{c['format']}-n{c['numiterations']}"
-            f"-s{c['blocksplitting']}")
+            f"-s{c['blocksplitting']}-m{c['blocksplittingmax']}")
 
 
 @pytest.mark.parametrize("case", _golden(0, 4000000), ids=_gid)
@@ -177,3 +182,24 @@ def test_full_size_round_trip(gpu_lib):
             for c in json.load(f):
                 if c["insize"] == 20000000 and c["blocksplitting"] == 0 and c["format"] == 0:
                     assert hashlib.sha256(out).hexdigest() == c["sha256"]
+
+
+def test_row_budget_ranges():
+    """The DP edge rows of one launch are capped by ZOPFLI_AMD_ROW_BUDGET_GB; beyond it the blocks of
+    a batch are squeezed in several launch ranges.  20 MB of text needs ~1.2 GB of rows: with a 1 GB
+    budget the batch runs as two ranges and must still produce the reference's bytes."""
+    import subprocess
+    import sys
+    code = (
+        "import hashlib, json, os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from zopfli_amd import ZopfliOptions, api, generate\n"
+        "out = api.compress(generate('T', 20000000), 0, ZopfliOptions(2, 0))\n"
+        "print(hashlib.sha256(out).hexdigest(), len(out))\n" % os.path.dirname(os.path.dirname(__file__)))
+    res = {}
+    for budget in ("1", "96"):
+        env = dict(os.environ, ZOPFLI_AMD_ROW_BUDGET_GB=budget)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[budget] = r.stdout.strip().split()
+    assert res["1"] == res["96"]

@@ -59,6 +59,37 @@ __device__ __forceinline__ int dev_length_extra_bits(u32 l) {
 }
 
 // ----------------------------------------------------------------------------
+// wave-level helpers
+// ----------------------------------------------------------------------------
+// wave64 inclusive scans on the DPP network (row_shr 1/2/4/8, row_bcast 15/31)
+#define ZMX_WAVE_SCAN(NAME, OP, IDENT)                                                   \
+  __device__ __forceinline__ u32 NAME(u32 v) {                                           \
+    u32 t;                                                                               \
+    t = (u32)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x111, 0xf, 0xf, false); v = OP(v, t); \
+    t = (u32)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x112, 0xf, 0xf, false); v = OP(v, t); \
+    t = (u32)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x114, 0xf, 0xf, false); v = OP(v, t); \
+    t = (u32)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x118, 0xf, 0xf, false); v = OP(v, t); \
+    t = (u32)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x142, 0xa, 0xf, false); v = OP(v, t); \
+    t = (u32)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x143, 0xc, 0xf, false); v = OP(v, t); \
+    return v;                                                                            \
+  }
+__device__ __forceinline__ u32 zmx_addu(u32 a, u32 b) { return a + b; }
+__device__ __forceinline__ u32 zmx_maxu(u32 a, u32 b) { return a > b ? a : b; }
+ZMX_WAVE_SCAN(wave_scan_add, zmx_addu, 0u)
+ZMX_WAVE_SCAN(wave_scan_max, zmx_maxu, 0u)
+
+__device__ __forceinline__ u32 rdlane_u32(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ float rdlane_f32(float v, u32 l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)l));
+}
+// cross-lane hand-off through LDS inside ONE wave: the LDS queue is in order per
+// wave, only the compiler has to be kept from reordering
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ----------------------------------------------------------------------------
 // K1a  same[]: run length ahead, bounded by the block end, capped at 65535
 // ----------------------------------------------------------------------------
 #define SAME_CH 64
@@ -437,19 +468,22 @@ __device__ __forceinline__ void hist_add_symbol(u32* hist, u32 litlen, u32 dist)
 
 // ----------------------------------------------------------------------------
 // K3  ZopfliLZ77Greedy (lz77.c:544-630) on the match table: one wave per block.
-//     The wave stages 1024 record headers at a time in LDS, lane 0 runs the
-//     lazy-matching state machine over them, all lanes flush the symbols.
+//     The lazy-matching automaton is a chain of dependent decisions over the
+//     visited positions.  64 record headers sit in VGPRs (lane i = position
+//     wb + i, the next window is prefetched), a step is one v_readlane plus
+//     scalar ALU; what a step emits is a bit in one of two SGPR masks ("this
+//     lane's literal" / "this lane's match"), and the marked lanes write their
+//     symbols and histogram bins once per window.
 // ----------------------------------------------------------------------------
-#define GR_CHUNK 1024u
+__device__ __forceinline__ uint2 greedy_window(const u32* rbase, u32 wb, u32 lane, u32 B) {
+  const u32 q = wb + lane < B ? wb + lane : (B ? B - 1 : 0);
+  return *reinterpret_cast<const uint2*>(rbase + (u64)q * 8);
+}
 
 __global__ __launch_bounds__(64) void k_greedy(const BlockDesc* __restrict__ blocks, const u32* __restrict__ recs,
                                                u32* __restrict__ store, u32* __restrict__ hist_out,
                                                u32* __restrict__ nsym_out) {
-  __shared__ u32 s_d0[GR_CHUNK];
-  __shared__ u8 s_lit[GR_CHUNK];
-  __shared__ u32 s_out[2 * GR_CHUNK + 2];
   __shared__ u32 s_hist[320];
-  __shared__ u32 s_i, s_nout, s_prev_len, s_prev_match, s_prev_lit, s_avail;
 
   const u32 b = blockIdx.x;
   const BlockDesc bd = blocks[b];
@@ -459,71 +493,83 @@ __global__ __launch_bounds__(64) void k_greedy(const BlockDesc* __restrict__ blo
   u32* sbase = store + bd.pos_off;
 
   for (u32 i = lane; i < 320; i += 64) s_hist[i] = 0;
-  if (lane == 0) { s_i = 0; s_prev_len = 0; s_prev_match = 0; s_prev_lit = 0; s_avail = 0; }
   __syncthreads();
 
   u32 total = 0;
-  for (;;) {
-    const u32 c0 = s_i;
-    if (c0 >= B) break;
-    const u32 cn = (B - c0 < GR_CHUNK) ? B - c0 : GR_CHUNK;
-    for (u32 t = lane; t < cn; t += 64) {
-      const uint2 h = *reinterpret_cast<const uint2*>(rbase + (u64)(c0 + t) * 8);
-      s_d0[t] = h.x;
-      s_lit[t] = (u8)(h.y >> 16);
-    }
-    __syncthreads();
-    if (lane == 0) {
-      u32 i = c0, nout = 0;
-      u32 prev_len = s_prev_len, prev_match = s_prev_match, prev_lit = s_prev_lit, avail = s_avail;
-      while (i < c0 + cn) {
-        const u32 h = s_d0[i - c0];
-        u32 leng = h & 0xffffu, dist = h >> 16;
-        const u32 lit = s_lit[i - c0];
-        int lengthscore = dist > 1024 ? (int)leng - 1 : (int)leng;                  // lz77.c:265-271
-        const int prevscore = prev_match > 1024 ? (int)prev_len - 1 : (int)prev_len;
-        bool emit = true;
-        if (avail) {                                                                  // lz77.c:581-607
-          avail = 0;
-          if (lengthscore > prevscore + 1) {
-            s_out[nout++] = prev_lit;                                                 // literal in[i-1]
-            if (lengthscore >= 3 && leng < ZMX_MAX_MATCH) {
-              avail = 1; prev_len = leng; prev_match = dist; prev_lit = lit;
-              emit = false;
+  if (B > 0) {
+    u32 i = 0;                                   // next position to visit
+    bool avail = false;                          // a match is held at position i - 1 (lz77.c:558-562)
+    u32 prev_h = 0, prev_lit = 0;                // its length | dist << 16, and the byte at i - 1
+    int prevscore = 0;
+    u32 wb = 0;
+    uint2 cur = greedy_window(rbase, 0, lane, B);
+    uint2 nxt = greedy_window(rbase, 64, lane, B);
+    for (;;) {
+      const u32 nwin = B - wb < 64u ? B - wb : 64u;
+      const u32 d0_v = cur.x;                    // length | dist << 16 of the position of this lane
+      const u32 lit_v = (cur.y >> 16) & 255u;
+      u64 m_lit = 0, m_match = 0;
+      u32 carry = 0, carry_sym = 0;              // a symbol for position wb - 1 (held across the window edge)
+      int idx = (int)(i - wb);
+      int last = idx;
+      while (idx < (int)nwin) {
+        const u32 h = rdlane_u32(d0_v, (u32)idx);
+        const u32 leng = h & 0xffffu, dist = h >> 16;
+        const int score = dist > 1024 ? (int)leng - 1 : (int)leng;          // lz77.c:265-271
+        last = idx;
+        if (avail) {                                                          // lz77.c:581-607
+          avail = false;
+          if (score > prevscore + 1) {
+            if (idx > 0) m_lit |= 1ull << (idx - 1); else { carry = 1; carry_sym = prev_lit; }
+            if (score >= 3 && leng < ZMX_MAX_MATCH) {
+              avail = true; prev_h = h; prevscore = score;
+              idx += 1;
+              continue;
             }
           } else {
-            s_out[nout++] = prev_len | (prev_match << 16);                           // the held match, at i-1
-            i += prev_len - 1;                                                        // (i-1) + prev_len
+            if (idx > 0) m_match |= 1ull << (idx - 1); else { carry = 1; carry_sym = prev_h; }
+            idx += (int)(prev_h & 0xffffu) - 1;                               // (i - 1) + prev_length
             continue;
           }
-        } else if (lengthscore >= 3 && leng < ZMX_MAX_MATCH) {                       // lz77.c:608-613
-          avail = 1; prev_len = leng; prev_match = dist; prev_lit = lit;
-          emit = false;
+        } else if (score >= 3 && leng < ZMX_MAX_MATCH) {                      // lz77.c:608-613
+          avail = true; prev_h = h; prevscore = score;
+          idx += 1;
+          continue;
         }
-        if (emit) {                                                                   // lz77.c:618-629
-          if (lengthscore >= 3) {
-            s_out[nout++] = leng | (dist << 16);
-          } else {
-            leng = 1;
-            s_out[nout++] = lit;
-          }
-          i += leng;
+        if (score >= 3) {                                                     // lz77.c:618-629
+          m_match |= 1ull << idx;
+          idx += (int)leng;
         } else {
-          i += 1;
+          m_lit |= 1ull << idx;
+          idx += 1;
         }
       }
-      s_i = i; s_nout = nout;
-      s_prev_len = prev_len; s_prev_match = prev_match; s_prev_lit = prev_lit; s_avail = avail;
+      if (avail) prev_lit = rdlane_u32(lit_v, (u32)last);   // the held match is at the last visited position
+      i = wb + (u32)idx;
+      // ---- emit this window's symbols in position order
+      const u64 m_any = m_lit | m_match;
+      if (carry && lane == 0) {
+        sbase[total] = carry_sym;
+        hist_add_symbol(s_hist, carry_sym & 0xffffu, carry_sym >> 16);
+      }
+      if ((m_any >> lane) & 1) {
+        const u32 below = (u32)__popcll(m_any & ((1ull << lane) - 1));
+        const u32 e = ((m_match >> lane) & 1) ? d0_v : lit_v;
+        sbase[total + carry + below] = e;
+        hist_add_symbol(s_hist, e & 0xffffu, e >> 16);
+      }
+      total += carry + (u32)__popcll(m_any);
+      if (i >= B) break;
+      // ---- next window: the prefetched one if the walk ended inside it
+      if (i < wb + 128) {
+        wb += 64;
+        cur = nxt;
+      } else {
+        wb = i;
+        cur = greedy_window(rbase, wb, lane, B);
+      }
+      nxt = greedy_window(rbase, wb + 64, lane, B);
     }
-    __syncthreads();
-    const u32 nout = s_nout;
-    for (u32 t = lane; t < nout; t += 64) {
-      const u32 e = s_out[t];
-      sbase[total + t] = e;
-      hist_add_symbol(s_hist, e & 0xffffu, e >> 16);
-    }
-    total += nout;
-    __syncthreads();
   }
   __syncthreads();
   for (u32 i = lane; i < 320; i += 64) hist_out[(u64)b * 320 + i] = s_hist[i];
@@ -554,34 +600,6 @@ __global__ __launch_bounds__(64) void k_greedy(const BlockDesc* __restrict__ blo
 //         histogram from length_array and the match records.
 // ----------------------------------------------------------------------------
 #define TR_CHUNK 2048u
-
-// wave64 inclusive scans on the DPP network (row_shr 1/2/4/8, row_bcast 15/31)
-#define ZMX_WAVE_SCAN(NAME, OP, IDENT)                                                   \
-  __device__ __forceinline__ u32 NAME(u32 v) {                                           \
-    u32 t;                                                                               \
-    t = (u32)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x111, 0xf, 0xf, false); v = OP(v, t); \
-    t = (u32)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x112, 0xf, 0xf, false); v = OP(v, t); \
-    t = (u32)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x114, 0xf, 0xf, false); v = OP(v, t); \
-    t = (u32)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x118, 0xf, 0xf, false); v = OP(v, t); \
-    t = (u32)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x142, 0xa, 0xf, false); v = OP(v, t); \
-    t = (u32)__builtin_amdgcn_update_dpp((int)(IDENT), (int)v, 0x143, 0xc, 0xf, false); v = OP(v, t); \
-    return v;                                                                            \
-  }
-__device__ __forceinline__ u32 zmx_addu(u32 a, u32 b) { return a + b; }
-__device__ __forceinline__ u32 zmx_maxu(u32 a, u32 b) { return a > b ? a : b; }
-ZMX_WAVE_SCAN(wave_scan_add, zmx_addu, 0u)
-ZMX_WAVE_SCAN(wave_scan_max, zmx_maxu, 0u)
-
-__device__ __forceinline__ u32 rdlane_u32(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
-__device__ __forceinline__ float rdlane_f32(float v, u32 l) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)l));
-}
-// cross-lane hand-off through LDS inside ONE wave: the LDS queue is in order per
-// wave, only the compiler has to be kept from reordering
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
 
 // ---------------------------------------------------------------- k_rowscan
 struct RowScanParams {

@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--numiterations", type=int, default=15)
     ap.add_argument("--cpu-sample", type=int, default=8 * MB)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo "
+                    "exercises the same sharding/gather/merge code where only one GPU is visible)")
+    ap.add_argument("--device-index", type=int, default=None, help="HIP device of this rank (default LOCAL_RANK)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -70,10 +73,15 @@ def main():
     from zopfli_amd import Context, ZopfliOptions, api, generate, sharding
     from zopfli_amd.sharding import crc32_combine
 
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.device_index is None else args.device_index
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
+            device = torch.device("cpu")   # payload tensors of the gather live where the backend can reach them
 
     lib = api.library()
     options = ZopfliOptions(args.numiterations, args.blocksplitting, 15)
@@ -86,7 +94,7 @@ def main():
     if rank > 0:
         prefix = generate("T", size, seed=rank)[-WINDOW:]  # tail of the previous shard = dictionary
     resident = prefix + shard
-    ctx = Context(local_rank, lib)
+    ctx = Context(dev_index, lib)
     ctx.set_input(resident)  # H2D, outside the timed region
     instart, inend = len(prefix), len(resident)
     final = 1 if rank == world - 1 else 0

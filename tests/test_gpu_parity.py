@@ -203,3 +203,23 @@ def test_row_budget_ranges():
         assert r.returncode == 0, r.stderr[-2000:]
         res[budget] = r.stdout.strip().split()
     assert res["1"] == res["96"]
+
+
+def test_reference_cli_linked_against_libzopfli_amd(tmp_path):
+    """the reference's own zopfli_bin.c, linked with -lzopfli_amd, writes the
+    same .gz / .zlib / .deflate files as the real reference library produces."""
+    import subprocess
+    from zopfli_amd._build import REF_CLI
+    if not os.path.exists(REF_CLI):
+        pytest.skip("tests/_build/zopfli_ref_cli_amd not built (needs /root/reference at build time)")
+    data = generate("X", 300000, 5)
+    src = tmp_path / "input.xml"
+    src.write_bytes(data)
+    for flag, ext, fmt in (("--gzip", ".gz", 0), ("--zlib", ".zlib", 1), ("--deflate", ".deflate", 2)):
+        r = subprocess.run([REF_CLI, flag, "--i5", str(src)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = (tmp_path / ("input.xml" + ext)).read_bytes()
+        if fmt == 0:
+            assert gzip.decompress(out) == data
+        if ol.have_ref():
+            assert out == ol.ref_compress(data, fmt, 5)

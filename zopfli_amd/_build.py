@@ -53,3 +53,22 @@ def build_oracle():
 def build_hosttest():
     """Test infrastructure: product host sources + oracle-backed zmx layer (CPU-only checks)."""
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hostlib")])
+
+
+REF_CLI = os.path.join(ROOT, "tests", "_build", "zopfli_ref_cli_amd")
+
+
+def build_ref_cli():
+    """Test infrastructure: the REFERENCE's own CLI (src/zopfli/zopfli_bin.c, compiled where it lies
+    under /root/reference, nothing copied) linked against libzopfli_amd.so instead of libzopfli —
+    the drop-in claim of INTEGRATION.md section 1.  Only possible where /root/reference exists; the
+    binary travels to the GPU box in tests/_build/."""
+    src = "/root/reference/src/zopfli/zopfli_bin.c"
+    if not os.path.exists(src):
+        return None
+    os.makedirs(os.path.dirname(REF_CLI), exist_ok=True)
+    if _newer(REF_CLI, [src, LIB]):
+        subprocess.check_call(["gcc", "-O2", "-w", src, "-I/root/reference/src/zopfli",
+                               "-L" + os.path.dirname(LIB), "-lzopfli_amd",
+                               "-Wl,-rpath," + os.path.dirname(LIB), "-o", REF_CLI])
+    return REF_CLI

@@ -223,3 +223,29 @@ def test_reference_cli_linked_against_libzopfli_amd(tmp_path):
             assert gzip.decompress(out) == data
         if ol.have_ref():
             assert out == ol.ref_compress(data, fmt, 5)
+
+
+def test_small_batches_and_threads():
+    """Device batches smaller than the request (ZOPFLI_AMD_PARTS_PER_BATCH=2 on 5 master blocks) and
+    two caller threads at once (the shared context serialises them) give the bytes of the default run."""
+    import subprocess
+    import sys
+    code = (
+        "import hashlib, sys, threading\n"
+        "sys.path.insert(0, %r)\n"
+        "from zopfli_amd import ZopfliOptions, api, generate\n"
+        "data = [generate('M', 4300000), generate('X', 1200000, 3)]\n"
+        "out = [None, None]\n"
+        "def run(i): out[i] = api.compress(data[i], 0, ZopfliOptions(2))\n"
+        "ts = [threading.Thread(target=run, args=(i,)) for i in range(2)]\n"
+        "[t.start() for t in ts]; [t.join() for t in ts]\n"
+        "print(' '.join(hashlib.sha256(o).hexdigest() for o in out))\n" % os.path.dirname(os.path.dirname(__file__)))
+    res = {}
+    for batch in ("2", "256"):
+        env = dict(os.environ, ZOPFLI_AMD_PARTS_PER_BATCH=batch)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[batch] = r.stdout.strip().split()
+    assert res["2"] == res["256"]
+    if ol.have_ref():
+        assert res["2"][0] == hashlib.sha256(ol.ref_compress(generate("M", 4300000), 0, 2)).hexdigest()

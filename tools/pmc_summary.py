@@ -5,6 +5,7 @@ on output (`fetch_bytes`) as MI355X_MICROARCH.md prescribes for gfx950 wide coal
 import collections
 import csv
 import json
+import re
 import sys
 
 
@@ -15,7 +16,7 @@ def main(paths):
         launches = collections.defaultdict(set)
         with open(path) as f:
             for r in csv.DictReader(f):
-                k = r["Kernel_Name"].split("(")[0]
+                k = re.sub(r"<.*>$", "", re.sub(r"^void\s+", "", r["Kernel_Name"].split("(")[0]))   # k_dp<false> -> k_dp
                 agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
                 launches[k].add(r["Dispatch_Id"])
         for k, v in agg.items():

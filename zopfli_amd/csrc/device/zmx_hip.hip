@@ -494,7 +494,8 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     if (tiles) hipLaunchKernelGGL(k_edges, dim3(tiles), dim3(256), 0, c->stream, ep);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
-    hipLaunchKernelGGL(k_dp, dim3(nblk), dim3(64), 0, c->stream, cp);
+    if (cp.prof) hipLaunchKernelGGL(k_dp<true>, dim3(nblk), dim3(64), 0, c->stream, cp);   // ZOPFLI_AMD_PROF
+    else hipLaunchKernelGGL(k_dp<false>, dim3(nblk), dim3(64), 0, c->stream, cp);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
     hipLaunchKernelGGL(k_trace, dim3(nblk), dim3(64), 0, c->stream, tp);

@@ -905,6 +905,7 @@ __device__ __forceinline__ void dp_fast_block(const double* ring0, const uint2* 
   }
 }
 
+template <bool PROF>
 __global__ __launch_bounds__(64) void k_dp(DpParams P) {
   __shared__ __align__(16) double s_ring[DP_FRONT + DP_RING + DP_MIRROR];
   __shared__ float s_xc[DP_XN];
@@ -928,8 +929,8 @@ __global__ __launch_bounds__(64) void k_dp(DpParams P) {
   const u32 ring_lds = (u32)(unsigned long)(__attribute__((address_space(3))) double*)s_ring;
 
   u64 t_stage = 0, t_chain = 0, t_mark = 0, n_fast = 0, n_slow = 0, t_fast = 0, n_two = 0, t_two = 0;
-  const bool prof = P.prof != nullptr;
-#define DP_TICK() (prof ? (u64)__builtin_readcyclecounter() : 0ull)
+  const bool prof = PROF && P.prof != nullptr;   // the counters exist only in the profiling instantiation
+#define DP_TICK() (PROF ? (u64)__builtin_readcyclecounter() : 0ull)
 
   // cost cells of the current group: c[s] of lane l = cell base + 64 s + l; l[s] = 1 + the
   // position the cell was reached from (0 = never), so length_array = cell + 1 - l[s]

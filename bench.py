@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 MB = 1000000
 WINDOW = 32768
-PMC_PROFILE = "r01_v2_bench100MB_pmc.json"
+PMC_PROFILE = "r01_v3_bench100MB_pmc.json"
 
 
 def cpu_baseline(sample, options):

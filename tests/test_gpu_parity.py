@@ -249,3 +249,45 @@ def test_small_batches_and_threads():
     assert res["2"] == res["256"]
     if ol.have_ref():
         assert res["2"][0] == hashlib.sha256(ol.ref_compress(generate("M", 4300000), 0, 2)).hexdigest()
+
+
+def _write_png(path, width, height, seed):
+    """A valid RGBA8 PNG (filter 0, zlib level 6) of a smooth gradient plus noise — no imaging library."""
+    import struct
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:height, 0:width]
+    img = np.stack([(x * 255 // max(width - 1, 1)), (y * 255 // max(height - 1, 1)), ((x + y) // 3 % 256),
+                    np.full_like(x, 255)], axis=-1).astype(np.int32)
+    img[..., :3] += rng.integers(-3, 4, size=(height, width, 3))
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    raw = b"".join(b"\x00" + img[r].tobytes() for r in range(height))
+
+    def chunk(tag, data):
+        body = tag + data
+        return struct.pack(">I", len(data)) + body + struct.pack(">I", zlib.crc32(body) & 0xffffffff)
+
+    png = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, 8, 6, 0, 0, 0))
+           + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+    with open(path, "wb") as f:
+        f.write(png)
+
+
+def test_zopflipng_linked_against_libzopfli_amd(tmp_path):
+    """BASELINE config 5 plumbing at 384x256: the reference's zopflipng linked with -lzopfli_amd writes the
+    same PNG as the all-reference build (CustomPNGDeflate -> ZopfliDeflate, zopflipng_lib.cc:47-66)."""
+    import subprocess
+    from zopfli_amd._build import PNG_AMD, PNG_REF
+    if not (os.path.exists(PNG_AMD) and os.path.exists(PNG_REF)):
+        pytest.skip("tests/_build/zopflipng_* not built (needs /root/reference at build time)")
+    src = str(tmp_path / "in.png")
+    _write_png(src, 384, 256, 7)
+    outs = {}
+    for name, exe in (("amd", PNG_AMD), ("ref", PNG_REF)):
+        dst = str(tmp_path / (name + ".png"))
+        r = subprocess.run([exe, "-y", "--iterations=5", "--filters=0p", src, dst], capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, (name, r.stdout[-1000:], r.stderr[-1000:])
+        with open(dst, "rb") as f:
+            outs[name] = f.read()
+    assert outs["amd"] == outs["ref"]
+    assert len(outs["amd"]) < os.path.getsize(src)

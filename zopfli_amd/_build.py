@@ -72,3 +72,35 @@ def build_ref_cli():
                                "-L" + os.path.dirname(LIB), "-lzopfli_amd",
                                "-Wl,-rpath," + os.path.dirname(LIB), "-o", REF_CLI])
     return REF_CLI
+
+
+PNG_AMD = os.path.join(ROOT, "tests", "_build", "zopflipng_amd")
+PNG_REF = os.path.join(ROOT, "tests", "_build", "zopflipng_ref")
+
+
+def build_zopflipng():
+    """Test infrastructure: the reference's zopflipng (src/zopflipng/*.cc + its vendored LodePNG, compiled
+    where they lie under /root/reference) twice — once with the reference's own zopfli objects and once
+    against libzopfli_amd.so (CustomPNGDeflate -> ZopfliDeflate, zopflipng_lib.cc:47-66).  INTEGRATION.md
+    section 3; both binaries travel to the GPU box in tests/_build/."""
+    ref = "/root/reference/src"
+    if not os.path.isdir(os.path.join(ref, "zopflipng")):
+        return None
+    os.makedirs(os.path.dirname(PNG_AMD), exist_ok=True)
+    png = [os.path.join(ref, "zopflipng", f) for f in ("zopflipng_bin.cc", "zopflipng_lib.cc")]
+    png += [os.path.join(ref, "zopflipng", "lodepng", f) for f in ("lodepng.cpp", "lodepng_util.cpp")]
+    if _newer(PNG_AMD, png + [LIB]):
+        subprocess.check_call(["g++", "-O2", "-w"] + png + ["-L" + os.path.dirname(LIB), "-lzopfli_amd",
+                              "-Wl,-rpath," + os.path.dirname(LIB), "-o", PNG_AMD])
+    if _newer(PNG_REF, png):
+        zsrc = os.path.join(ref, "zopfli")
+        zc = [os.path.join(zsrc, f) for f in sorted(os.listdir(zsrc)) if f.endswith(".c") and f != "zopfli_bin.c"]
+        objdir = os.path.join(ROOT, "tests", "_build", "zref_obj")
+        os.makedirs(objdir, exist_ok=True)
+        objs = []
+        for c in zc:
+            o = os.path.join(objdir, os.path.basename(c)[:-2] + ".o")
+            subprocess.check_call(["gcc", "-O2", "-w", "-c", c, "-o", o])
+            objs.append(o)
+        subprocess.check_call(["g++", "-O2", "-w"] + png + objs + ["-lm", "-o", PNG_REF])
+    return PNG_AMD

@@ -70,8 +70,18 @@ struct BitStream {
       bytes.resize((total_bits + 7) / 8, 0);
       uint8_t* dst = bytes.data() + old - 1;
       uint8_t* const end = bytes.data() + bytes.size();
-      unsigned carry = *dst;
-      for (size_t i = 0; i < nbytes; ++i) {
+      uint64_t carry = *dst;   // the sh bits already used in the last byte
+      size_t i = 0;
+      // eight source bytes per step: out = carry | v << sh, next carry = the sh bits shifted out
+      for (; i + 8 <= nbytes && dst + 8 <= end; i += 8) {
+        uint64_t v;
+        std::memcpy(&v, src + i, 8);
+        const uint64_t out = carry | (v << sh);
+        std::memcpy(dst, &out, 8);
+        dst += 8;
+        carry = v >> (64 - sh);
+      }
+      for (; i < nbytes; ++i) {
         const unsigned v = src[i];
         *dst++ = static_cast<uint8_t>(carry | (v << sh));
         carry = v >> (8 - sh);

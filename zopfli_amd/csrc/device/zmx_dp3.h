@@ -1,0 +1,346 @@
+// k_dp3: the DP chain of k_dp with its row fetching / masking moved to three producer
+// waves of the same workgroup.  Included only by zmx_hip.hip, after zmx_kernels.h.
+//
+// A lone wave issues about one instruction per 4.3 cycles; in k_dp 8 of the ~26
+// instructions per position (and both LDS round trips) only fetch and mask row values.
+// Here every wave of the workgroup walks the SAME deterministic sequence of steps — a step
+// is a run of positions of one 64-position group whose edge rows span at most D3_SPAN ring
+// slots; where it ends (span, group end, long-run shortcut, block end) depends only on
+// dph[], never on DP values — so no wave has to tell another where it is:
+//
+//   wave 0 (consumer)   runs one step behind: reads ready-made 64-lane rows (+inf outside the
+//                       row) of a step from an LDS tile and runs the chain; positions that
+//                       need more than two cell registers, ragged tails and shortcuts use
+//                       k_dp's generic path straight from the ring.
+//   waves 1..3          build the tile of the step (8-position blocks round-robin); wave 1
+//                       also keeps the LDS row ring filled by LDS-DMA.
+//   one s_barrier per step; tiles are double buffered.
+//
+// After a shortcut (and at the start) the ring restarts at a new place: the walk inserts
+// two bubble steps so that nobody reads the ring while wave 1 primes it.
+#pragma once
+
+#define D3_NP 3u
+#define D3_SPAN 896u     // rows of four consecutive steps fit in the ring (4 * 896 + slack <= 4096)
+#define D3_EV_NONE 0u
+#define D3_EV_SHORTCUT 1u
+#define D3_EV_GROUP_END 2u
+#define D3_EV_BUBBLE 3u  // nothing to do
+#define D3_EV_PRIME 4u   // wave 1 primes the ring at the start of the segment that follows
+
+struct D3Group {          // the current group: lane l = position base + l
+  u32 roff, kend, offend; // kend = 0 beyond the block end
+  u64 m_short, m_r1, m_bad;   // m_bad: positions that cannot be in a fast block
+  u32 navail;
+};
+
+struct D3Walk {           // wave-uniform walker state (+ the per-lane dph prefetch)
+  u32 base = 0, q = 0;
+  bool noshort = false, have_group = false;
+  u32 bubbles = 2;        // the walk starts with BUBBLE, PRIME
+  u32 pf_base = 0xffffffffu;
+  uint2 pf_dh = make_uint2(0, 0);
+};
+
+struct D3Step {
+  u32 base, q, n, event, a_cur;
+};
+
+__device__ __forceinline__ void d3_load_group(D3Walk& W, D3Group& G, const uint2* dbase, u32 B, u32 lane) {
+  const u32 jj = W.base + lane;
+  G.navail = (B - W.base < 64u) ? B - W.base : 64u;   // W.base <= B
+  const bool act = lane < G.navail;
+  uint2 dh = W.pf_dh;
+  if (W.pf_base != W.base) dh = dbase[jj < B ? jj : B - 1];
+  W.pf_base = W.base + 64;
+  W.pf_dh = dbase[jj + 64 < B ? jj + 64 : B - 1];
+  G.kend = act ? (dh.y & 0xffffu) : 0u;
+  G.roff = dh.x;
+  G.offend = G.roff + G.kend;
+  G.m_short = __ballot(act && (dh.y >> 16) != 0);
+  G.m_r1 = __ballot(G.kend + lane >= 64u);                            // needs cell register 1
+  G.m_bad = G.m_short | __ballot(G.kend + lane >= 128u) | (G.m_r1 & 0xffffffffull);  // tile2 holds lanes 32..63 only
+  W.have_group = true;
+}
+
+// The next step of the walk.  Identical in every wave.
+__device__ __forceinline__ D3Step d3_next(D3Walk& W, D3Group& G, const uint2* dbase, u32 B, u32 lane) {
+  D3Step S;
+  if (W.bubbles) {
+    S.base = W.base; S.q = 0; S.n = 0; S.a_cur = 0;
+    S.event = W.bubbles == 2 ? D3_EV_BUBBLE : D3_EV_PRIME;
+    --W.bubbles;
+    return S;
+  }
+  if (!W.have_group) { d3_load_group(W, G, dbase, B, lane); W.q = 0; }
+  u64 ms = W.q < 64 ? G.m_short & ~((1ull << W.q) - 1) : 0ull;
+  if (W.noshort) ms &= ~(1ull << W.q);               // squeeze.c:273: not tested again right after a shortcut
+  const u32 stop = ms ? (u32)__ffsll((long long)ms) - 1 : 64u;
+  const u32 limit = stop < G.navail ? stop : G.navail;
+  S.base = W.base; S.q = W.q; S.n = 0; S.a_cur = 0;
+  if (W.q < limit) {
+    S.a_cur = rdlane_u32(G.roff, W.q) & ~(DP_PIECE - 1);
+    const u64 fit = __ballot(lane >= W.q && lane < limit && G.offend - S.a_cur <= D3_SPAN);
+    S.n = (u32)__popcll(fit);
+  }
+  if (ms && W.q + S.n == stop) {                     // a flagged position follows
+    S.event = D3_EV_SHORTCUT;
+    W.base = W.base + stop + ZMX_MAX_MATCH;
+    W.noshort = true;
+    W.have_group = false;
+    W.bubbles = 2;
+  } else if (W.q + S.n == G.navail) {
+    S.event = D3_EV_GROUP_END;
+    W.base += 64;
+    if (S.n) W.noshort = false;
+    W.have_group = false;
+  } else {
+    S.event = D3_EV_NONE;
+    W.q += S.n;
+    W.noshort = false;
+  }
+  return S;
+}
+
+__device__ __forceinline__ bool d3_fast(const D3Step& S, const D3Group& G, u32 p0) {
+  return p0 + 8 <= S.q + S.n && ((u32)(G.m_bad >> p0) & 255u) == 0;
+}
+
+template <bool PROF>
+__global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
+  __shared__ __align__(16) double s_ring[DP_FRONT + DP_RING + DP_MIRROR];
+  __shared__ __align__(16) double s_t1[2][64 * 64];   // register-0 rows, row = position in the group
+  __shared__ __align__(16) double s_t2[2][32 * 64];   // register-1 rows, row = position & 31
+  __shared__ uint2 s_tab[D3_NP][64];
+  __shared__ float s_xc[DP_XN];
+  __shared__ u16 s_xl[DP_XN];
+
+  const u32 tid = threadIdx.x;
+  const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const u32 lane = tid & 63;
+  const u32 b = P.block0 + blockIdx.x;
+  const BlockDesc bd = P.blocks[b];
+  const u32 B = (u32)(bd.inend - bd.instart);
+  if (B == 0) return;
+  const uint2* dbase = P.dph + bd.pos_off;
+  u16* la = P.la + bd.la_off;
+  const double* rows = P.rows + P.row_base[b];
+  const u32 total_pad = (u32)((P.block_edges[b] + DP_PIECE - 1) & ~(u64)(DP_PIECE - 1));
+  const double mincost = P.mincost[b];
+  // squeeze.c:260: cost of (length 258, dist 1) = (0 + 0) + ll[285] + d[0]
+  const double symbolcost258 = (double)(0 + 0) + P.cost[(u64)b * 320 + 285] + P.cost[(u64)b * 320 + 288];
+  const double kInf = __longlong_as_double(0x7ff0000000000000ll);
+  const u32 ring_lds = (u32)(unsigned long)(__attribute__((address_space(3))) double*)s_ring;
+
+  D3Walk W;
+  D3Group G;
+  G.roff = G.kend = G.offend = 0; G.m_short = G.m_r1 = G.m_bad = 0; G.navail = 0;
+
+  if (wave == 0) {
+    // ================================================================= consumer
+    float c[6];
+    u32 l[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) { c[s] = 1e30f; l[s] = 0; }
+    if (lane == 0) c[0] = 0.0f;
+    u64 t_work = 0, n_fast = 0, n_slow = 0, n_steps = 0;
+
+    __syncthreads();   // iteration 0: the producers' first step, nothing to consume yet
+    u32 it = 1;
+    while (W.bubbles || W.base <= B) {
+      const u64 tw0 = PROF ? (u64)__builtin_readcyclecounter() : 0ull;
+      const D3Step S = d3_next(W, G, dbase, B, lane);
+      const double* t1 = s_t1[(it - 1) & 1];
+      const double* t2 = s_t2[(it - 1) & 1];
+      u32 base = S.base;
+      u32 p0 = S.q;
+      while (p0 < S.q + S.n) {
+        if (d3_fast(S, G, p0)) {
+          const bool two = ((u32)(G.m_r1 >> p0) & 255u) != 0;
+          double w0[8], w1[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) w0[u] = t1[(p0 + u) * 64 + lane];
+          if (two) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w1[u] = t2[((p0 + u) & 31) * 64 + lane];
+          }
+          if (!two) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const u32 p = p0 + u;
+              const double cj = (double)rdlane_f32(c[0], p);
+              const u32 src1 = base + p + 1;
+              const double mcl0 = __builtin_amdgcn_inverse_ballot_w64(2ull << p) ? -kInf : mincost;   // lane p + 1: the literal
+              DP_RELAX(c[0], l[0], w0[u], mcl0)
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const u32 p = p0 + u;
+              const double cj = (double)rdlane_f32(c[0], p);
+              const u32 src1 = base + p + 1;
+              const double mcl0 = __builtin_amdgcn_inverse_ballot_w64(2ull << p) ? -kInf : mincost;
+              DP_RELAX(c[0], l[0], w0[u], mcl0)
+              const double mcl1 = __builtin_amdgcn_inverse_ballot_w64((u64)((p + 1) >> 6)) ? -kInf : mincost;   // p = 63: lane 0
+              DP_RELAX(c[1], l[1], w1[u], mcl1)
+            }
+          }
+          n_fast += 8;
+          p0 += 8;
+          continue;
+        }
+        // generic path straight from the ring (ragged tails, long matches, exempt flagged positions)
+        const u32 pend = p0 + 8 <= S.q + S.n ? p0 + 8 : S.q + S.n;
+        for (u32 p = p0; p < pend; ++p) {
+          const u32 ke = rdlane_u32(G.kend, p);
+          const u32 ro = rdlane_u32(G.roff, p);
+          const double cj = (double)rdlane_f32(c[0], p);
+          const u32 src1 = base + p + 1;
+          const u32 km1 = lane - p - 1;
+          const u32 smax = (ke + p) >> 6;
+#pragma unroll
+          for (int s = 0; s < 6; ++s) {
+            if ((u32)s <= smax) {
+              const u32 k1 = km1 + 64u * s;
+              if (k1 < ke) {
+                const double w = s_ring[DP_FRONT + ((ro + k1) & (DP_RING - 1))];
+                const double mcl = k1 == 0 ? -kInf : mincost;
+                DP_RELAX(c[s], l[s], w, mcl)
+              }
+            }
+          }
+        }
+        n_slow += pend - p0;
+        p0 = pend;
+      }
+      if (S.event == D3_EV_GROUP_END) {
+        // cells base..base+63 are final
+        const u32 jj = base + lane;
+        if (jj <= B && jj >= 1) la[jj] = (u16)(l[0] ? jj + 1 - l[0] : 0u);
+#pragma unroll
+        for (int s = 0; s < 5; ++s) { c[s] = c[s + 1]; l[s] = l[s + 1]; }
+        c[5] = 1e30f;
+        l[5] = 0;
+      } else if (S.event == D3_EV_SHORTCUT) {
+        // long-run shortcut at position q + n of the group (squeeze.c:251-271)
+        const u32 p = S.q + S.n;
+        const u32 j = base + p;
+        if (lane < p && base + lane >= 1) la[base + lane] = (u16)(l[0] ? base + lane + 1 - l[0] : 0u);
+        wave_lds_sync();
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+          const u32 x = base + 64u * s + lane;
+          s_xc[64 * s + lane] = c[s];
+          s_xl[64 * s + lane] = (u16)(l[s] ? x + 1 - l[s] : 0u);
+        }
+        wave_lds_sync();
+        // costs[j+t+258] = costs[j+t] + symbolcost for t = 0..257, unconditionally; cells
+        // j..j+257 are consumed with the lengths they have now
+        float nc4[5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+          const u32 t = 64u * r + lane;
+          nc4[r] = 1e30f;
+          if (t < ZMX_MAX_MATCH) {
+            la[j + t] = s_xl[p + t];
+            nc4[r] = (float)((double)s_xc[p + t] + symbolcost258);
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < 6; ++s) { c[s] = 1e30f; l[s] = 0; }
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+          const u32 t = 64u * r + lane;
+          if (t < ZMX_MAX_MATCH) { c[r] = nc4[r]; l[r] = j + t + 1; }
+        }
+        wave_lds_sync();
+      }
+      if (PROF) { t_work += (u64)__builtin_readcyclecounter() - tw0; ++n_steps; }
+      __syncthreads();
+      ++it;
+    }
+    if (lane == 0) la[0] = 0;
+    if (PROF && P.prof && lane == 0) {
+      u64* o = P.prof + (u64)b * 16;
+      o[0] = n_steps; o[1] = t_work; o[2] = n_fast; o[3] = n_slow; o[4] = B; o[5] = t_work; o[6] = 0; o[7] = 0;
+    }
+    return;
+  }
+
+  // =================================================================== producers
+  const u32 my = wave - 1;
+  u32 issued_end = 0;      // wave 1: rows [.., issued_end) have been requested into the ring
+  u32 a_prev = 0;          // a_cur of the step the consumer works on during this iteration
+  u32 it = 0;
+  bool more = true;
+  while (more) {
+    const D3Step S = d3_next(W, G, dbase, B, lane);
+    more = W.bubbles || W.base <= B;
+    if (S.event == D3_EV_PRIME) {
+      // the segment that follows starts at W.base: load its group now, prime the ring from there
+      if (!W.have_group && W.base <= B) { d3_load_group(W, G, dbase, B, lane); W.q = 0; }
+      if (wave == 1) {
+        const u32 a0 = rdlane_u32(G.roff, 0) & ~(DP_PIECE - 1);
+        issued_end = a0;
+        a_prev = a0;
+        const u32 lim = a0 + DP_RING < total_pad ? a0 + DP_RING : total_pad;
+        while (issued_end < lim) {
+          const u32 slot = issued_end & (DP_RING - 1);
+          dp_dma_piece(rows + issued_end + lane * 2, ring_lds + (DP_FRONT + slot) * 8);
+          if (slot < DP_MIRROR) dp_dma_piece(rows + issued_end + lane * 2, ring_lds + (DP_FRONT + DP_RING + slot) * 8);
+          issued_end += DP_PIECE;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    } else if (S.event != D3_EV_BUBBLE) {
+      if (wave == 1) {
+        // what was requested during the previous step has landed; keep the ring one ring ahead of
+        // the step the consumer is reading
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const u32 lim = a_prev + DP_RING < total_pad ? a_prev + DP_RING : total_pad;
+        while (issued_end < lim) {
+          const u32 slot = issued_end & (DP_RING - 1);
+          dp_dma_piece(rows + issued_end + lane * 2, ring_lds + (DP_FRONT + slot) * 8);
+          if (slot < DP_MIRROR) dp_dma_piece(rows + issued_end + lane * 2, ring_lds + (DP_FRONT + DP_RING + slot) * 8);
+          issued_end += DP_PIECE;
+        }
+        if (S.n) a_prev = S.a_cur;
+      }
+      if (S.n) {
+        // my copy of the per-position table of this group (cheap enough to redo per step)
+        wave_lds_sync();
+        s_tab[my][lane] = make_uint2(((G.roff & (DP_RING - 1)) - lane - 1) * 8u, G.kend);
+        wave_lds_sync();
+        double* t1 = s_t1[it & 1];
+        double* t2 = s_t2[it & 1];
+        const char* ring0 = reinterpret_cast<const char*>(s_ring + DP_FRONT);
+        u32 blk = 0;
+        for (u32 p0 = S.q; p0 < S.q + S.n; p0 += 8) {
+          if (!d3_fast(S, G, p0)) continue;   // (a non-fast block is at most 8 positions: the walk realigns after it)
+          if ((blk++ % D3_NP) != my) continue;
+          const bool two = ((u32)(G.m_r1 >> p0) & 255u) != 0;
+          uint2 t[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[u] = s_tab[my][p0 + u];
+          double v0[8], v1[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const double* row = reinterpret_cast<const double*>(ring0 + (int)t[u].x);
+            v0[u] = row[lane];                 // row[lane] = edge k = lane - p
+            if (two) v1[u] = row[lane + 64];
+          }
+          const u32 d0 = lane - p0 - 1;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const u32 km1 = d0 - u;
+            t1[(p0 + u) * 64 + lane] = km1 < t[u].y ? v0[u] : kInf;
+            if (two) t2[((p0 + u) & 31) * 64 + lane] = km1 + 64 < t[u].y ? v1[u] : kInf;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    ++it;
+  }
+  __syncthreads();   // the consumer's last step
+}

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "zmx_kernels.h"
+#include "zmx_dp3.h"
 #include "zopfli_amd.h"
 
 namespace {
@@ -494,8 +495,14 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     if (tiles) hipLaunchKernelGGL(k_edges, dim3(tiles), dim3(256), 0, c->stream, ep);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
-    if (cp.prof) hipLaunchKernelGGL(k_dp<true>, dim3(nblk), dim3(64), 0, c->stream, cp);   // ZOPFLI_AMD_PROF
-    else hipLaunchKernelGGL(k_dp<false>, dim3(nblk), dim3(64), 0, c->stream, cp);
+    static const bool one_wave = [] { const char* e = std::getenv("ZOPFLI_AMD_DP"); return e && e[0] == '1'; }();
+    if (one_wave) {   // the single-wave chain (A/B reference)
+      if (cp.prof) hipLaunchKernelGGL(k_dp<true>, dim3(nblk), dim3(64), 0, c->stream, cp);   // ZOPFLI_AMD_PROF
+      else hipLaunchKernelGGL(k_dp<false>, dim3(nblk), dim3(64), 0, c->stream, cp);
+    } else {
+      if (cp.prof) hipLaunchKernelGGL(k_dp3<true>, dim3(nblk), dim3(64 * (D3_NP + 1)), 0, c->stream, cp);
+      else hipLaunchKernelGGL(k_dp3<false>, dim3(nblk), dim3(64 * (D3_NP + 1)), 0, c->stream, cp);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
     hipLaunchKernelGGL(k_trace, dim3(nblk), dim3(64), 0, c->stream, tp);

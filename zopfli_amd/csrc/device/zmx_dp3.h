@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
         }
         if (S.n) a_prev = S.a_cur;
       }
-      if (S.n) {
+      if (S.n && !(PROF && P.debug_nofetch)) {
         // my copy of the per-position table of this group (cheap enough to redo per step)
         wave_lds_sync();
         s_tab[my][lane] = make_uint2(((G.roff & (DP_RING - 1)) - lane - 1) * 8u, G.kend);

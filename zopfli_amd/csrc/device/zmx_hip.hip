@@ -472,6 +472,8 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   cp.block_edges = t->d_block_edges;
   cp.la = t->d_la;
   cp.prof = t->d_prof;
+  static const bool nofetch = std::getenv("ZOPFLI_AMD_DEBUG_NOFETCH") != nullptr;
+  cp.debug_nofetch = nofetch ? 1 : 0;
   TraceParams tp;
   tp.blocks = t->d_blocks;
   tp.recs = t->d_recs;
@@ -517,6 +519,7 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   }
   HIPCHK(hipMemcpyAsync(nsym, t->d_nsym, t->nb * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(hist, t->d_hist, t->nb * ZMX_HIST * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  if (nofetch) std::fprintf(stderr, "DEBUG_NOFETCH: k_dp %.2f ms\n", ksec[1] * 1e3);
   const int rc = CheckFlags(c, t, "zmx_squeeze_run");
   if (rc) return rc;
   {

@@ -835,6 +835,7 @@ struct DpParams {
   const u64* block_edges;
   u16* la;
   u64* prof;               // optional [nb_total][8] cycle counters (ZOPFLI_AMD_PROF=1), else null
+  int debug_nofetch;       // timing experiment (profiling build only): producers build nothing, results are wrong
 };
 
 // One position of the chain on cell register `CS` (round S): the edge values `WV`

@@ -20,6 +20,20 @@
 // two bubble steps so that nobody reads the ring while wave 1 primes it.
 #pragma once
 
+// On a fast block the mincost test of squeeze.c:293 is provably a no-op: the producers verify
+// that every match edge of the block costs at least mincost (w >= mincost); rounding is monotone,
+// so fl(w + cj) >= fl(mincost + cj), hence "newCost < costs[j+k]" already implies
+// "costs[j+k] > mincostaddcostj".  A block with an edge below mincost (possible only through
+// rounding in the cost model) is flagged and takes the generic path, which tests literally.
+#define D3_RELAX(CS, LS, WV)                                                 \
+  {                                                                          \
+    const double old_ = (double)(CS);                                        \
+    const double nc_ = (WV) + cj;                    /* squeeze.c:278,297 */  \
+    const bool upd_ = nc_ < old_;                    /* :298 */              \
+    CS = upd_ ? (float)nc_ : CS;                                             \
+    LS = upd_ ? src1 : LS;                                                   \
+  }
+
 #define D3_NP 3u
 #define D3_SPAN 896u     // rows of four consecutive steps fit in the ring (4 * 896 + slack <= 4096)
 #define D3_EV_NONE 0u
@@ -112,6 +126,7 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
   __shared__ __align__(16) double s_t1[2][64 * 64];   // register-0 rows, row = position in the group
   __shared__ __align__(16) double s_t2[2][32 * 64];   // register-1 rows, row = position & 31
   __shared__ uint2 s_tab[D3_NP][64];
+  __shared__ u32 s_badblk[2];   // per tile buffer: bit i = block i of the step has an edge below mincost
   __shared__ float s_xc[DP_XN];
   __shared__ u16 s_xl[DP_XN];
 
@@ -132,6 +147,7 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
   const double kInf = __longlong_as_double(0x7ff0000000000000ll);
   const u32 ring_lds = (u32)(unsigned long)(__attribute__((address_space(3))) double*)s_ring;
 
+  if (tid < 2) s_badblk[tid] = 0;
   D3Walk W;
   D3Group G;
   G.roff = G.kend = G.offend = 0; G.m_short = G.m_r1 = G.m_bad = 0; G.navail = 0;
@@ -152,10 +168,16 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
       const D3Step S = d3_next(W, G, dbase, B, lane);
       const double* t1 = s_t1[(it - 1) & 1];
       const double* t2 = s_t2[(it - 1) & 1];
+      u32 badblk = 0;
+      if (S.n) {
+        badblk = (u32)__builtin_amdgcn_readfirstlane((int)s_badblk[(it - 1) & 1]);
+        if (lane == 0) s_badblk[(it - 1) & 1] = 0;   // the producers OR into it again two steps from now
+      }
       u32 base = S.base;
       u32 p0 = S.q;
-      while (p0 < S.q + S.n) {
-        if (d3_fast(S, G, p0)) {
+      u32 bi = 0;   // block index within the step
+      for (; p0 < S.q + S.n; ++bi) {
+        if (d3_fast(S, G, p0) && !((badblk >> bi) & 1)) {
           const bool two = ((u32)(G.m_r1 >> p0) & 255u) != 0;
           double w0[8], w1[8];
 #pragma unroll
@@ -170,8 +192,7 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
               const u32 p = p0 + u;
               const double cj = (double)rdlane_f32(c[0], p);
               const u32 src1 = base + p + 1;
-              const double mcl0 = __builtin_amdgcn_inverse_ballot_w64(2ull << p) ? -kInf : mincost;   // lane p + 1: the literal
-              DP_RELAX(c[0], l[0], w0[u], mcl0)
+              D3_RELAX(c[0], l[0], w0[u])
             }
           } else {
 #pragma unroll
@@ -179,17 +200,16 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
               const u32 p = p0 + u;
               const double cj = (double)rdlane_f32(c[0], p);
               const u32 src1 = base + p + 1;
-              const double mcl0 = __builtin_amdgcn_inverse_ballot_w64(2ull << p) ? -kInf : mincost;
-              DP_RELAX(c[0], l[0], w0[u], mcl0)
-              const double mcl1 = __builtin_amdgcn_inverse_ballot_w64((u64)((p + 1) >> 6)) ? -kInf : mincost;   // p = 63: lane 0
-              DP_RELAX(c[1], l[1], w1[u], mcl1)
+              D3_RELAX(c[0], l[0], w0[u])
+              D3_RELAX(c[1], l[1], w1[u])
             }
           }
           n_fast += 8;
           p0 += 8;
           continue;
         }
-        // generic path straight from the ring (ragged tails, long matches, exempt flagged positions)
+        // generic path straight from the ring (ragged tails, long matches, exempt flagged positions,
+        // blocks with an edge below mincost): the reference's tests, literally
         const u32 pend = p0 + 8 <= S.q + S.n ? p0 + 8 : S.q + S.n;
         for (u32 p = p0; p < pend; ++p) {
           const u32 ke = rdlane_u32(G.kend, p);
@@ -330,12 +350,20 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
             if (two) v1[u] = row[lane + 64];
           }
           const u32 d0 = lane - p0 - 1;
+          bool below = false;   // a match edge (k >= 3) of this block costs less than mincost
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
             const u32 km1 = d0 - u;
-            t1[(p0 + u) * 64 + lane] = km1 < t[u].y ? v0[u] : kInf;
-            if (two) t2[((p0 + u) & 31) * 64 + lane] = km1 + 64 < t[u].y ? v1[u] : kInf;
+            const bool val0 = km1 < t[u].y;
+            t1[(p0 + u) * 64 + lane] = val0 ? v0[u] : kInf;
+            below |= val0 && km1 != 0 && v0[u] < mincost;           // km1 == 0: the literal has no such test
+            if (two) {
+              const bool val1 = km1 + 64 < t[u].y;
+              t2[((p0 + u) & 31) * 64 + lane] = val1 ? v1[u] : kInf;
+              below |= val1 && km1 + 64 != 0 && v1[u] < mincost;
+            }
           }
+          if (__ballot(below) && lane == 0) atomicOr(&s_badblk[it & 1], 1u << ((p0 - S.q) >> 3));
         }
       }
     }

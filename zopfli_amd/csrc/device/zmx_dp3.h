@@ -52,8 +52,12 @@ struct D3Walk {           // wave-uniform walker state (+ the per-lane dph prefe
   u32 base = 0, q = 0;
   bool noshort = false, have_group = false;
   u32 bubbles = 2;        // the walk starts with BUBBLE, PRIME
+  // dph of the next group, requested one group ahead.  Two register sets used alternately: with
+  // one, the compiler parks the new load in a temporary and copies it over at once — a full
+  // global-load stall per group.
   u32 pf_base = 0xffffffffu;
-  uint2 pf_dh = make_uint2(0, 0);
+  u32 pf_sel = 0;
+  uint2 pf_a = make_uint2(0, 0), pf_b = make_uint2(0, 0);
 };
 
 struct D3Step {
@@ -64,10 +68,19 @@ __device__ __forceinline__ void d3_load_group(D3Walk& W, D3Group& G, const uint2
   const u32 jj = W.base + lane;
   G.navail = (B - W.base < 64u) ? B - W.base : 64u;   // W.base <= B
   const bool act = lane < G.navail;
-  uint2 dh = W.pf_dh;
-  if (W.pf_base != W.base) dh = dbase[jj < B ? jj : B - 1];
+  const uint2* nextp = dbase + (jj + 64 < B ? jj + 64 : B - 1);
+  uint2 dh;
+  if (W.pf_sel == 0) {
+    dh = W.pf_a;
+    if (W.pf_base != W.base) dh = dbase[jj < B ? jj : B - 1];
+    W.pf_b = *nextp;
+  } else {
+    dh = W.pf_b;
+    if (W.pf_base != W.base) dh = dbase[jj < B ? jj : B - 1];
+    W.pf_a = *nextp;
+  }
+  W.pf_sel ^= 1;
   W.pf_base = W.base + 64;
-  W.pf_dh = dbase[jj + 64 < B ? jj + 64 : B - 1];
   G.kend = act ? (dh.y & 0xffffu) : 0u;
   G.roff = dh.x;
   G.offend = G.roff + G.kend;
@@ -127,6 +140,8 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
   __shared__ __align__(16) double s_t2[2][32 * 64];   // register-1 rows, row = position & 31
   __shared__ uint2 s_tab[D3_NP][64];
   __shared__ u32 s_badblk[2];   // per tile buffer: bit i = block i of the step has an edge below mincost
+  __shared__ u32 s_desc[2][8];  // per tile buffer, written by wave 1: [0] q | n << 8 | event << 16 | last << 24 [1] base [2..3] m_r1 [4..5] m_bad
+  __shared__ uint2 s_tabc[2][64];   // per tile buffer: {roff, kend} of the group, for the consumer's generic path
   __shared__ float s_xc[DP_XN];
   __shared__ u16 s_xl[DP_XN];
 
@@ -163,9 +178,20 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
 
     __syncthreads();   // iteration 0: the producers' first step, nothing to consume yet
     u32 it = 1;
-    while (W.bubbles || W.base <= B) {
+    for (;;) {
       const u64 tw0 = PROF ? (u64)__builtin_readcyclecounter() : 0ull;
-      const D3Step S = d3_next(W, G, dbase, B, lane);
+      // the step as wave 1 described it (the consumer never looks at dph[] itself)
+      u32 dv[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dv[i] = s_desc[(it - 1) & 1][i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dv[i] = (u32)__builtin_amdgcn_readfirstlane((int)dv[i]);
+      D3Step S;
+      S.q = dv[0] & 255u; S.n = (dv[0] >> 8) & 255u; S.event = (dv[0] >> 16) & 255u; S.base = dv[1]; S.a_cur = 0;
+      const bool last = (dv[0] >> 24) != 0;
+      G.m_r1 = ((u64)dv[3] << 32) | dv[2];
+      G.m_bad = ((u64)dv[5] << 32) | dv[4];
+      const uint2* tabc = s_tabc[(it - 1) & 1];
       const double* t1 = s_t1[(it - 1) & 1];
       const double* t2 = s_t2[(it - 1) & 1];
       u32 badblk = 0;
@@ -230,8 +256,9 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
         // blocks with an edge below mincost): the reference's tests, literally
         const u32 pend = p0 + 8 <= S.q + S.n ? p0 + 8 : S.q + S.n;
         for (u32 p = p0; p < pend; ++p) {
-          const u32 ke = rdlane_u32(G.kend, p);
-          const u32 ro = rdlane_u32(G.roff, p);
+          const uint2 tc = tabc[p];
+          const u32 ro = (u32)__builtin_amdgcn_readfirstlane((int)tc.x);
+          const u32 ke = (u32)__builtin_amdgcn_readfirstlane((int)tc.y);
           const double cj = (double)rdlane_f32(c[0], p);
           const u32 src1 = base + p + 1;
           const u32 km1 = lane - p - 1;
@@ -296,6 +323,7 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
       if (PROF) { t_work += (u64)__builtin_readcyclecounter() - tw0; ++n_steps; }
       __syncthreads();
       ++it;
+      if (last) break;
     }
     if (lane == 0) la[0] = 0;
     if (PROF && P.prof && lane == 0) {
@@ -314,6 +342,16 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
   while (more) {
     const D3Step S = d3_next(W, G, dbase, B, lane);
     more = W.bubbles || W.base <= B;
+    if (wave == 1) {   // describe the step for the consumer
+      if (S.n) s_tabc[it & 1][lane] = make_uint2(G.roff, G.kend);
+      if (lane == 0) {
+        u32* d = s_desc[it & 1];
+        d[0] = S.q | (S.n << 8) | (S.event << 16) | ((more ? 0u : 1u) << 24);
+        d[1] = S.base;
+        d[2] = (u32)G.m_r1; d[3] = (u32)(G.m_r1 >> 32);
+        d[4] = (u32)G.m_bad; d[5] = (u32)(G.m_bad >> 32);
+      }
+    }
     if (S.event == D3_EV_PRIME) {
       // the segment that follows starts at W.base: load its group now, prime the ring from there
       if (!W.have_group && W.base <= B) { d3_load_group(W, G, dbase, B, lane); W.q = 0; }

@@ -15,6 +15,7 @@
 
 #include "zmx_kernels.h"
 #include "zmx_dp3.h"
+#include "zmx_trace.h"
 #include "zopfli_amd.h"
 
 namespace {
@@ -91,6 +92,10 @@ struct zmx_tables {
   uint2* d_dph = nullptr;         // per position: DP row offset, kend | shortcut flag (k_rowscan)
   u64* d_block_edges = nullptr;   // per block: DP edges
   u64* d_row_base = nullptr;      // per block: first slot in ctx->d_rows for its launch range
+  u32* d_seg_off = nullptr;       // per block: first trace segment (cumulative)
+  u32* d_extab = nullptr;         // per trace segment: exit table (k_trace_exits)
+  uint2* d_seginfo = nullptr;     // per trace segment: entry, symbol offset (k_trace_link)
+  std::vector<u32> seg_off;
   std::vector<u64> block_edges;
   std::vector<u32> tile_off;
   std::vector<std::pair<u32, u32>> ranges;  // blocks [first, last) squeezed together (row budget)
@@ -251,6 +256,9 @@ void zmx_tables_free(zmx_ctx* c, zmx_tables* t) {
   PoolFree(c, t->d_dph);
   PoolFree(c, t->d_block_edges);
   PoolFree(c, t->d_row_base);
+  PoolFree(c, t->d_seg_off);
+  PoolFree(c, t->d_extab);
+  PoolFree(c, t->d_seginfo);
   PoolFree(c, t->d_counters);
   PoolFree(c, t->d_flags);
   PoolFree(c, t->d_prof);
@@ -391,6 +399,13 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   t->ranges.emplace_back(first, static_cast<u32>(nb));
   t->max_range_rows = std::max(t->max_range_rows, cur);
   HIPCHK(hipMemcpyAsync(t->d_row_base, row_base.data(), nb * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+  // trace segments (zmx_trace.h)
+  t->seg_off.assign(nb + 1, 0);
+  for (size_t b = 0; b < nb; ++b) t->seg_off[b + 1] = t->seg_off[b] + (t->bsize[b] + TS_SEG - 1) / TS_SEG;
+  HIPCHK(PoolAlloc(c, &t->d_seg_off, nb + 1));
+  HIPCHK(PoolAlloc(c, &t->d_extab, static_cast<size_t>(t->seg_off[nb]) * TS_ENT));
+  HIPCHK(PoolAlloc(c, &t->d_seginfo, t->seg_off[nb]));
+  HIPCHK(hipMemcpyAsync(t->d_seg_off, t->seg_off.data(), (nb + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -474,8 +489,10 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   cp.prof = t->d_prof;
   static const bool nofetch = std::getenv("ZOPFLI_AMD_DEBUG_NOFETCH") != nullptr;
   cp.debug_nofetch = nofetch ? 1 : 0;
-  TraceParams tp;
+  TraceSegParams tp;
   tp.blocks = t->d_blocks;
+  tp.seg_off = t->d_seg_off;
+  tp.nb_total = static_cast<u32>(t->nb);
   tp.recs = t->d_recs;
   tp.pool = t->d_pool;
   tp.la = t->d_la;
@@ -485,7 +502,8 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   tp.hist_out = t->d_hist;
   tp.nsym_out = t->d_nsym;
   tp.flags = t->d_flags;
-  tp.prof = t->d_prof;
+  tp.extab = t->d_extab;
+  tp.seginfo = t->d_seginfo;
   double ksec[3] = {0, 0, 0};
   for (const auto& r : t->ranges) {
     const unsigned nblk = r.second - r.first;
@@ -507,7 +525,11 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
-    hipLaunchKernelGGL(k_trace, dim3(nblk), dim3(64), 0, c->stream, tp);
+    tp.seg0 = t->seg_off[r.first];
+    const unsigned nseg = t->seg_off[r.second] - t->seg_off[r.first];
+    if (nseg) hipLaunchKernelGGL(k_trace_exits, dim3(nseg), dim3(320), 0, c->stream, tp);
+    hipLaunchKernelGGL(k_trace_link, dim3(nblk), dim3(64), 0, c->stream, tp);
+    if (nseg) hipLaunchKernelGGL(k_trace_emit, dim3(nseg), dim3(64), 0, c->stream, tp);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[3], c->stream));
     HIPCHK(hipEventSynchronize(c->ev[3]));
@@ -533,10 +555,10 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     HIPCHK(hipMemcpy(pr.data(), t->d_prof, pr.size() * sizeof(u64), hipMemcpyDeviceToHost));
     double a[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (size_t b = 0; b < t->nb; ++b) for (int k = 0; k < 12; ++k) a[k] += static_cast<double>(pr[b * 16 + k]);
-    std::fprintf(stderr, "squeeze prof: edges %.2f ms dp %.2f ms trace %.2f ms; k_dp cycles/position stage %.1f chain %.1f (inside fast blocks %.1f, two-register blocks %.1f/position); fast %.1f%% (two-register %.1f%%) of %.0f positions; k_trace cycles/symbol walk %.1f resolve %.1f request %.1f (%.0f symbols)\n",
-                 ksec[0] * 1e3, ksec[1] * 1e3, ksec[2] * 1e3, a[0] / a[4], a[1] / a[4], a[5] / a[4], a[7] / (a[6] + 1e-9),
-                 100.0 * a[2] / (a[2] + a[3] + 1e-9), 100.0 * a[6] / (a[2] + a[3] + 1e-9), a[4],
-                 a[8] / a[11], a[9] / a[11], a[10] / a[11], a[11]);
+    std::fprintf(stderr, "squeeze prof: edges %.2f ms dp %.2f ms trace %.2f ms; chain wave busy %.1f cycles/position, "
+                 "%.0f steps, fast %.1f%% of %.0f positions\n",
+                 ksec[0] * 1e3, ksec[1] * 1e3, ksec[2] * 1e3, a[1] / a[4], a[0],
+                 100.0 * a[2] / (a[2] + a[3] + 1e-9), a[4]);
   }
   return 0;
 }

@@ -596,8 +596,9 @@ __global__ __launch_bounds__(64) void k_greedy(const BlockDesc* __restrict__ blo
 //         position is a v_readlane, edge rows stream HBM -> LDS ring by
 //         LDS-DMA one ring ahead, and 8 positions of row values are preloaded
 //         into registers so that no memory latency sits on the chain.
-//     k_trace   (every run, one wave per block)  TraceBackwards + FollowPath +
-//         histogram from length_array and the match records.
+//     zmx_dp3.h  k_dp3: the same chain with the row fetching on producer waves (default).
+//     zmx_trace.h  TraceBackwards + FollowPath + histogram, segmented (k_trace_exits /
+//         k_trace_link / k_trace_emit).
 // ----------------------------------------------------------------------------
 #define TR_CHUNK 2048u
 
@@ -1110,172 +1111,4 @@ __global__ __launch_bounds__(64) void k_dp(DpParams P) {
     u64* o = P.prof + (u64)b * 16;
     o[0] = t_stage; o[1] = t_chain; o[2] = n_fast; o[3] = n_slow; o[4] = B; o[5] = t_fast; o[6] = n_two; o[7] = t_two;
   }
-}
-
-// ------------------------------------------------------------------ k_trace
-struct TraceParams {
-  const BlockDesc* blocks;
-  u32 block0;
-  const u32* recs;
-  const u32* pool;
-  const u16* la;
-  const int* slot;         // [nb_total]
-  u32* store0;
-  u32* store1;
-  u32* hist_out;
-  u32* nsym_out;
-  u32* flags;              // [1] error bits
-  u64* prof;               // optional [nb_total][16] cycle counters (slots 8..), else null
-};
-
-__global__ __launch_bounds__(64) void k_trace(TraceParams P) {
-  __shared__ __align__(16) u16 s_la[TR_CHUNK];
-  __shared__ u32 s_sym[128];       // (start position, length) of walked symbols awaiting resolution
-  __shared__ u32 s_len[128];
-  __shared__ u32 s_hist[320];
-
-  const u32 b = P.block0 + blockIdx.x;
-  const BlockDesc bd = P.blocks[b];
-  const u32 B = (u32)(bd.inend - bd.instart);
-  const u32 lane = threadIdx.x;
-  const u32* rbase = P.recs + bd.pos_off * 8;
-  const u16* la = P.la + bd.la_off;
-  u32* sbase = (P.slot[b] ? P.store1 : P.store0) + bd.pos_off;
-
-  for (u32 i = lane; i < 320; i += 64) s_hist[i] = 0;
-  __syncthreads();
-
-  // TraceBackwards (squeeze.c:317) is a chain of dependent reads.  64 cells of length_array
-  // sit in one VGPR (lane i = cell wb + i); a step is v_readlane + s_sub and sets the bit of
-  // the visited cell in an SGPR mask — the lane of a visited cell x holds everything about
-  // the symbol that ENDS there: length la[x], start x - la[x].  After a window the marked
-  // lanes are compacted (highest cell first = stream order from the back) into an LDS
-  // queue; every 64 queued symbols the lanes resolve FollowPath (squeeze.c:338:
-  // dist = sublen[length] of the match record) in parallel, with the record
-  // loads of one batch in flight while the next windows are walked.
-  const bool prof = P.prof != nullptr;
-  u64 t_walk = 0, t_res = 0, t_req = 0, t_mark = prof ? (u64)__builtin_readcyclecounter() : 0ull;
-#define TR_LAP(ACC) if (prof) { const u64 t_ = (u64)__builtin_readcyclecounter(); ACC += t_ - t_mark; t_mark = t_; }
-  u32 head = B;
-  u32 total = 0;                  // symbols resolved or queued for resolution
-  u32 queued = 0;                 // symbols in s_sym/s_len
-  u32 lo = 0, hi = 0;             // cells [lo, hi] are staged in s_la
-  bool bad = false;
-  u32 pend_n = 0, pend_total = 0, pend_len = 0;
-  uint4 pend_ra = make_uint4(0, 0, 0, 0), pend_rb = make_uint4(0, 0, 0, 0);
-
-  for (;;) {
-    // ---- walk windows until 64 symbols are queued or the start is reached
-    while (queued < 64 && head > 0 && !bad) {
-      const u32 wb = head > 63 ? head - 63 : 0;
-      if (hi == 0 || wb < lo) {   // restage [lo, head]: four 16-byte loads per lane, issued together
-        lo = head > TR_CHUNK - 8 ? (head - (TR_CHUNK - 8)) & ~7u : 0;
-        hi = head;
-        __syncthreads();
-        uint4 v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const u32 i8 = (lane + 64u * r) * 8;
-          v[r] = make_uint4(0, 0, 0, 0);
-          if (lo + i8 <= hi) v[r] = *reinterpret_cast<const uint4*>(la + lo + i8);   // la rows are padded to 8 entries
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) reinterpret_cast<uint4*>(s_la)[lane + 64 * r] = v[r];
-        __syncthreads();
-      }
-      const u32 cell = wb + lane;
-      const u32 la_raw = cell <= head ? (u32)s_la[cell - lo] : 0u;
-      const u32 la_v = la_raw ? la_raw : 1u;        // never-reached cells hold 0: keep the walk moving,
-      u64 mask = 0;                                 // validity of the visited cells is checked below
-      int idx = (int)(head - wb);
-      const int lim = __builtin_amdgcn_readfirstlane(wb == 0 ? 1 : 0);   // cell 0 starts the block: not a symbol end
-      do {
-        const u32 len = rdlane_u32(la_v, (u32)idx);
-        mask |= 1ull << idx;
-        idx -= (int)len;
-      } while (idx >= lim);
-      if (__ballot(((mask >> lane) & 1) && (la_raw == 0 || la_raw > cell))) { bad = true; break; }   // corrupt length_array
-      head = (u32)((int)wb + idx);   // first cell below the window (or 0)
-      // compact: rank from the top of the window
-      const bool on = (mask >> lane) & 1;
-      const u32 above = (u32)__popcll(lane < 63 ? mask >> (lane + 1) : 0ull);
-      if (on) {
-        s_sym[queued + above] = cell - la_v;
-        s_len[queued + above] = la_v;
-      }
-      queued += (u32)__popcll(mask);
-      __syncthreads();
-    }
-    TR_LAP(t_walk)
-    // ---- resolve the pending batch (its records were requested one round ago)
-    if (pend_n) {
-      if (lane < pend_n) {
-        u32 e;
-        const u32 d1 = pend_ra.y;
-        if (pend_len >= 3) {
-          const u32 ncpf = d1 >> 24;
-          u32 dist = 0;
-          if (ncpf != 0xffu) {
-            const u32 w[6] = {pend_ra.z, pend_ra.w, pend_rb.x, pend_rb.y, pend_rb.z, pend_rb.w};
-#pragma unroll
-            for (int k = 7; k >= 0; --k) {
-              const u32 bit = 24u * k;
-              const u32 lo32 = w[bit >> 5] >> (bit & 31);
-              const u32 v = (bit & 31) > 8 ? (lo32 | (w[(bit >> 5) + 1 > 5 ? 5 : (bit >> 5) + 1] << (32 - (bit & 31)))) : lo32;
-              if ((u32)k < ncpf && (v & 255u) + 3u >= pend_len) dist = (v >> 8) & 0xffffu;
-            }
-          } else {
-            const u32 off = pend_ra.z, cnt = pend_ra.w & 0xffffu;
-            u32 plo = 0, phi = cnt;   // first entry with len >= pend_len
-            while (plo < phi) {
-              const u32 mid = (plo + phi) >> 1;
-              if ((P.pool[off + mid] & 0xffffu) < pend_len) plo = mid + 1; else phi = mid;
-            }
-            if (plo < cnt) dist = P.pool[off + plo] >> 16;
-          }
-          e = pend_len | (dist << 16);
-          if (dist == 0) atomicOr(&P.flags[1], 4u);
-        } else {
-          e = (d1 >> 16) & 255u;
-        }
-        sbase[B - 1 - (pend_total + lane)] = e;
-        hist_add_symbol(s_hist, e & 0xffffu, e >> 16);
-      }
-      pend_n = 0;
-    }
-    TR_LAP(t_res)
-    if (queued == 0) break;
-    // ---- request the records of up to 64 queued symbols, keep the rest queued
-    {
-      const u32 n = queued < 64 ? queued : 64;
-      pend_n = n;
-      pend_total = total;
-      u32 pos = 0;
-      if (lane < n) {
-        pos = s_sym[lane];
-        pend_len = s_len[lane];
-        const u32* rec = rbase + (u64)pos * 8;
-        pend_ra = *reinterpret_cast<const uint4*>(rec);
-        pend_rb = *reinterpret_cast<const uint4*>(rec + 4);
-      }
-      total += n;
-      const u32 rest = queued - n;
-      __syncthreads();
-      u32 mv_s = 0, mv_l = 0;
-      if (lane < rest) { mv_s = s_sym[n + lane]; mv_l = s_len[n + lane]; }
-      __syncthreads();
-      if (lane < rest) { s_sym[lane] = mv_s; s_len[lane] = mv_l; }
-      queued = rest;
-      __syncthreads();
-    }
-    TR_LAP(t_req)
-  }
-  if (prof && lane == 0) {
-    u64* o = P.prof + (u64)b * 16 + 8;
-    o[0] = t_walk; o[1] = t_res; o[2] = t_req; o[3] = total;
-  }
-  if (bad && lane == 0) atomicOr(&P.flags[1], 2u);
-  __syncthreads();
-  for (u32 i = lane; i < 320; i += 64) P.hist_out[(u64)b * 320 + i] = s_hist[i];
-  if (lane == 0) P.nsym_out[b] = total;
 }

@@ -16,6 +16,7 @@
 #include "zmx_kernels.h"
 #include "zmx_dp3.h"
 #include "zmx_trace.h"
+#include "zmx_greedy.h"
 #include "zopfli_amd.h"
 
 namespace {
@@ -403,7 +404,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   t->seg_off.assign(nb + 1, 0);
   for (size_t b = 0; b < nb; ++b) t->seg_off[b + 1] = t->seg_off[b] + (t->bsize[b] + TS_SEG - 1) / TS_SEG;
   HIPCHK(PoolAlloc(c, &t->d_seg_off, nb + 1));
-  HIPCHK(PoolAlloc(c, &t->d_extab, static_cast<size_t>(t->seg_off[nb]) * TS_ENT));
+  HIPCHK(PoolAlloc(c, &t->d_extab, static_cast<size_t>(t->seg_off[nb]) * GS_STATES));   // shared by the trace (TS_ENT per segment)
   HIPCHK(PoolAlloc(c, &t->d_seginfo, t->seg_off[nb]));
   HIPCHK(hipMemcpyAsync(t->d_seg_off, t->seg_off.data(), (nb + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -438,8 +439,20 @@ int zmx_lz77_greedy(zmx_ctx* c, zmx_tables* t, int slot, uint32_t* nsym, uint32_
   if (t->nb == 0) return 0;
   if (slot != 0 && slot != 1) return FailMsg("zmx_lz77_greedy: slot must be 0 or 1");
   HIPCHK(hipSetDevice(c->device));
-  hipLaunchKernelGGL(k_greedy, dim3(static_cast<unsigned>(t->nb)), dim3(64), 0, c->stream, t->d_blocks, t->d_recs,
-                     t->d_store[slot], t->d_hist, t->d_nsym);
+  GreedySegParams gp;
+  gp.blocks = t->d_blocks;
+  gp.seg_off = t->d_seg_off;
+  gp.nb = static_cast<u32>(t->nb);
+  gp.recs = t->d_recs;
+  gp.store = t->d_store[slot];
+  gp.hist_out = t->d_hist;
+  gp.nsym_out = t->d_nsym;
+  gp.extab = t->d_extab;
+  gp.seginfo = t->d_seginfo;
+  const unsigned nseg = t->seg_off[t->nb];
+  if (nseg) hipLaunchKernelGGL(k_greedy_exits, dim3(nseg), dim3(576), 0, c->stream, gp);
+  hipLaunchKernelGGL(k_greedy_link, dim3(static_cast<unsigned>(t->nb)), dim3(64), 0, c->stream, gp);
+  if (nseg) hipLaunchKernelGGL(k_greedy_emit, dim3(nseg), dim3(64), 0, c->stream, gp);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(nsym, t->d_nsym, t->nb * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(hist, t->d_hist, t->nb * ZMX_HIST * sizeof(u32), hipMemcpyDeviceToHost, c->stream));

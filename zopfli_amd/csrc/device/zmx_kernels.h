@@ -467,113 +467,13 @@ __device__ __forceinline__ void hist_add_symbol(u32* hist, u32 litlen, u32 dist)
 }
 
 // ----------------------------------------------------------------------------
-// K3  ZopfliLZ77Greedy (lz77.c:544-630) on the match table: one wave per block.
-//     The lazy-matching automaton is a chain of dependent decisions over the
-//     visited positions.  64 record headers sit in VGPRs (lane i = position
-//     wb + i, the next window is prefetched), a step is one v_readlane plus
-//     scalar ALU; what a step emits is a bit in one of two SGPR masks ("this
-//     lane's literal" / "this lane's match"), and the marked lanes write their
-//     symbols and histogram bins once per window.
+// K3  ZopfliLZ77Greedy (lz77.c:544-630) on the match table: zmx_greedy.h
+//     (segmented: k_greedy_exits / k_greedy_link / k_greedy_emit).  Here only the
+//     window loader they share.
 // ----------------------------------------------------------------------------
 __device__ __forceinline__ uint2 greedy_window(const u32* rbase, u32 wb, u32 lane, u32 B) {
   const u32 q = wb + lane < B ? wb + lane : (B ? B - 1 : 0);
   return *reinterpret_cast<const uint2*>(rbase + (u64)q * 8);
-}
-
-__global__ __launch_bounds__(64) void k_greedy(const BlockDesc* __restrict__ blocks, const u32* __restrict__ recs,
-                                               u32* __restrict__ store, u32* __restrict__ hist_out,
-                                               u32* __restrict__ nsym_out) {
-  __shared__ u32 s_hist[320];
-
-  const u32 b = blockIdx.x;
-  const BlockDesc bd = blocks[b];
-  const u32 B = (u32)(bd.inend - bd.instart);
-  const u32 lane = threadIdx.x;
-  const u32* rbase = recs + bd.pos_off * 8;
-  u32* sbase = store + bd.pos_off;
-
-  for (u32 i = lane; i < 320; i += 64) s_hist[i] = 0;
-  __syncthreads();
-
-  u32 total = 0;
-  if (B > 0) {
-    u32 i = 0;                                   // next position to visit
-    bool avail = false;                          // a match is held at position i - 1 (lz77.c:558-562)
-    u32 prev_h = 0, prev_lit = 0;                // its length | dist << 16, and the byte at i - 1
-    int prevscore = 0;
-    u32 wb = 0;
-    uint2 cur = greedy_window(rbase, 0, lane, B);
-    uint2 nxt = greedy_window(rbase, 64, lane, B);
-    for (;;) {
-      const u32 nwin = B - wb < 64u ? B - wb : 64u;
-      const u32 d0_v = cur.x;                    // length | dist << 16 of the position of this lane
-      const u32 lit_v = (cur.y >> 16) & 255u;
-      u64 m_lit = 0, m_match = 0;
-      u32 carry = 0, carry_sym = 0;              // a symbol for position wb - 1 (held across the window edge)
-      int idx = (int)(i - wb);
-      int last = idx;
-      while (idx < (int)nwin) {
-        const u32 h = rdlane_u32(d0_v, (u32)idx);
-        const u32 leng = h & 0xffffu, dist = h >> 16;
-        const int score = dist > 1024 ? (int)leng - 1 : (int)leng;          // lz77.c:265-271
-        last = idx;
-        if (avail) {                                                          // lz77.c:581-607
-          avail = false;
-          if (score > prevscore + 1) {
-            if (idx > 0) m_lit |= 1ull << (idx - 1); else { carry = 1; carry_sym = prev_lit; }
-            if (score >= 3 && leng < ZMX_MAX_MATCH) {
-              avail = true; prev_h = h; prevscore = score;
-              idx += 1;
-              continue;
-            }
-          } else {
-            if (idx > 0) m_match |= 1ull << (idx - 1); else { carry = 1; carry_sym = prev_h; }
-            idx += (int)(prev_h & 0xffffu) - 1;                               // (i - 1) + prev_length
-            continue;
-          }
-        } else if (score >= 3 && leng < ZMX_MAX_MATCH) {                      // lz77.c:608-613
-          avail = true; prev_h = h; prevscore = score;
-          idx += 1;
-          continue;
-        }
-        if (score >= 3) {                                                     // lz77.c:618-629
-          m_match |= 1ull << idx;
-          idx += (int)leng;
-        } else {
-          m_lit |= 1ull << idx;
-          idx += 1;
-        }
-      }
-      if (avail) prev_lit = rdlane_u32(lit_v, (u32)last);   // the held match is at the last visited position
-      i = wb + (u32)idx;
-      // ---- emit this window's symbols in position order
-      const u64 m_any = m_lit | m_match;
-      if (carry && lane == 0) {
-        sbase[total] = carry_sym;
-        hist_add_symbol(s_hist, carry_sym & 0xffffu, carry_sym >> 16);
-      }
-      if ((m_any >> lane) & 1) {
-        const u32 below = (u32)__popcll(m_any & ((1ull << lane) - 1));
-        const u32 e = ((m_match >> lane) & 1) ? d0_v : lit_v;
-        sbase[total + carry + below] = e;
-        hist_add_symbol(s_hist, e & 0xffffu, e >> 16);
-      }
-      total += carry + (u32)__popcll(m_any);
-      if (i >= B) break;
-      // ---- next window: the prefetched one if the walk ended inside it
-      if (i < wb + 128) {
-        wb += 64;
-        cur = nxt;
-      } else {
-        wb = i;
-        cur = greedy_window(rbase, wb, lane, B);
-      }
-      nxt = greedy_window(rbase, wb + 64, lane, B);
-    }
-  }
-  __syncthreads();
-  for (u32 i = lane; i < 320; i += 64) hist_out[(u64)b * 320 + i] = s_hist[i];
-  if (lane == 0) nsym_out[b] = total;
 }
 
 // ----------------------------------------------------------------------------

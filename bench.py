@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 MB = 1000000
 WINDOW = 32768
-PMC_PROFILE = "r01_v3_bench100MB_pmc.json"
+PMC_PROFILE = "r01_v4_bench100MB_pmc.json"
 
 
 def cpu_baseline(sample, options):
@@ -171,7 +171,7 @@ def main():
             d = zlib.decompressobj(31)
             n = len(d.decompress(out)) + len(d.flush())
             roundtrip = (n == total)
-        # ---- roofline of the dominant kernel (k_dp, the serial DP chain): algorithmic bytes = 31 B per
+        # ---- roofline of the dominant kernel (k_dp3, the serial DP chain): algorithmic bytes = 31 B per
         #      position per launch (28 B match record + 1 B literal + 2 B length_array)
         launches = timing_acc.get("squeeze_launches", 0.0)
         ksec = timing_acc.get("dp_kernel", 0.0)
@@ -187,8 +187,8 @@ def main():
             if (os.path.exists(pmc) and size == 100 * MB and args.numiterations == 15
                     and args.blocksplitting == 0 and world == 1):
                 with open(pmc) as f:
-                    traffic = round(json.load(f).get("k_dp", {}).get("hbm_bytes", 0) / 1e9, 3) or None
-            roofline = {"bound": "hbm", "kernel": "k_dp", "achieved": round(achieved, 3), "peak": 8000.0,
+                    traffic = round(json.load(f).get("k_dp3", {}).get("hbm_bytes", 0) / 1e9, 3) or None
+            roofline = {"bound": "hbm", "kernel": "k_dp3", "achieved": round(achieved, 3), "peak": 8000.0,
                         "unit": "GB/s", "frac": round(achieved / 8000.0, 6), "traffic": traffic,
                         "traffic_unit": "GB per launch (rocprofv3 PMC, profiles/" + PMC_PROFILE + ")",
                         "algorithmic_gb_per_launch": round(per_launch_bytes / 1e9, 3),

@@ -154,13 +154,13 @@ int zmx_chunks_merge(const unsigned char* const* blobs, const size_t* blobsizes,
 
 /* Timing breakdown of the last Zopfli* / zmx_deflate_range call on this
  * thread: seconds spent in [0] match tables [1] greedy [2] squeeze runs
- * [3] host cost model [4] block split [5] encode [6] k_dp kernel time
+ * [3] host cost model [4] block split [5] encode [6] DP-chain kernel (k_dp3) time
  * (HIP events on the launch stream) [7] squeeze runs launched.  For bench.py's
  * roofline object. */
 int zmx_last_timing(double* out8);
 
 /* Kernel-only seconds (HIP events) of the squeeze runs since the last Zopfli* /
- * zmx_deflate_range call started: [0] k_edges [1] k_dp [2] k_trace
+ * zmx_deflate_range call started: [0] k_edges [1] k_dp3 [2] k_trace_* (exits + link + emit)
  * [3] squeeze runs launched. */
 int zmx_last_kernel_timing(double* out4);
 

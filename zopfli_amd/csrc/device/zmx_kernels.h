@@ -136,21 +136,24 @@ __global__ __launch_bounds__(256) void k_same(const u8* __restrict__ in, const B
 }
 
 // ----------------------------------------------------------------------------
-// K1b  prev links: sequential head-table replay in LDS, one wave per
-//      (block, 32768-position chunk, chain).  Positions older than 32767 are
-//      unreachable (hash.c:110-114 + window aliasing), so every chunk warms up
-//      from 32768 positions before its first emitted position.
+// K1b  prev links: the reference's head-table replay (hash.c:110-114, 131-135), one wave per
+//      (block, 32768-position chunk, chain), 64 positions per step.  All lanes read
+//      head[key] (the state before the step); positions of the same step that share a
+//      key are found with 15 ballots — one per key bit, lane mask = AND of "lanes whose
+//      bit equals mine" — so a lane's previous occurrence is the nearest lower lane of
+//      its key group, else the old head; the last lane of each group writes the head.
+//      Positions older than 32767 are unreachable (hash.c:110-114 + window aliasing),
+//      so every chunk warms up from 32768 positions before its first emitted position.
 // ----------------------------------------------------------------------------
 #define CH_EMIT 32768u
 #define CH_TILE 1024u
-#define CH_LDS_BYTES (65536 + 2 * CH_TILE * 2)
+#define CH_LDS_BYTES (65536 + CH_TILE * 2)
 
 __global__ __launch_bounds__(64) void k_chain(const u8* __restrict__ in, const BlockDesc* __restrict__ blocks,
                                               const u16* __restrict__ same16, ushort4* __restrict__ links) {
   extern __shared__ __align__(16) u8 dyn_lds[];
-  u16* head = reinterpret_cast<u16*>(dyn_lds);
+  u16* head = reinterpret_cast<u16*>(dyn_lds);   // last position (relative to w0) of every key, 0xffff = none
   u16* keys = head + 32768;
-  u16* outs = keys + CH_TILE;
 
   const BlockDesc bd = blocks[blockIdx.y];
   const u32 chain = blockIdx.z;
@@ -160,6 +163,8 @@ __global__ __launch_bounds__(64) void k_chain(const u8* __restrict__ in, const B
   const u64 e1 = (e0 + CH_EMIT < L) ? e0 + CH_EMIT : L;
   const u64 w0 = e0 >= ZMX_WINDOW ? e0 - ZMX_WINDOW : 0;
   const u32 lane = threadIdx.x;
+  const u64 lt_mask = (1ull << lane) - 1;          // lanes below me
+  const u64 gt_mask = ~((2ull << lane) - 1);       // lanes above me (lane 63: 2 << 63 = 0, mask = 0)
 
   for (u32 i = lane; i < 16384; i += 64) reinterpret_cast<u32*>(head)[i] = 0xffffffffu;
   __syncthreads();
@@ -180,43 +185,35 @@ __global__ __launch_bounds__(64) void k_chain(const u8* __restrict__ in, const B
       keys[i] = (u16)v;
     }
     __syncthreads();
-    if (lane == 0) {
-      const u32 cur0 = (u32)(t0 - w0);
-      u32 i = 0;
-      for (; i + 8 <= tn; i += 8) {
-        u32 kk[8], old[8];
+    const u32 cur0 = (u32)(t0 - w0);
+    for (u32 i0 = 0; i0 < tn; i0 += 64) {
+      const u32 i = i0 + lane;
+      const bool act = i < tn;
+      const u32 key = act ? (u32)keys[i] : 0u;
+      const u32 old = act ? (u32)head[key] : (u32)ZMX_NONE16;
+      u64 grp = __ballot(act);                       // lanes of this step with my key
 #pragma unroll
-        for (int u = 0; u < 8; ++u) kk[u] = keys[i + u];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          old[u] = head[kk[u]];
-          head[kk[u]] = (u16)(cur0 + i + u);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          u32 d = old[u] == ZMX_NONE16 ? 0u : (cur0 + i + u) - old[u];
-          if (d > 32767u) d = 0;
-          outs[i + u] = (u16)d;
-        }
+      for (int bit = 0; bit < 15; ++bit) {
+        const bool mine = (key >> bit) & 1;
+        const u64 bm = __ballot(mine);
+        grp &= mine ? bm : ~bm;
       }
-      for (; i < tn; ++i) {
-        const u32 key = keys[i];
-        const u32 old = head[key];
-        head[key] = (u16)(cur0 + i);
-        u32 d = old == ZMX_NONE16 ? 0u : (cur0 + i) - old;
-        if (d > 32767u) d = 0;
-        outs[i] = (u16)d;
-      }
-    }
-    __syncthreads();
-    for (u32 i = lane; i < tn; i += 64) {
+      const u64 lower = grp & lt_mask;
+      const u32 r = cur0 + i;
+      u32 d;
+      if (lower) d = lane - (63u - (u32)__clzll((long long)lower));   // nearest lower lane of the group
+      else d = old == ZMX_NONE16 ? 0u : r - old;
+      if (d > 32767u) d = 0;
+      wave_lds_sync();                               // every lane has read the old heads
+      if (act && (grp & gt_mask) == 0) head[key] = (u16)r;   // the last of each group
+      wave_lds_sync();
       const u64 k = t0 + i;
-      if (k >= e0) {
+      if (act && k >= e0) {
         if (chain == 0) {
-          lk[k].x = outs[i];
+          lk[k].x = (u16)d;
           lk[k].z = same[k];
         } else {
-          lk[k].y = outs[i];
+          lk[k].y = (u16)d;
         }
       }
     }

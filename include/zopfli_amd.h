@@ -164,6 +164,10 @@ int zmx_last_timing(double* out8);
  * [3] squeeze runs launched. */
 int zmx_last_kernel_timing(double* out4);
 
+/* Host tail of the last call on this thread, seconds: [0] best LZ77 stores device -> host
+ * [1] chunk serialisation (zmx_deflate_range). */
+int zmx_last_host_timing(double* out2);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,7 @@ def bind(lib):
     lib.zmx_chunks_merge.argtypes = [P(ctypes.c_char_p), P(sz), sz, P(ctypes.c_ubyte), P(_u8p), P(sz)]
     lib.zmx_last_timing.argtypes = [P(ctypes.c_double)]
     lib.zmx_last_kernel_timing.argtypes = [P(ctypes.c_double)]
+    lib.zmx_last_host_timing.argtypes = [P(ctypes.c_double)]
     return lib
 
 
@@ -126,6 +127,9 @@ def last_timing(lib=None):
     k = (ctypes.c_double * 4)()
     lib.zmx_last_kernel_timing(k)
     d["edges_kernel"], d["trace_kernel"] = k[0], k[2]
+    h = (ctypes.c_double * 2)()
+    lib.zmx_last_host_timing(h)
+    d["download"], d["serialize"] = h[0], h[1]
     return d
 
 

@@ -2,6 +2,7 @@
 // (zopfli.h:67,86; deflate.h:58,67; gzip_container.h:42; zlib_container.h:42),
 // plus the resident-input stream entry points used by bench.py and by the
 // multi-GPU gather.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -272,11 +273,13 @@ int zmx_deflate_range(zmx_ctx* ctx, const ZopfliOptions* options, size_t instart
   std::vector<zamd::Chunk> chunks;
   const int rc = RunParts(ctx, *options, 2, parts, &chunks);
   if (rc) return rc;
+  const auto ts0 = std::chrono::steady_clock::now();
   const std::vector<uint8_t> v = zamd::SerializeChunks(chunks, zmx_internal_input_host(ctx));
   *blob = static_cast<unsigned char*>(std::malloc(v.size() ? v.size() : 1));
   if (!*blob) return -1;
   std::memcpy(*blob, v.data(), v.size());
   *blobsize = v.size();
+  zamd::ThreadTiming().serialize += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
   return 0;
 }
 
@@ -306,6 +309,12 @@ int zmx_last_timing(double* out8) {
 
 int zmx_last_kernel_timing(double* out4) {
   zmx_internal_kernel_stats(out4, &out4[3], 0);
+  return 0;
+}
+
+int zmx_last_host_timing(double* out2) {
+  out2[0] = zamd::ThreadTiming().download;
+  out2[1] = zamd::ThreadTiming().serialize;
   return 0;
 }
 

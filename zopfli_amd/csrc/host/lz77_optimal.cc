@@ -221,9 +221,11 @@ int Lz77OptimalBatch(zmx_ctx* ctx, const ZopfliOptions& options, const std::vect
     ThreadTiming().cost_model += (tb - ta) + (td - tc);
   }
 
+  const double tdl = Now();
   for (size_t b = 0; b < nb && !rc; ++b) {
     if (it[b].best_slot >= 0) rc = Download(ctx, t, b, it[b].best_slot, it[b].best_nsym, &(*out)[b]);
   }
+  ThreadTiming().download += Now() - tdl;
   zmx_tables_free(ctx, t);
   return rc;
 }

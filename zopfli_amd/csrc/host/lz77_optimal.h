@@ -20,6 +20,7 @@ struct SymbolRun {
 
 struct Timing {
   double tables = 0, greedy = 0, squeeze = 0, cost_model = 0, split = 0, encode = 0;
+  double download = 0, serialize = 0;   // best stores device -> host; chunks -> blob
 };
 Timing& ThreadTiming();
 

@@ -203,6 +203,24 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
       u32 p0 = S.q;
       u32 bi = 0;   // block index within the step
       for (; p0 < S.q + S.n; ++bi) {
+        // four single-register blocks in one go (the usual start of a group)
+        if (p0 + 32 <= S.q + S.n && ((u32)(G.m_bad >> p0)) == 0 && ((badblk >> bi) & 15) == 0 &&
+            ((u32)(G.m_r1 >> p0)) == 0) {
+          double w0[32];
+#pragma unroll
+          for (int u = 0; u < 32; ++u) w0[u] = t1[(p0 + u) * 64 + lane];
+#pragma unroll
+          for (int u = 0; u < 32; ++u) {
+            const u32 p = p0 + u;
+            const double cj = (double)rdlane_f32(c[0], p);
+            const u32 src1 = base + p + 1;
+            D3_RELAX(c[0], l[0], w0[u])
+          }
+          n_fast += 32;
+          p0 += 32;
+          bi += 3;
+          continue;
+        }
         // two single-register blocks in one go: 16 rows in flight, half the dispatch
         if (d3_fast(S, G, p0) && d3_fast(S, G, p0 + 8) && ((badblk >> bi) & 3) == 0 &&
             ((u32)(G.m_r1 >> p0) & 0xffffu) == 0) {

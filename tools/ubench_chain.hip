@@ -179,6 +179,78 @@ __global__ void k_readlane_tp(u32* out, u64* cyc) {
   out[threadIdx.x] = acc; if (threadIdx.x == 0) cyc[0] = t1 - t0;
 }
 
+// cvt round trip: f64 -> f32 -> f64 dependent
+__global__ void k_cvt_rt(double* out, u64* cyc, double x) {
+  double a = out[threadIdx.x];
+  u64 t0 = __builtin_readcyclecounter();
+#pragma unroll 16
+  for (int i = 0; i < N; ++i) a = (double)(float)a;
+  u64 t1 = __builtin_readcyclecounter();
+  out[threadIdx.x] = a + x; if (threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+// k_dp3's fast path: one position per step (prune-free relax), rows in registers
+__global__ void k_step_d3(float* out, u64* cyc, const double* w) {
+  float c = out[threadIdx.x];
+  u32 l = 0;
+  double w0[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) w0[u] = w[(threadIdx.x + u) & 63] + u;
+  u64 t0 = __builtin_readcyclecounter();
+  for (int i = 0; i < N / 16; ++i) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const u32 p = (i * 16 + u) & 63;
+      const double cj = (double)rdlane_f32(c, p);
+      const double old_ = (double)c, nc_ = w0[u] + cj;
+      const bool upd = nc_ < old_;
+      c = upd ? (float)nc_ : c;
+      l = upd ? (u32)(i * 16 + u) : l;
+    }
+  }
+  u64 t1 = __builtin_readcyclecounter();
+  out[threadIdx.x] = c + (float)l; if (threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+// two positions per step: c[p] and the not-yet-final c[p+1] are read together; the literal edge
+// p -> p+1 is evaluated on wave-uniform VGPR values (no second SGPR round trip)
+__global__ void k_step_pair(float* out, u64* cyc, const double* w) {
+  __shared__ double s_lit[64];
+  s_lit[threadIdx.x] = w[threadIdx.x];
+  __syncthreads();
+  float c = out[threadIdx.x];
+  u32 l = 0;
+  double w0[16], wl[8];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) w0[u] = w[(threadIdx.x + u) & 63] + u;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) wl[u] = s_lit[u * 2];   // uniform address: the value in every lane
+  u64 t0 = __builtin_readcyclecounter();
+  for (int i = 0; i < N / 16; ++i) {
+#pragma unroll
+    for (int u = 0; u < 16; u += 2) {
+      const u32 p = (i * 16 + u) & 63;
+      const float sa = rdlane_f32(c, p), sb = rdlane_f32(c, (p + 1) & 63);
+      const double cja = (double)sa;
+      const double t = wl[u >> 1] + cja;
+      const float cb = t < (double)sb ? (float)t : sb;      // c[p+1], final
+      const double cjb = (double)cb;
+      {
+        const double old_ = (double)c, nc_ = w0[u] + cja;
+        const bool upd = nc_ < old_;
+        c = upd ? (float)nc_ : c;
+        l = upd ? (u32)(i * 16 + u) : l;
+      }
+      {
+        const double old_ = (double)c, nc_ = w0[u + 1] + cjb;
+        const bool upd = nc_ < old_;
+        c = upd ? (float)nc_ : c;
+        l = upd ? (u32)(i * 16 + u + 1) : l;
+      }
+    }
+  }
+  u64 t1 = __builtin_readcyclecounter();
+  out[threadIdx.x] = c + (float)l; if (threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+
 int main() {
   double* d; float* f; u32* u; u64* cyc; double* w;
   hipMalloc(&d, 64 * 8); hipMalloc(&f, 64 * 4); hipMalloc(&u, 64 * 4); hipMalloc(&cyc, 8); hipMalloc(&w, 64 * 8);
@@ -202,6 +274,9 @@ int main() {
   RUN(k_cmp_sel, d, cyc, 1e300, 0.5)
   RUN(k_step_v1, f, cyc, w, 2.0)
   RUN(k_step_v2, f, cyc, w, 2.0)
+  RUN(k_cvt_rt, d, cyc, 1.5)
+  RUN(k_step_d3, f, cyc, w)
+  RUN(k_step_pair, f, cyc, w)
   RUN(k_lit_chain, d, cyc, w, 2.0)
   RUN(k_lds_chase, u, cyc)
   RUN(k_int_tp, u, cyc, 5u)

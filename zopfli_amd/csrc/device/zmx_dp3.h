@@ -175,6 +175,8 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
     for (int s = 0; s < 6; ++s) { c[s] = 1e30f; l[s] = 0; }
     if (lane == 0) c[0] = 0.0f;
     u64 t_work = 0, n_fast = 0, n_slow = 0, n_steps = 0;
+    u64 tp[5] = {0, 0, 0, 0, 0}, np[5] = {0, 0, 0, 0, 0};   // PROF: cycles and positions per path
+#define D3_TICK() (PROF ? (u64)__builtin_readcyclecounter() : 0ull)
 
     __syncthreads();   // iteration 0: the producers' first step, nothing to consume yet
     u32 it = 1;
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
       u32 p0 = S.q;
       u32 bi = 0;   // block index within the step
       for (; p0 < S.q + S.n; ++bi) {
+        const u64 tk = D3_TICK();
         // four single-register blocks in one go (the usual start of a group)
         if (p0 + 32 <= S.q + S.n && ((u32)(G.m_bad >> p0)) == 0 && ((badblk >> bi) & 15) == 0 &&
             ((u32)(G.m_r1 >> p0)) == 0) {
@@ -219,6 +222,7 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
           n_fast += 32;
           p0 += 32;
           bi += 3;
+          if (PROF) { tp[0] += D3_TICK() - tk; np[0] += 32; }
           continue;
         }
         // two single-register blocks in one go: 16 rows in flight, half the dispatch
@@ -237,6 +241,7 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
           n_fast += 16;
           p0 += 16;
           ++bi;
+          if (PROF) { tp[1] += D3_TICK() - tk; np[1] += 16; }
           continue;
         }
         if (d3_fast(S, G, p0) && !((badblk >> bi) & 1)) {
@@ -268,6 +273,7 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
           }
           n_fast += 8;
           p0 += 8;
+          if (PROF) { tp[two ? 3 : 2] += D3_TICK() - tk; np[two ? 3 : 2] += 8; }
           continue;
         }
         // generic path straight from the ring (ragged tails, long matches, exempt flagged positions,
@@ -294,6 +300,7 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
           }
         }
         n_slow += pend - p0;
+        if (PROF) { tp[4] += D3_TICK() - tk; np[4] += pend - p0; }
         p0 = pend;
       }
       if (S.event == D3_EV_GROUP_END) {
@@ -346,8 +353,10 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
     if (lane == 0) la[0] = 0;
     if (PROF && P.prof && lane == 0) {
       u64* o = P.prof + (u64)b * 16;
-      o[0] = n_steps; o[1] = t_work; o[2] = n_fast; o[3] = n_slow; o[4] = B; o[5] = t_work; o[6] = 0; o[7] = 0;
+      o[0] = n_steps; o[1] = t_work; o[2] = n_fast; o[3] = n_slow; o[4] = B;
+      for (int i = 0; i < 5; ++i) { o[5 + 2 * i] = tp[i]; o[6 + 2 * i] = np[i]; }
     }
+#undef D3_TICK
     return;
   }
 

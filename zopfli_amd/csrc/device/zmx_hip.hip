@@ -15,6 +15,7 @@
 
 #include "zmx_kernels.h"
 #include "zmx_dp3.h"
+#include "zmx_sq.h"
 #include "zmx_trace.h"
 #include "zmx_greedy.h"
 #include "zopfli_amd.h"
@@ -471,7 +472,11 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   HIPCHK(hipMemcpyAsync(t->d_cost, cost, t->nb * ZMX_HIST * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(t->d_mincost, mincost, t->nb * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(t->d_slot, slot, t->nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  if (t->max_range_rows > c->rows_cap) {
+  // ZOPFLI_AMD_DP selects an A/B variant of the chain kernel: 1 = k_dp (one wave), 4 = k_sq (fused
+  // edge costs, slower: DESIGN.md section 7); anything else = k_dp3, the product path.
+  static const int dp_mode = [] { const char* e = std::getenv("ZOPFLI_AMD_DP"); return e ? std::atoi(e) : 0; }();
+  const bool need_rows = dp_mode != 4;
+  if (need_rows && t->max_range_rows > c->rows_cap) {
     if (c->d_rows) HIPCHK(hipFree(c->d_rows));
     c->d_rows = nullptr;
     c->rows_cap = 0;
@@ -500,6 +505,8 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   cp.block_edges = t->d_block_edges;
   cp.la = t->d_la;
   cp.prof = t->d_prof;
+  cp.recs = t->d_recs;
+  cp.pool = t->d_pool;
   static const bool nofetch = std::getenv("ZOPFLI_AMD_DEBUG_NOFETCH") != nullptr;
   cp.debug_nofetch = nofetch ? 1 : 0;
   TraceSegParams tp;
@@ -525,14 +532,16 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     cp.block0 = r.first;
     tp.block0 = r.first;
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    if (tiles) hipLaunchKernelGGL(k_edges, dim3(tiles), dim3(256), 0, c->stream, ep);
+    if (tiles && need_rows) hipLaunchKernelGGL(k_edges, dim3(tiles), dim3(256), 0, c->stream, ep);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
-    static const bool one_wave = [] { const char* e = std::getenv("ZOPFLI_AMD_DP"); return e && e[0] == '1'; }();
-    if (one_wave) {   // the single-wave chain (A/B reference)
-      if (cp.prof) hipLaunchKernelGGL(k_dp<true>, dim3(nblk), dim3(64), 0, c->stream, cp);   // ZOPFLI_AMD_PROF
+    if (dp_mode == 1) {          // single-wave chain over k_edges' rows (A/B reference)
+      if (cp.prof) hipLaunchKernelGGL(k_dp<true>, dim3(nblk), dim3(64), 0, c->stream, cp);
       else hipLaunchKernelGGL(k_dp<false>, dim3(nblk), dim3(64), 0, c->stream, cp);
-    } else {
+    } else if (dp_mode == 4) {   // experiment: edge costs computed by the producer waves (no k_edges, no rows[])
+      if (cp.prof) hipLaunchKernelGGL(k_sq<true>, dim3(nblk), dim3(64 * (SQ_NP + 1)), 0, c->stream, cp);
+      else hipLaunchKernelGGL(k_sq<false>, dim3(nblk), dim3(64 * (SQ_NP + 1)), 0, c->stream, cp);
+    } else {                     // the product path: producer waves stage k_edges' rows for the chain wave
       if (cp.prof) hipLaunchKernelGGL(k_dp3<true>, dim3(nblk), dim3(64 * (D3_NP + 1)), 0, c->stream, cp);
       else hipLaunchKernelGGL(k_dp3<false>, dim3(nblk), dim3(64 * (D3_NP + 1)), 0, c->stream, cp);
     }
@@ -566,12 +575,20 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   if (t->d_prof) {
     std::vector<u64> pr(t->nb * 16);
     HIPCHK(hipMemcpy(pr.data(), t->d_prof, pr.size() * sizeof(u64), hipMemcpyDeviceToHost));
-    double a[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (size_t b = 0; b < t->nb; ++b) for (int k = 0; k < 12; ++k) a[k] += static_cast<double>(pr[b * 16 + k]);
+    double a[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t b = 0; b < t->nb; ++b) for (int k = 0; k < 16; ++k) a[k] += static_cast<double>(pr[b * 16 + k]);
     std::fprintf(stderr, "squeeze prof: edges %.2f ms dp %.2f ms trace %.2f ms; chain wave busy %.1f cycles/position, "
                  "%.0f steps, fast %.1f%% of %.0f positions\n",
                  ksec[0] * 1e3, ksec[1] * 1e3, ksec[2] * 1e3, a[1] / a[4], a[0],
                  100.0 * a[2] / (a[2] + a[3] + 1e-9), a[4]);
+    if (dp_mode != 1 && dp_mode != 4) {
+      const char* nm[5] = {"32", "16", "8", "8 (two registers)", "generic"};
+      for (int i = 0; i < 5; ++i)
+        std::fprintf(stderr, "  path %-18s %5.1f%% of positions, %6.1f cycles/position\n", nm[i], 100.0 * a[6 + 2 * i] / a[4],
+                     a[5 + 2 * i] / (a[6 + 2 * i] + 1e-9));
+    } else if (a[8] > 0)
+      std::fprintf(stderr, "  producer wave 1, cycles/step: next %.0f decode %.0f fill %.0f passes %.0f barrier %.0f; "
+                   "%.2f passes/step\n", a[8] / a[0], a[9] / a[0], a[10] / a[0], a[11] / a[0], a[12] / a[0], a[13] / a[0]);
   }
   return 0;
 }

@@ -734,6 +734,8 @@ struct DpParams {
   u16* la;
   u64* prof;               // optional [nb_total][8] cycle counters (ZOPFLI_AMD_PROF=1), else null
   int debug_nofetch;       // timing experiment (profiling build only): producers build nothing, results are wrong
+  const u32* recs;         // k_sq: the match records and the change-point pool
+  const u32* pool;
 };
 
 // One position of the chain on cell register `CS` (round S): the edge values `WV`

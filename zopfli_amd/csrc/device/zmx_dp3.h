@@ -34,7 +34,27 @@
     LS = upd_ ? src1 : LS;                                                   \
   }
 
-#define D3_NP 3u
+// The same with the source recorded as a small constant K (1 + index of the position in its
+// block): the select takes an inline constant, no per-position scalar add and move.
+#define D3_RELAX_K(CS, LT, WV, K)                                            \
+  {                                                                          \
+    const double old_ = (double)(CS);                                        \
+    const double nc_ = (WV) + cj;                                            \
+    const bool upd_ = nc_ < old_;                                            \
+    CS = upd_ ? (float)nc_ : CS;                                             \
+    LT = upd_ ? (K) : LT;                                                    \
+  }
+
+// Cells WB .. WB + 31 (lanes 0..31 of register 0) are final: write their lengths and move the
+// window of cell registers 32 cells on.
+#define D3_RETIRE32(WB)                                                      \
+  {                                                                          \
+    const u32 jj_ = (WB) + lane;                                             \
+    if (lane < 32 && jj_ >= 1 && jj_ <= B) la[jj_] = (u16)(l[0] ? jj_ + 1 - l[0] : 0u); \
+    d3_rot32(c, l, lane);                                                    \
+  }
+
+#define D3_NB 2u         // tile-building waves (waves 2..); wave 0 = the chain, wave 1 = the walk and the ring
 #define D3_SPAN 896u     // rows of four consecutive steps fit in the ring (4 * 896 + slack <= 4096)
 #define D3_EV_NONE 0u
 #define D3_EV_SHORTCUT 1u
@@ -58,26 +78,31 @@ struct D3Walk {           // wave-uniform walker state (+ the per-lane dph prefe
   u32 pf_base = 0xffffffffu;
   u32 pf_sel = 0;
   uint2 pf_a = make_uint2(0, 0), pf_b = make_uint2(0, 0);
+  u32 pf_wa = 0, pf_wb = 0;   // the word of k_edges' bad-edge bitmap that holds the lane's position
 };
 
 struct D3Step {
   u32 base, q, n, event, a_cur;
 };
 
-__device__ __forceinline__ void d3_load_group(D3Walk& W, D3Group& G, const uint2* dbase, u32 B, u32 lane) {
+__device__ __forceinline__ void d3_load_group(D3Walk& W, D3Group& G, const uint2* dbase, const u32* badpos,
+                                              u32 pos_off, u32 B, u32 lane) {
   const u32 jj = W.base + lane;
   G.navail = (B - W.base < 64u) ? B - W.base : 64u;   // W.base <= B
   const bool act = lane < G.navail;
-  const uint2* nextp = dbase + (jj + 64 < B ? jj + 64 : B - 1);
+  const u32 cur = jj < B ? jj : B - 1, nxt = jj + 64 < B ? jj + 64 : B - 1;
   uint2 dh;
+  u32 bw;
   if (W.pf_sel == 0) {
-    dh = W.pf_a;
-    if (W.pf_base != W.base) dh = dbase[jj < B ? jj : B - 1];
-    W.pf_b = *nextp;
+    dh = W.pf_a; bw = W.pf_wa;
+    if (W.pf_base != W.base) { dh = dbase[cur]; bw = badpos[(pos_off + cur) >> 5]; }
+    W.pf_b = dbase[nxt];
+    W.pf_wb = badpos[(pos_off + nxt) >> 5];
   } else {
-    dh = W.pf_b;
-    if (W.pf_base != W.base) dh = dbase[jj < B ? jj : B - 1];
-    W.pf_a = *nextp;
+    dh = W.pf_b; bw = W.pf_wb;
+    if (W.pf_base != W.base) { dh = dbase[cur]; bw = badpos[(pos_off + cur) >> 5]; }
+    W.pf_a = dbase[nxt];
+    W.pf_wa = badpos[(pos_off + nxt) >> 5];
   }
   W.pf_sel ^= 1;
   W.pf_base = W.base + 64;
@@ -85,21 +110,32 @@ __device__ __forceinline__ void d3_load_group(D3Walk& W, D3Group& G, const uint2
   G.roff = dh.x;
   G.offend = G.roff + G.kend;
   G.m_short = __ballot(act && (dh.y >> 16) != 0);
-  G.m_r1 = __ballot(G.kend + lane >= 64u);                            // needs cell register 1
-  G.m_bad = G.m_short | __ballot(G.kend + lane >= 128u) | (G.m_r1 & 0xffffffffull);  // tile2 holds lanes 32..63 only
+  // the chain wave re-bases its cell registers every 32 positions (see the consumer): a position
+  // sits in lane (lane & 31) of the window, its edges reach cell register (kend + (lane & 31)) >> 6
+  G.m_r1 = __ballot(G.kend + (lane & 31u) >= 64u);                    // needs cell register 1
+  // not for the fast path: flagged, more than two registers, two registers in rows 0..31 (tile 2
+  // holds rows 32..63 only), or a match edge below mincost (k_edges' bitmap; see D3_RELAX)
+  G.m_bad = G.m_short | __ballot(G.kend + (lane & 31u) >= 128u) | (G.m_r1 & 0xffffffffull) |
+            __ballot(act && ((bw >> ((pos_off + cur) & 31u)) & 1u) != 0);
   W.have_group = true;
 }
 
-// The next step of the walk.  Identical in every wave.
-__device__ __forceinline__ D3Step d3_next(D3Walk& W, D3Group& G, const uint2* dbase, u32 B, u32 lane) {
+// The next step of the walk (wave 1 only; the other waves read its description from LDS).
+__device__ __forceinline__ D3Step d3_next(D3Walk& W, D3Group& G, const uint2* dbase, const u32* badpos, u32 pos_off,
+                                          u32 B, u32 lane) {
   D3Step S;
   if (W.bubbles) {
     S.base = W.base; S.q = 0; S.n = 0; S.a_cur = 0;
     S.event = W.bubbles == 2 ? D3_EV_BUBBLE : D3_EV_PRIME;
     --W.bubbles;
+    if (S.event == D3_EV_PRIME) {
+      // the segment that follows starts at W.base: load its group now; the ring is primed from its first row
+      if (!W.have_group && W.base <= B) { d3_load_group(W, G, dbase, badpos, pos_off, B, lane); W.q = 0; }
+      S.a_cur = rdlane_u32(G.roff, 0) & ~(DP_PIECE - 1);
+    }
     return S;
   }
-  if (!W.have_group) { d3_load_group(W, G, dbase, B, lane); W.q = 0; }
+  if (!W.have_group) { d3_load_group(W, G, dbase, badpos, pos_off, B, lane); W.q = 0; }
   u64 ms = W.q < 64 ? G.m_short & ~((1ull << W.q) - 1) : 0ull;
   if (W.noshort) ms &= ~(1ull << W.q);               // squeeze.c:273: not tested again right after a shortcut
   const u32 stop = ms ? (u32)__ffsll((long long)ms) - 1 : 64u;
@@ -129,19 +165,46 @@ __device__ __forceinline__ D3Step d3_next(D3Walk& W, D3Group& G, const uint2* db
   return S;
 }
 
-__device__ __forceinline__ bool d3_fast(const D3Step& S, const D3Group& G, u32 p0) {
-  return p0 + 8 <= S.q + S.n && ((u32)(G.m_bad >> p0) & 255u) == 0;
+// Move six cell registers 32 lanes down: new x[s] = { x[s] lanes 32..63, x[s+1] lanes 0..31 }.
+// v_permlane32_swap(a, b) exchanges lanes 32..63 of a with lanes 0..31 of b: one swap and one
+// select per register.
+__device__ __forceinline__ void d3_rot32_u(u32 (&x)[6], u32 fresh, bool lo) {
+  u32 t = x[0];
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const auto r = __builtin_amdgcn_permlane32_swap(t, x[s + 1], false, false);   // {t.lo | x.lo}, {t.hi | x.hi}
+    x[s] = lo ? r[1] : r[0];
+    t = r[1];
+  }
+  const auto r = __builtin_amdgcn_permlane32_swap(t, fresh, false, false);
+  x[5] = r[1];
+}
+
+__device__ __forceinline__ void d3_rot32(float (&c)[6], u32 (&l)[6], u32 lane) {
+  const bool lo = lane < 32;
+  u32 cu[6];
+#pragma unroll
+  for (int s = 0; s < 6; ++s) cu[s] = __float_as_uint(c[s]);
+  d3_rot32_u(cu, __float_as_uint(1e30f), lo);
+#pragma unroll
+  for (int s = 0; s < 6; ++s) c[s] = __uint_as_float(cu[s]);
+  d3_rot32_u(l, 0u, lo);
+}
+
+__device__ __forceinline__ bool d3_fast(u32 end, u64 m_bad, u32 p0) {
+  return p0 + 8 <= end && (p0 & 31u) <= 24u && ((u32)(m_bad >> p0) & 255u) == 0;   // inside one window
 }
 
 template <bool PROF>
-__global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
+__global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
   __shared__ __align__(16) double s_ring[DP_FRONT + DP_RING + DP_MIRROR];
   __shared__ __align__(16) double s_t1[2][64 * 64];   // register-0 rows, row = position in the group
   __shared__ __align__(16) double s_t2[2][32 * 64];   // register-1 rows, row = position & 31
-  __shared__ uint2 s_tab[D3_NP][64];
-  __shared__ u32 s_badblk[2];   // per tile buffer: bit i = block i of the step has an edge below mincost
-  __shared__ u32 s_desc[2][8];  // per tile buffer, written by wave 1: [0] q | n << 8 | event << 16 | last << 24 [1] base [2..3] m_r1 [4..5] m_bad
-  __shared__ uint2 s_tabc[2][64];   // per tile buffer: {roff, kend} of the group, for the consumer's generic path
+  __shared__ uint2 s_tab[D3_NB][64];
+  // step descriptors, written by wave 1 a step ahead of the builders, two ahead of the chain wave:
+  // [0] q | n << 8 | event << 16 | last << 24 [1] base [2..3] m_r1 [4..5] m_bad
+  __shared__ u32 s_desc[3][8];
+  __shared__ uint2 s_tabc[3][64];   // {roff, kend} of the step's group
   __shared__ float s_xc[DP_XN];
   __shared__ u16 s_xl[DP_XN];
 
@@ -161,11 +224,7 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
   const double symbolcost258 = (double)(0 + 0) + P.cost[(u64)b * 320 + 285] + P.cost[(u64)b * 320 + 288];
   const double kInf = __longlong_as_double(0x7ff0000000000000ll);
   const u32 ring_lds = (u32)(unsigned long)(__attribute__((address_space(3))) double*)s_ring;
-
-  if (tid < 2) s_badblk[tid] = 0;
-  D3Walk W;
-  D3Group G;
-  G.roff = G.kend = G.offend = 0; G.m_short = G.m_r1 = G.m_bad = 0; G.navail = 0;
+#define D3_TICK() (PROF ? (u64)__builtin_readcyclecounter() : 0ull)
 
   if (wave == 0) {
     // ================================================================= consumer
@@ -174,51 +233,51 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
 #pragma unroll
     for (int s = 0; s < 6; ++s) { c[s] = 1e30f; l[s] = 0; }
     if (lane == 0) c[0] = 0.0f;
+    u32 wo = 0;   // the cell registers cover cells base + wo + 64 s + lane: wo = 32 once the chain is past position 31 of the group
     u64 t_work = 0, n_fast = 0, n_slow = 0, n_steps = 0;
     u64 tp[5] = {0, 0, 0, 0, 0}, np[5] = {0, 0, 0, 0, 0};   // PROF: cycles and positions per path
-#define D3_TICK() (PROF ? (u64)__builtin_readcyclecounter() : 0ull)
 
-    __syncthreads();   // iteration 0: the producers' first step, nothing to consume yet
-    u32 it = 1;
+    __syncthreads();   // iteration 0: wave 1 walks step 0
+    __syncthreads();   // iteration 1: the builders' first step, nothing to consume yet
+    u32 it = 2;        // this wave works on step it - 2
     for (;;) {
       const u64 tw0 = PROF ? (u64)__builtin_readcyclecounter() : 0ull;
       // the step as wave 1 described it (the consumer never looks at dph[] itself)
       u32 dv[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) dv[i] = s_desc[(it - 1) & 1][i];
+      for (int i = 0; i < 6; ++i) dv[i] = s_desc[(it - 2) % 3][i];
 #pragma unroll
       for (int i = 0; i < 6; ++i) dv[i] = (u32)__builtin_amdgcn_readfirstlane((int)dv[i]);
       D3Step S;
       S.q = dv[0] & 255u; S.n = (dv[0] >> 8) & 255u; S.event = (dv[0] >> 16) & 255u; S.base = dv[1]; S.a_cur = 0;
       const bool last = (dv[0] >> 24) != 0;
+      struct { u64 m_r1, m_bad; } G;   // the step's group, as wave 1 described it
       G.m_r1 = ((u64)dv[3] << 32) | dv[2];
       G.m_bad = ((u64)dv[5] << 32) | dv[4];
-      const uint2* tabc = s_tabc[(it - 1) & 1];
-      const double* t1 = s_t1[(it - 1) & 1];
-      const double* t2 = s_t2[(it - 1) & 1];
-      u32 badblk = 0;
-      if (S.n) {
-        badblk = (u32)__builtin_amdgcn_readfirstlane((int)s_badblk[(it - 1) & 1]);
-        if (lane == 0) s_badblk[(it - 1) & 1] = 0;   // the producers OR into it again two steps from now
-      }
-      u32 base = S.base;
+      const uint2* tabc = s_tabc[(it - 2) % 3];
+      const double* t1 = s_t1[it & 1];
+      const double* t2 = s_t2[it & 1];
+      const u32 send = S.q + S.n;
+      const u32 base = S.base;
       u32 p0 = S.q;
       u32 bi = 0;   // block index within the step
       for (; p0 < S.q + S.n; ++bi) {
         const u64 tk = D3_TICK();
-        // four single-register blocks in one go (the usual start of a group)
-        if (p0 + 32 <= S.q + S.n && ((u32)(G.m_bad >> p0)) == 0 && ((badblk >> bi) & 15) == 0 &&
+        if (p0 >= 32 && wo == 0) { D3_RETIRE32(base) wo = 32; }
+        const u32 pw0 = p0 - wo;                 // window lane of position p0
+        // a whole window of single-register positions (the usual case)
+        if (pw0 == 0 && p0 + 32 <= S.q + S.n && ((u32)(G.m_bad >> p0)) == 0 &&
             ((u32)(G.m_r1 >> p0)) == 0) {
           double w0[32];
 #pragma unroll
           for (int u = 0; u < 32; ++u) w0[u] = t1[(p0 + u) * 64 + lane];
+          u32 lt = 0;                            // 1 + index of the last position that updated the cell
 #pragma unroll
           for (int u = 0; u < 32; ++u) {
-            const u32 p = p0 + u;
-            const double cj = (double)rdlane_f32(c[0], p);
-            const u32 src1 = base + p + 1;
-            D3_RELAX(c[0], l[0], w0[u])
+            const double cj = (double)rdlane_f32(c[0], (u32)u);
+            D3_RELAX_K(c[0], lt, w0[u], (u32)(u + 1))
           }
+          l[0] = lt ? base + p0 + lt : l[0];
           n_fast += 32;
           p0 += 32;
           bi += 3;
@@ -226,25 +285,25 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
           continue;
         }
         // two single-register blocks in one go: 16 rows in flight, half the dispatch
-        if (d3_fast(S, G, p0) && d3_fast(S, G, p0 + 8) && ((badblk >> bi) & 3) == 0 &&
+        if (pw0 <= 16 && d3_fast(send, G.m_bad, p0) && d3_fast(send, G.m_bad, p0 + 8) &&
             ((u32)(G.m_r1 >> p0) & 0xffffu) == 0) {
           double w0[16];
 #pragma unroll
           for (int u = 0; u < 16; ++u) w0[u] = t1[(p0 + u) * 64 + lane];
+          u32 lt = 0;
 #pragma unroll
           for (int u = 0; u < 16; ++u) {
-            const u32 p = p0 + u;
-            const double cj = (double)rdlane_f32(c[0], p);
-            const u32 src1 = base + p + 1;
-            D3_RELAX(c[0], l[0], w0[u])
+            const double cj = (double)rdlane_f32(c[0], pw0 + u);
+            D3_RELAX_K(c[0], lt, w0[u], (u32)(u + 1))
           }
+          l[0] = lt ? base + p0 + lt : l[0];
           n_fast += 16;
           p0 += 16;
           ++bi;
           if (PROF) { tp[1] += D3_TICK() - tk; np[1] += 16; }
           continue;
         }
-        if (d3_fast(S, G, p0) && !((badblk >> bi) & 1)) {
+        if (d3_fast(send, G.m_bad, p0)) {
           const bool two = ((u32)(G.m_r1 >> p0) & 255u) != 0;
           double w0[8], w1[8];
 #pragma unroll
@@ -253,40 +312,41 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) w1[u] = t2[((p0 + u) & 31) * 64 + lane];
           }
+          u32 lt = 0, lt1 = 0;
           if (!two) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-              const u32 p = p0 + u;
-              const double cj = (double)rdlane_f32(c[0], p);
-              const u32 src1 = base + p + 1;
-              D3_RELAX(c[0], l[0], w0[u])
+              const double cj = (double)rdlane_f32(c[0], pw0 + u);
+              D3_RELAX_K(c[0], lt, w0[u], (u32)(u + 1))
             }
           } else {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-              const u32 p = p0 + u;
-              const double cj = (double)rdlane_f32(c[0], p);
-              const u32 src1 = base + p + 1;
-              D3_RELAX(c[0], l[0], w0[u])
-              D3_RELAX(c[1], l[1], w1[u])
+              const double cj = (double)rdlane_f32(c[0], pw0 + u);
+              D3_RELAX_K(c[0], lt, w0[u], (u32)(u + 1))
+              D3_RELAX_K(c[1], lt1, w1[u], (u32)(u + 1))
             }
+            l[1] = lt1 ? base + p0 + lt1 : l[1];
           }
+          l[0] = lt ? base + p0 + lt : l[0];
           n_fast += 8;
           p0 += 8;
           if (PROF) { tp[two ? 3 : 2] += D3_TICK() - tk; np[two ? 3 : 2] += 8; }
           continue;
         }
         // generic path straight from the ring (ragged tails, long matches, exempt flagged positions,
-        // blocks with an edge below mincost): the reference's tests, literally
+        // blocks that straddle two windows or have an edge below mincost): the reference's tests, literally
         const u32 pend = p0 + 8 <= S.q + S.n ? p0 + 8 : S.q + S.n;
         for (u32 p = p0; p < pend; ++p) {
+          if (p >= 32 && wo == 0) { D3_RETIRE32(base) wo = 32; }
+          const u32 pw = p - wo;
           const uint2 tc = tabc[p];
           const u32 ro = (u32)__builtin_amdgcn_readfirstlane((int)tc.x);
           const u32 ke = (u32)__builtin_amdgcn_readfirstlane((int)tc.y);
-          const double cj = (double)rdlane_f32(c[0], p);
+          const double cj = (double)rdlane_f32(c[0], pw);
           const u32 src1 = base + p + 1;
-          const u32 km1 = lane - p - 1;
-          const u32 smax = (ke + p) >> 6;
+          const u32 km1 = lane - pw - 1;
+          const u32 smax = (ke + pw) >> 6;
 #pragma unroll
           for (int s = 0; s < 6; ++s) {
             if ((u32)s <= smax) {
@@ -304,22 +364,22 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
         p0 = pend;
       }
       if (S.event == D3_EV_GROUP_END) {
-        // cells base..base+63 are final
-        const u32 jj = base + lane;
-        if (jj <= B && jj >= 1) la[jj] = (u16)(l[0] ? jj + 1 - l[0] : 0u);
-#pragma unroll
-        for (int s = 0; s < 5; ++s) { c[s] = c[s + 1]; l[s] = l[s + 1]; }
-        c[5] = 1e30f;
-        l[5] = 0;
+        // every cell of the group is final: retire what is left of it, the registers move on to
+        // the next group's base
+        if (wo == 0) { D3_RETIRE32(base) }
+        { D3_RETIRE32(base + 32) }
+        wo = 0;
       } else if (S.event == D3_EV_SHORTCUT) {
         // long-run shortcut at position q + n of the group (squeeze.c:251-271)
         const u32 p = S.q + S.n;
+        if (p >= 32 && wo == 0) { D3_RETIRE32(base) wo = 32; }
+        const u32 pw = p - wo, wbase = base + wo;
         const u32 j = base + p;
-        if (lane < p && base + lane >= 1) la[base + lane] = (u16)(l[0] ? base + lane + 1 - l[0] : 0u);
+        if (lane < pw && wbase + lane >= 1) la[wbase + lane] = (u16)(l[0] ? wbase + lane + 1 - l[0] : 0u);
         wave_lds_sync();
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
-          const u32 x = base + 64u * s + lane;
+          const u32 x = wbase + 64u * s + lane;
           s_xc[64 * s + lane] = c[s];
           s_xl[64 * s + lane] = (u16)(l[s] ? x + 1 - l[s] : 0u);
         }
@@ -332,8 +392,8 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
           const u32 t = 64u * r + lane;
           nc4[r] = 1e30f;
           if (t < ZMX_MAX_MATCH) {
-            la[j + t] = s_xl[p + t];
-            nc4[r] = (float)((double)s_xc[p + t] + symbolcost258);
+            la[j + t] = s_xl[pw + t];
+            nc4[r] = (float)((double)s_xc[pw + t] + symbolcost258);
           }
         }
 #pragma unroll
@@ -343,6 +403,7 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
           const u32 t = 64u * r + lane;
           if (t < ZMX_MAX_MATCH) { c[r] = nc4[r]; l[r] = j + t + 1; }
         }
+        wo = 0;                                  // the registers now sit at the next group's base, j + 258
         wave_lds_sync();
       }
       if (PROF) { t_work += (u64)__builtin_readcyclecounter() - tw0; ++n_steps; }
@@ -352,38 +413,30 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
     }
     if (lane == 0) la[0] = 0;
     if (PROF && P.prof && lane == 0) {
-      u64* o = P.prof + (u64)b * 16;
+      u64* o = P.prof + (u64)b * ZMX_PROF_N;
       o[0] = n_steps; o[1] = t_work; o[2] = n_fast; o[3] = n_slow; o[4] = B;
       for (int i = 0; i < 5; ++i) { o[5 + 2 * i] = tp[i]; o[6 + 2 * i] = np[i]; }
     }
-#undef D3_TICK
     return;
   }
 
-  // =================================================================== producers
-  const u32 my = wave - 1;
-  u32 issued_end = 0;      // wave 1: rows [.., issued_end) have been requested into the ring
-  u32 a_prev = 0;          // a_cur of the step the consumer works on during this iteration
-  u32 it = 0;
-  bool more = true;
-  while (more) {
-    const D3Step S = d3_next(W, G, dbase, B, lane);
-    more = W.bubbles || W.base <= B;
-    if (wave == 1) {   // describe the step for the consumer
-      if (S.n) s_tabc[it & 1][lane] = make_uint2(G.roff, G.kend);
-      if (lane == 0) {
-        u32* d = s_desc[it & 1];
-        d[0] = S.q | (S.n << 8) | (S.event << 16) | ((more ? 0u : 1u) << 24);
-        d[1] = S.base;
-        d[2] = (u32)G.m_r1; d[3] = (u32)(G.m_r1 >> 32);
-        d[4] = (u32)G.m_bad; d[5] = (u32)(G.m_bad >> 32);
-      }
-    }
-    if (S.event == D3_EV_PRIME) {
-      // the segment that follows starts at W.base: load its group now, prime the ring from there
-      if (!W.have_group && W.base <= B) { d3_load_group(W, G, dbase, B, lane); W.q = 0; }
-      if (wave == 1) {
-        const u32 a0 = rdlane_u32(G.roff, 0) & ~(DP_PIECE - 1);
+  // =================================================================== wave 1: the walk and the ring
+  u64 tq[4] = {0, 0, 0, 0};   // PROF: cycles in the walk / ring upkeep / tiles / barrier
+  if (wave == 1) {
+    D3Walk W;
+    D3Group G;
+    G.roff = G.kend = G.offend = 0; G.m_short = G.m_r1 = G.m_bad = 0; G.navail = 0;
+    D3Step cur;              // the step the builders work on during this iteration (walked one iteration ago)
+    cur.base = cur.q = cur.n = cur.a_cur = 0; cur.event = D3_EV_BUBBLE;
+    u32 issued_end = 0;      // rows [.., issued_end) have been requested into the ring
+    u32 a_prev = 0;          // a_cur of the step the chain wave works on during this iteration
+    u32 it = 0, tail = 0;
+    bool more = true;
+    while (tail < 2) {       // two more barriers after the last step has been walked
+      const u64 tk0 = D3_TICK();
+      // ---- the ring, for the step walked one iteration ago
+      if (cur.event == D3_EV_PRIME) {
+        const u32 a0 = cur.a_cur;
         issued_end = a0;
         a_prev = a0;
         const u32 lim = a0 + DP_RING < total_pad ? a0 + DP_RING : total_pad;
@@ -394,11 +447,9 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
           issued_end += DP_PIECE;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-    } else if (S.event != D3_EV_BUBBLE) {
-      if (wave == 1) {
-        // what was requested during the previous step has landed; keep the ring one ring ahead of
-        // the step the consumer is reading
+      } else if (cur.event != D3_EV_BUBBLE) {
+        // what was requested during the previous iteration has landed; keep the ring one ring ahead
+        // of the step the chain wave is reading
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const u32 lim = a_prev + DP_RING < total_pad ? a_prev + DP_RING : total_pad;
         while (issued_end < lim) {
@@ -407,51 +458,97 @@ __global__ __launch_bounds__(64 * (D3_NP + 1)) void k_dp3(DpParams P) {
           if (slot < DP_MIRROR) dp_dma_piece(rows + issued_end + lane * 2, ring_lds + (DP_FRONT + DP_RING + slot) * 8);
           issued_end += DP_PIECE;
         }
-        if (S.n) a_prev = S.a_cur;
+        if (cur.n) a_prev = cur.a_cur;
       }
-      if (S.n && !(PROF && P.debug_nofetch)) {
-        // my copy of the per-position table of this group (cheap enough to redo per step)
+      const u64 tk1 = D3_TICK();
+      // ---- walk one step ahead and describe it
+      cur.n = 0; cur.event = D3_EV_BUBBLE;
+      if (more) {
+        cur = d3_next(W, G, dbase, P.badpos + (bd.pos_off >> 5), (u32)(bd.pos_off & 31), B, lane);
+        more = W.bubbles || W.base <= B;
+        if (cur.n) s_tabc[it % 3][lane] = make_uint2(G.roff, G.kend);
+        if (lane == 0) {
+          u32* d = s_desc[it % 3];
+          d[0] = cur.q | (cur.n << 8) | (cur.event << 16) | ((more ? 0u : 1u) << 24);
+          d[1] = cur.base;
+          d[2] = (u32)G.m_r1; d[3] = (u32)(G.m_r1 >> 32);
+          d[4] = (u32)G.m_bad; d[5] = (u32)(G.m_bad >> 32);
+        }
+      } else {
+        ++tail;
+      }
+      const u64 tk2 = D3_TICK();
+      __syncthreads();
+      if (PROF) { tq[1] += tk1 - tk0; tq[0] += tk2 - tk1; tq[3] += D3_TICK() - tk2; }
+      ++it;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA in flight when the workgroup's LDS is released
+  } else {
+    // ================================================================= waves 2..: the tiles
+    const u32 my = wave - 2;
+    __syncthreads();         // iteration 0: wave 1 walks step 0
+    u32 it = 1;              // this wave works on step it - 1
+    for (;;) {
+      const u64 tk0 = D3_TICK();
+      u32 dv[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dv[i] = s_desc[(it - 1) % 3][i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dv[i] = (u32)__builtin_amdgcn_readfirstlane((int)dv[i]);
+      const u32 sq = dv[0] & 255u, sn = (dv[0] >> 8) & 255u, sev = (dv[0] >> 16) & 255u;
+      const bool last = (dv[0] >> 24) != 0;
+      const u64 m_r1 = ((u64)dv[3] << 32) | dv[2], m_bad = ((u64)dv[5] << 32) | dv[4];
+      if (sn && sev != D3_EV_BUBBLE && sev != D3_EV_PRIME && !(PROF && P.debug_nofetch)) {
+        const uint2 tc = s_tabc[(it - 1) % 3][lane];
         wave_lds_sync();
-        s_tab[my][lane] = make_uint2(((G.roff & (DP_RING - 1)) - lane - 1) * 8u, G.kend);
+        s_tab[my][lane] = make_uint2(((tc.x & (DP_RING - 1)) - lane - 1) * 8u, tc.y);
         wave_lds_sync();
-        double* t1 = s_t1[it & 1];
-        double* t2 = s_t2[it & 1];
+        double* t1 = s_t1[(it - 1) & 1];
+        double* t2 = s_t2[(it - 1) & 1];
         const char* ring0 = reinterpret_cast<const char*>(s_ring + DP_FRONT);
         u32 blk = 0;
-        for (u32 p0 = S.q; p0 < S.q + S.n; p0 += 8) {
-          if (!d3_fast(S, G, p0)) continue;   // (a non-fast block is at most 8 positions: the walk realigns after it)
-          if ((blk++ % D3_NP) != my) continue;
-          const bool two = ((u32)(G.m_r1 >> p0) & 255u) != 0;
+        for (u32 p0 = sq; p0 < sq + sn; p0 += 8) {
+          if (!d3_fast(sq + sn, m_bad, p0)) continue;   // (a non-fast block is at most 8 positions: the walk realigns after it)
+          if ((blk++ % D3_NB) != my) continue;
+          const bool two = ((u32)(m_r1 >> p0) & 255u) != 0;
           uint2 t[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) t[u] = s_tab[my][p0 + u];
-          double v0[8], v1[8];
+          const u32 wl = lane + (p0 & 32u);   // window lane -> group lane
+          const u32 d0 = wl - p0 - 1;
+          if (!two) {
+            double v0[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const double* row = reinterpret_cast<const double*>(ring0 + (int)t[u].x);
-            v0[u] = row[lane];                 // row[lane] = edge k = lane - p
-            if (two) v1[u] = row[lane + 64];
-          }
-          const u32 d0 = lane - p0 - 1;
-          bool below = false;   // a match edge (k >= 3) of this block costs less than mincost
+            for (int u = 0; u < 8; ++u) v0[u] = reinterpret_cast<const double*>(ring0 + (int)t[u].x)[wl];   // row[x] = edge k = x - p
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const u32 km1 = d0 - u;
-            const bool val0 = km1 < t[u].y;
-            t1[(p0 + u) * 64 + lane] = val0 ? v0[u] : kInf;
-            below |= val0 && km1 != 0 && v0[u] < mincost;           // km1 == 0: the literal has no such test
-            if (two) {
-              const bool val1 = km1 + 64 < t[u].y;
-              t2[((p0 + u) & 31) * 64 + lane] = val1 ? v1[u] : kInf;
-              below |= val1 && km1 + 64 != 0 && v1[u] < mincost;
+            for (int u = 0; u < 8; ++u) t1[(p0 + u) * 64 + lane] = d0 - u < t[u].y ? v0[u] : kInf;
+          } else {
+            double v0[8], v1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const double* row = reinterpret_cast<const double*>(ring0 + (int)t[u].x);
+              v0[u] = row[wl];
+              v1[u] = row[wl + 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              t1[(p0 + u) * 64 + lane] = d0 - u < t[u].y ? v0[u] : kInf;
+              t2[((p0 + u) & 31) * 64 + lane] = d0 - u + 64 < t[u].y ? v1[u] : kInf;
             }
           }
-          if (__ballot(below) && lane == 0) atomicOr(&s_badblk[it & 1], 1u << ((p0 - S.q) >> 3));
         }
       }
+      const u64 tk1 = D3_TICK();
+      __syncthreads();
+      if (PROF) { tq[2] += tk1 - tk0; tq[3] += D3_TICK() - tk1; }
+      ++it;
+      if (last) break;
     }
-    __syncthreads();
-    ++it;
+    __syncthreads();         // the chain wave's last step
   }
-  __syncthreads();   // the consumer's last step
+  if (PROF && P.prof && wave <= 2 && lane == 0) {
+    u64* o = P.prof + (u64)b * ZMX_PROF_N + 16 + 8 * (wave - 1);
+    for (int i = 0; i < 4; ++i) o[i] = tq[i];
+  }
+#undef D3_TICK
 }

@@ -93,6 +93,8 @@ struct zmx_tables {
   int* d_slot = nullptr;
   uint2* d_dph = nullptr;         // per position: DP row offset, kend | shortcut flag (k_rowscan)
   u64* d_block_edges = nullptr;   // per block: DP edges
+  u32* d_badpos = nullptr;        // bit per position: k_edges found a match edge below mincost (per run)
+  size_t badpos_words = 0;
   u64* d_row_base = nullptr;      // per block: first slot in ctx->d_rows for its launch range
   u32* d_seg_off = nullptr;       // per block: first trace segment (cumulative)
   u32* d_extab = nullptr;         // per trace segment: exit table (k_trace_exits)
@@ -257,6 +259,7 @@ void zmx_tables_free(zmx_ctx* c, zmx_tables* t) {
   PoolFree(c, t->d_slot);
   PoolFree(c, t->d_dph);
   PoolFree(c, t->d_block_edges);
+  PoolFree(c, t->d_badpos);
   PoolFree(c, t->d_row_base);
   PoolFree(c, t->d_seg_off);
   PoolFree(c, t->d_extab);
@@ -315,6 +318,8 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   HIPCHK(PoolAlloc(c, &t->d_slot, nb));
   HIPCHK(PoolAlloc(c, &t->d_dph, pos_off));
   HIPCHK(PoolAlloc(c, &t->d_block_edges, nb));
+  t->badpos_words = pos_off / 32 + 4;
+  HIPCHK(PoolAlloc(c, &t->d_badpos, t->badpos_words));
   HIPCHK(PoolAlloc(c, &t->d_row_base, nb));
   HIPCHK(PoolAlloc(c, &t->d_counters, 16));
   HIPCHK(PoolAlloc(c, &t->d_flags, 4));
@@ -484,7 +489,7 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     c->rows_cap = t->max_range_rows;
   }
   static const bool want_prof = std::getenv("ZOPFLI_AMD_PROF") != nullptr;
-  if (want_prof && !t->d_prof) HIPCHK(PoolAlloc(c, &t->d_prof, t->nb * 16));
+  if (want_prof && !t->d_prof) HIPCHK(PoolAlloc(c, &t->d_prof, t->nb * ZMX_PROF_N));
   EdgeParams ep;
   ep.blocks = t->d_blocks;
   ep.tile_off = t->d_tile_off;
@@ -495,6 +500,8 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   ep.cost = t->d_cost;
   ep.rows = c->d_rows;
   ep.row_base = t->d_row_base;
+  ep.mincost = t->d_mincost;
+  ep.badpos = t->d_badpos;
   DpParams cp;
   cp.blocks = t->d_blocks;
   cp.dph = t->d_dph;
@@ -507,6 +514,8 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   cp.prof = t->d_prof;
   cp.recs = t->d_recs;
   cp.pool = t->d_pool;
+  cp.badpos = t->d_badpos;
+  if (need_rows) HIPCHK(hipMemsetAsync(t->d_badpos, 0, t->badpos_words * sizeof(u32), c->stream));
   static const bool nofetch = std::getenv("ZOPFLI_AMD_DEBUG_NOFETCH") != nullptr;
   cp.debug_nofetch = nofetch ? 1 : 0;
   TraceSegParams tp;
@@ -542,8 +551,8 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
       if (cp.prof) hipLaunchKernelGGL(k_sq<true>, dim3(nblk), dim3(64 * (SQ_NP + 1)), 0, c->stream, cp);
       else hipLaunchKernelGGL(k_sq<false>, dim3(nblk), dim3(64 * (SQ_NP + 1)), 0, c->stream, cp);
     } else {                     // the product path: producer waves stage k_edges' rows for the chain wave
-      if (cp.prof) hipLaunchKernelGGL(k_dp3<true>, dim3(nblk), dim3(64 * (D3_NP + 1)), 0, c->stream, cp);
-      else hipLaunchKernelGGL(k_dp3<false>, dim3(nblk), dim3(64 * (D3_NP + 1)), 0, c->stream, cp);
+      if (cp.prof) hipLaunchKernelGGL(k_dp3<true>, dim3(nblk), dim3(64 * (D3_NB + 2)), 0, c->stream, cp);
+      else hipLaunchKernelGGL(k_dp3<false>, dim3(nblk), dim3(64 * (D3_NB + 2)), 0, c->stream, cp);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
@@ -573,10 +582,11 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   }
   for (size_t b = 0; b < t->nb; ++b) t->store_begin[slot[b]][b] = t->bsize[b] - nsym[b];
   if (t->d_prof) {
-    std::vector<u64> pr(t->nb * 16);
+    std::vector<u64> pr(t->nb * ZMX_PROF_N);
     HIPCHK(hipMemcpy(pr.data(), t->d_prof, pr.size() * sizeof(u64), hipMemcpyDeviceToHost));
-    double a[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (size_t b = 0; b < t->nb; ++b) for (int k = 0; k < 16; ++k) a[k] += static_cast<double>(pr[b * 16 + k]);
+    double a[ZMX_PROF_N] = {};
+    for (size_t b = 0; b < t->nb; ++b)
+      for (unsigned k = 0; k < ZMX_PROF_N; ++k) a[k] += static_cast<double>(pr[b * ZMX_PROF_N + k]);
     std::fprintf(stderr, "squeeze prof: edges %.2f ms dp %.2f ms trace %.2f ms; chain wave busy %.1f cycles/position, "
                  "%.0f steps, fast %.1f%% of %.0f positions\n",
                  ksec[0] * 1e3, ksec[1] * 1e3, ksec[2] * 1e3, a[1] / a[4], a[0],
@@ -586,6 +596,9 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
       for (int i = 0; i < 5; ++i)
         std::fprintf(stderr, "  path %-18s %5.1f%% of positions, %6.1f cycles/position\n", nm[i], 100.0 * a[6 + 2 * i] / a[4],
                      a[5 + 2 * i] / (a[6 + 2 * i] + 1e-9));
+      for (int w = 0; w < 2; ++w)
+        std::fprintf(stderr, "  producer wave %d, cycles/step: walk %.0f ring %.0f tiles %.0f barrier %.0f\n", w + 1,
+                     a[16 + 8 * w] / a[0], a[17 + 8 * w] / a[0], a[18 + 8 * w] / a[0], a[19 + 8 * w] / a[0]);
     } else if (a[8] > 0)
       std::fprintf(stderr, "  producer wave 1, cycles/step: next %.0f decode %.0f fill %.0f passes %.0f barrier %.0f; "
                    "%.2f passes/step\n", a[8] / a[0], a[9] / a[0], a[10] / a[0], a[11] / a[0], a[12] / a[0], a[13] / a[0]);

@@ -561,6 +561,8 @@ struct EdgeParams {
   const double* cost;      // [nb_total][320]
   double* rows;
   const u64* row_base;     // [nb_total] first row slot of each block (in doubles)
+  const double* mincost;   // [nb_total]
+  u32* badpos;             // bit per position (pos_off + p): a match edge of it costs less than mincost (zeroed per run)
 };
 
 __global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
@@ -588,6 +590,9 @@ __global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
   const u32* rbase = P.recs + bd.pos_off * 8;
   const uint2* dbase = P.dph + bd.pos_off;
   double* rows = P.rows + P.row_base[b];
+  // squeeze.c:293's mincost test is a no-op unless an edge costs less than mincost (possible only
+  // through rounding in the cost model): such positions are reported, k_dp3 tests them literally
+  const double mincost = P.mincost[b];
 
   for (u32 i = tid; i < 288; i += 256) s_ll[i] = P.cost[(u64)b * 320 + i];
   if (tid < 32) s_d[tid] = P.cost[(u64)b * 320 + 288 + tid];
@@ -687,6 +692,10 @@ __global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
             const u32 dist = s_hdist[wid][p][idx];
             // squeeze.c:155: (lbits + dbits) as int, then + ll, then + d
             w = ((double)((int)s_klb[k] + dev_dist_extra_bits(dist)) + s_kll[k]) + s_d[dev_dist_symbol(dist)];
+            if (w < mincost) {
+              const u64 gp = bd.pos_off + base + p;
+              atomicOr(&P.badpos[gp >> 5], 1u << (gp & 31));
+            }
           }
           rows[(u64)off_q + e] = w;
         }
@@ -705,8 +714,12 @@ __global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
             if ((P.pool[poff + mid] & 0xffffu) < k) plo = mid + 1; else phi = mid;
           }
           const u32 dist = plo < pn ? P.pool[poff + plo] >> 16 : 1u;
-          rows[(u64)roff_p + k - 1] =
-              ((double)((int)s_klb[k] + dev_dist_extra_bits(dist)) + s_kll[k]) + s_d[dev_dist_symbol(dist)];
+          const double w = ((double)((int)s_klb[k] + dev_dist_extra_bits(dist)) + s_kll[k]) + s_d[dev_dist_symbol(dist)];
+          rows[(u64)roff_p + k - 1] = w;
+          if (w < mincost) {
+            const u64 gp = bd.pos_off + base + p;
+            atomicOr(&P.badpos[gp >> 5], 1u << (gp & 31));
+          }
         }
       }
       q += n;
@@ -715,6 +728,7 @@ __global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
 }
 
 // ------------------------------------------------------------------ k_dp
+#define ZMX_PROF_N 32u                // u64 profiling counters per block (ZOPFLI_AMD_PROF)
 #define DP_RING 4096u                 // doubles in the LDS ring (32 KB)
 #define DP_PIECE 128u                 // doubles per LDS-DMA instruction (64 lanes x 16 B)
 #define DP_SPAN (DP_RING / 2 - 256u)  // row span of one sub-chunk: the next one is always resident too
@@ -736,6 +750,7 @@ struct DpParams {
   int debug_nofetch;       // timing experiment (profiling build only): producers build nothing, results are wrong
   const u32* recs;         // k_sq: the match records and the change-point pool
   const u32* pool;
+  const u32* badpos;       // k_edges' bad-edge bitmap (k_dp3)
 };
 
 // One position of the chain on cell register `CS` (round S): the edge values `WV`
@@ -1007,7 +1022,7 @@ __global__ __launch_bounds__(64) void k_dp(DpParams P) {
   }
   if (lane == 0) la[0] = 0;
   if (prof && lane == 0) {
-    u64* o = P.prof + (u64)b * 16;
+    u64* o = P.prof + (u64)b * ZMX_PROF_N;
     o[0] = t_stage; o[1] = t_chain; o[2] = n_fast; o[3] = n_slow; o[4] = B; o[5] = t_fast; o[6] = n_two; o[7] = t_two;
   }
 }

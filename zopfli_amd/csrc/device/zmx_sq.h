@@ -338,7 +338,7 @@ __global__ __launch_bounds__(64 * (SQ_NP + 1)) void k_sq(DpParams P) {
     }
     if (lane == 0) la[0] = 0;
     if (PROF && P.prof && lane == 0) {
-      u64* o = P.prof + (u64)b * 16;
+      u64* o = P.prof + (u64)b * ZMX_PROF_N;
       o[0] = n_steps; o[1] = t_work; o[2] = n_fast; o[3] = n_slow; o[4] = B; o[5] = 0; o[6] = 0; o[7] = 0;
     }
     return;
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(64 * (SQ_NP + 1)) void k_sq(DpParams P) {
   }
   __syncthreads();   // the chain wave's last step
   if (PROF && P.prof && wave == 1 && lane == 0) {
-    u64* o = P.prof + (u64)b * 16 + 8;
+    u64* o = P.prof + (u64)b * ZMX_PROF_N + 8;
     o[0] = tp_next; o[1] = tp_dec; o[2] = tp_fill; o[3] = tp_pass; o[4] = tp_bar; o[5] = n_pass;
   }
 #undef SQ_TICK

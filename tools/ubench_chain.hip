@@ -251,6 +251,68 @@ __global__ void k_step_pair(float* out, u64* cyc, const double* w) {
   out[threadIdx.x] = c + (float)l; if (threadIdx.x == 0) cyc[0] = t1 - t0;
 }
 
+// issue rate with only the first NACT lanes active (does the SIMD skip idle 16-lane passes?)
+template <int NACT>
+__global__ void k_int_tp_lanes(u32* out, u64* cyc, u32 x) {
+  u32 a0 = out[threadIdx.x], a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+  double d0 = a0, d1 = a1, d2 = a2, d3 = a3;
+  u64 t0 = 0, t1 = 0;
+  if (threadIdx.x < NACT) {
+    t0 = __builtin_readcyclecounter();
+#pragma unroll 4
+    for (int i = 0; i < N / 8; ++i) { a0 = a0 * 3 + x; a1 = a1 * 3 + x; a2 = a2 * 3 + x; a3 = a3 * 3 + x; d0 += 1.5; d1 += 1.5; d2 += 1.5; d3 += 1.5; }
+    t1 = __builtin_readcyclecounter();
+  }
+  out[threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (u32)(d0 + d1 + d2 + d3); if (threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+// k_step_d3 with the cost through v_min_f64 (no vcc on the cost chain); l from a side compare
+__global__ void k_step_min(float* out, u64* cyc, const double* w) {
+  float c = out[threadIdx.x];
+  u32 l = 0;
+  double w0[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) w0[u] = w[(threadIdx.x + u) & 63] + u;
+  double cd = (double)c;
+  u64 t0 = __builtin_readcyclecounter();
+  for (int i = 0; i < N / 16; ++i) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const u32 p = (i * 16 + u) & 63;
+      const double cj = (double)rdlane_f32(c, p);
+      const double nc_ = w0[u] + cj;
+      const bool upd = nc_ < cd;
+      c = (float)fmin(nc_, cd);
+      cd = (double)c;
+      l = upd ? (u32)(u + 1) : l;
+    }
+  }
+  u64 t1 = __builtin_readcyclecounter();
+  out[threadIdx.x] = c + (float)l; if (threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+// the same with the constant-source trick of k_dp3 (reference point)
+__global__ void k_step_d3k(float* out, u64* cyc, const double* w) {
+  float c = out[threadIdx.x];
+  u32 l = 0;
+  double w0[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) w0[u] = w[(threadIdx.x + u) & 63] + u;
+  u64 t0 = __builtin_readcyclecounter();
+  for (int i = 0; i < N / 16; ++i) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const u32 p = (i * 16 + u) & 63;
+      const double cj = (double)rdlane_f32(c, p);
+      const double old_ = (double)c, nc_ = w0[u] + cj;
+      const bool upd = nc_ < old_;
+      c = upd ? (float)nc_ : c;
+      l = upd ? (u32)(u + 1) : l;
+    }
+  }
+  u64 t1 = __builtin_readcyclecounter();
+  out[threadIdx.x] = c + (float)l; if (threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+
 int main() {
   double* d; float* f; u32* u; u64* cyc; double* w;
   hipMalloc(&d, 64 * 8); hipMalloc(&f, 64 * 4); hipMalloc(&u, 64 * 4); hipMalloc(&cyc, 8); hipMalloc(&w, 64 * 8);
@@ -277,10 +339,15 @@ int main() {
   RUN(k_cvt_rt, d, cyc, 1.5)
   RUN(k_step_d3, f, cyc, w)
   RUN(k_step_pair, f, cyc, w)
+  RUN(k_step_d3k, f, cyc, w)
+  RUN(k_step_min, f, cyc, w)
   RUN(k_lit_chain, d, cyc, w, 2.0)
   RUN(k_lds_chase, u, cyc)
   RUN(k_int_tp, u, cyc, 5u)
   RUN(k_readlane_tp, u, cyc)
+  RUN(k_int_tp_lanes<64>, u, cyc, 5u)
+  RUN(k_int_tp_lanes<32>, u, cyc, 5u)
+  RUN(k_int_tp_lanes<16>, u, cyc, 5u)
   RUN(k_fast_block<0>, f, cyc, 2.0)
   RUN(k_fast_block<1>, f, cyc, 2.0)
   RUN(k_fast_block<2>, f, cyc, 2.0)

@@ -34,15 +34,16 @@
     LS = upd_ ? src1 : LS;                                                   \
   }
 
-// The same with the source recorded as a small constant K (1 + index of the position in its
-// block): the select takes an inline constant, no per-position scalar add and move.
+// The hot form.  The source is recorded as a small constant K (1 + index of the position in its
+// block): the select takes an inline constant.  The new cost goes through v_min_f64 instead of
+// compare + select: (float)min(nc, (double)c) is (float)nc when nc < c and c itself otherwise
+// (exactly: c is a float), and it keeps the cost chain clear of the slow VALU -> VCC -> VALU path.
 #define D3_RELAX_K(CS, LT, WV, K)                                            \
   {                                                                          \
     const double old_ = (double)(CS);                                        \
     const double nc_ = (WV) + cj;                                            \
-    const bool upd_ = nc_ < old_;                                            \
-    CS = upd_ ? (float)nc_ : CS;                                             \
-    LT = upd_ ? (K) : LT;                                                    \
+    LT = nc_ < old_ ? (K) : LT;                                              \
+    CS = (float)fmin(nc_, old_);                                             \
   }
 
 // Cells WB .. WB + 31 (lanes 0..31 of register 0) are final: write their lengths and move the
@@ -51,7 +52,13 @@
   {                                                                          \
     const u32 jj_ = (WB) + lane;                                             \
     if (lane < 32 && jj_ >= 1 && jj_ <= B) la[jj_] = (u16)(l[0] ? jj_ + 1 - l[0] : 0u); \
-    d3_rot32(c, l, lane);                                                    \
+    if (reach < 64) {              /* only register 0 holds anything */      \
+      c[0] = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(c[0]), __float_as_uint(1e30f), false, false)[1]); \
+      l[0] = __builtin_amdgcn_permlane32_swap(l[0], 0u, false, false)[1];    \
+    } else {                                                                 \
+      d3_rot32(c, l, lane);                                                  \
+    }                                                                        \
+    reach = reach >= 32 ? reach - 32 : 0;                                    \
   }
 
 #define D3_NB 2u         // tile-building waves (waves 2..); wave 0 = the chain, wave 1 = the walk and the ring
@@ -233,6 +240,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
 #pragma unroll
     for (int s = 0; s < 6; ++s) { c[s] = 1e30f; l[s] = 0; }
     if (lane == 0) c[0] = 0.0f;
+    u32 reach = 0;   // no cell beyond window cell `reach` has been written: registers above reach >> 6 are fresh
     u32 wo = 0;   // the cell registers cover cells base + wo + 64 s + lane: wo = 32 once the chain is past position 31 of the group
     u64 t_work = 0, n_fast = 0, n_slow = 0, n_steps = 0;
     u64 tp[5] = {0, 0, 0, 0, 0}, np[5] = {0, 0, 0, 0, 0};   // PROF: cycles and positions per path
@@ -261,6 +269,37 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
       const u32 base = S.base;
       u32 p0 = S.q;
       u32 bi = 0;   // block index within the step
+      if (S.q == 0 && S.n == 64 && wo == 0 && (G.m_bad | G.m_r1) == 0) {
+        // a whole group of single-register positions (the usual step): both windows' rows are
+        // requested up front, the second window's arrive while the first one runs
+        const u64 tk = D3_TICK();
+        double wa[32], wb[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) wa[u] = t1[u * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) wb[u] = t1[(32 + u) * 64 + lane];
+        u32 lt = 0;                              // 1 + index of the last position that updated the cell
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+          const double cj = (double)rdlane_f32(c[0], (u32)u);
+          D3_RELAX_K(c[0], lt, wa[u], (u32)(u + 1))
+        }
+        l[0] = lt ? base + lt : l[0];
+        reach = reach > 63 ? reach : 63;
+        D3_RETIRE32(base)
+        wo = 32;
+        lt = 0;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+          const double cj = (double)rdlane_f32(c[0], (u32)u);
+          D3_RELAX_K(c[0], lt, wb[u], (u32)(u + 1))
+        }
+        l[0] = lt ? base + 32 + lt : l[0];
+        reach = reach > 63 ? reach : 63;
+        n_fast += 64;
+        p0 = 64;
+        if (PROF) { tp[0] += D3_TICK() - tk; np[0] += 64; }
+      }
       for (; p0 < S.q + S.n; ++bi) {
         const u64 tk = D3_TICK();
         if (p0 >= 32 && wo == 0) { D3_RETIRE32(base) wo = 32; }
@@ -278,6 +317,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
             D3_RELAX_K(c[0], lt, w0[u], (u32)(u + 1))
           }
           l[0] = lt ? base + p0 + lt : l[0];
+          reach = reach > 63 ? reach : 63;
           n_fast += 32;
           p0 += 32;
           bi += 3;
@@ -297,6 +337,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
             D3_RELAX_K(c[0], lt, w0[u], (u32)(u + 1))
           }
           l[0] = lt ? base + p0 + lt : l[0];
+          reach = reach > 63 ? reach : 63;
           n_fast += 16;
           p0 += 16;
           ++bi;
@@ -329,6 +370,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
             l[1] = lt1 ? base + p0 + lt1 : l[1];
           }
           l[0] = lt ? base + p0 + lt : l[0];
+          { const u32 r_ = two ? 127u : 63u; reach = reach > r_ ? reach : r_; }
           n_fast += 8;
           p0 += 8;
           if (PROF) { tp[two ? 3 : 2] += D3_TICK() - tk; np[two ? 3 : 2] += 8; }
@@ -347,6 +389,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
           const u32 src1 = base + p + 1;
           const u32 km1 = lane - pw - 1;
           const u32 smax = (ke + pw) >> 6;
+          reach = reach > ke + pw ? reach : ke + pw;
 #pragma unroll
           for (int s = 0; s < 6; ++s) {
             if ((u32)s <= smax) {
@@ -404,6 +447,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
           if (t < ZMX_MAX_MATCH) { c[r] = nc4[r]; l[r] = j + t + 1; }
         }
         wo = 0;                                  // the registers now sit at the next group's base, j + 258
+        reach = ZMX_MAX_MATCH - 1;
         wave_lds_sync();
       }
       if (PROF) { t_work += (u64)__builtin_readcyclecounter() - tw0; ++n_steps; }

@@ -553,17 +553,32 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
         u32 blk = 0;
         for (u32 p0 = sq; p0 < sq + sn; p0 += 8) {
           if (!d3_fast(sq + sn, m_bad, p0)) continue;   // (a non-fast block is at most 8 positions: the walk realigns after it)
+          const u32 wl = lane + (p0 & 32u);   // window lane -> group lane
+          const u32 d0 = wl - p0 - 1;
+          // two single-register blocks of one window in one pass: twice the LDS reads in flight
+          if ((p0 & 31u) <= 16u && d3_fast(sq + sn, m_bad, p0 + 8) && ((u32)(m_r1 >> p0) & 0xffffu) == 0) {
+            if ((blk++ % D3_NB) == my) {
+              uint2 t[16];
+#pragma unroll
+              for (int u = 0; u < 16; ++u) t[u] = s_tab[my][p0 + u];
+              double v0[16];
+#pragma unroll
+              for (int u = 0; u < 16; ++u) v0[u] = reinterpret_cast<const double*>(ring0 + (int)t[u].x)[wl];   // row[x] = edge k = x - p
+#pragma unroll
+              for (int u = 0; u < 16; ++u) t1[(p0 + u) * 64 + lane] = d0 - u < t[u].y ? v0[u] : kInf;
+            }
+            p0 += 8;
+            continue;
+          }
           if ((blk++ % D3_NB) != my) continue;
           const bool two = ((u32)(m_r1 >> p0) & 255u) != 0;
           uint2 t[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) t[u] = s_tab[my][p0 + u];
-          const u32 wl = lane + (p0 & 32u);   // window lane -> group lane
-          const u32 d0 = wl - p0 - 1;
           if (!two) {
             double v0[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v0[u] = reinterpret_cast<const double*>(ring0 + (int)t[u].x)[wl];   // row[x] = edge k = x - p
+            for (int u = 0; u < 8; ++u) v0[u] = reinterpret_cast<const double*>(ring0 + (int)t[u].x)[wl];
 #pragma unroll
             for (int u = 0; u < 8; ++u) t1[(p0 + u) * 64 + lane] = d0 - u < t[u].y ? v0[u] : kInf;
           } else {

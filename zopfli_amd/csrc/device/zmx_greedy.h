@@ -35,8 +35,15 @@ __device__ __forceinline__ int gs_score(u32 h) {
   return dist > 1024 ? (int)leng - 1 : (int)leng;      // lz77.c:265-271
 }
 
-__global__ __launch_bounds__(576) void k_greedy_exits(GreedySegParams P) {
+// Pointer jumping over the automaton's states (see k_trace_exits): J[2 (i - lo) + held] = (state
+// after a run of visits, symbols emitted on the way); a state that left the segment is
+// 0x8000 | 2 (i - hi) + held.
+#define GS_ROUNDS 6
+#define GS_THREADS 512u
+
+__global__ __launch_bounds__(GS_THREADS) void k_greedy_exits(GreedySegParams P) {
   __shared__ u32 s_h[TS_SEG + 1];   // s_h[x] = header of position lo - 1 + x
+  __shared__ u32 s_j[2 * TS_SEG];
   const u32 seg = blockIdx.x;
   const u32 b = ts_find_block(P.seg_off, P.nb, seg);
   const BlockDesc bd = P.blocks[b];
@@ -44,40 +51,67 @@ __global__ __launch_bounds__(576) void k_greedy_exits(GreedySegParams P) {
   const u32 lo = (seg - P.seg_off[b]) * TS_SEG;
   const u32 hi = lo + TS_SEG < B ? lo + TS_SEG : B;
   const u32* rbase = P.recs + bd.pos_off * 8;
-  for (u32 x = threadIdx.x; x <= hi - lo; x += blockDim.x) {
+  for (u32 x = threadIdx.x; x <= hi - lo; x += GS_THREADS) {
     const u32 pos = lo + x;   // header of position pos - 1
     s_h[x] = pos >= 1 ? rbase[(u64)(pos - 1) * 8] : 0u;
   }
   __syncthreads();
-  const u32 st = threadIdx.x;
-  if (st >= GS_STATES) return;
-  u32 i = lo + (st >> 1);
-  bool held = st & 1;
-  if (i >= hi || (held && i == 0)) return;       // not an entry state of this segment
-  u32 cnt = 0;
-  while (i < hi) {
+  const u32 ns = 2 * (hi - lo);
+  // one visit of the automaton from every state (lz77.c:581-629)
+  for (u32 st = threadIdx.x; st < ns; st += GS_THREADS) {
+    u32 i = lo + (st >> 1);
+    bool held = st & 1;
+    u32 cnt = 0;
     const u32 h = s_h[i - lo + 1];
     const u32 leng = h & 0xffffu;
     const int score = gs_score(h);
-    if (held) {                                                             // lz77.c:581-607
+    bool done = false;
+    if (held) {                                                               // lz77.c:581-607
       held = false;
       const u32 hp = s_h[i - lo];
-      ++cnt;                                     // the literal or the match of position i - 1
-      if (score > gs_score(hp) + 1) {
-        if (score >= 3 && leng < ZMX_MAX_MATCH) { held = true; ++i; continue; }
-      } else {
-        i += (hp & 0xffffu) - 1;
+      if ((hp & 0xffffu) < 3u) {                 // no match can be held at i - 1: the state is never reached;
+        s_j[st] = 0x8000u;                       // park it (every live transition moves forward, runs terminate)
         continue;
       }
-    } else if (score >= 3 && leng < ZMX_MAX_MATCH) {                        // lz77.c:608-613
+      ++cnt;                                     // the literal or the match of position i - 1
+      if (score > gs_score(hp) + 1) {
+        if (score >= 3 && leng < ZMX_MAX_MATCH) { held = true; ++i; done = true; }
+      } else {
+        i += (hp & 0xffffu) - 1;
+        done = true;
+      }
+    } else if (score >= 3 && leng < ZMX_MAX_MATCH) {                          // lz77.c:608-613
       held = true; ++i;
-      continue;
+      done = true;
     }
-    ++cnt;                                                                   // lz77.c:618-629
-    i += score >= 3 ? leng : 1u;
+    if (!done) {                                                              // lz77.c:618-629
+      ++cnt;
+      i += score >= 3 ? leng : 1u;
+    }
+    const u32 code = i < hi ? 2 * (i - lo) + (held ? 1u : 0u) : 0x8000u | (2 * (i - hi) + (held ? 1u : 0u));
+    s_j[st] = code | (cnt << 16);
   }
-  const u32 j = i - hi;                          // <= 257 (i < B cannot end held: see k_greedy_emit)
-  P.extab[(u64)seg * GS_STATES + st] = (2 * j + (held ? 1u : 0u)) | (cnt << 16);
+  __syncthreads();
+  for (int r = 0; r < GS_ROUNDS; ++r) {
+    for (u32 st = threadIdx.x; st < ns; st += GS_THREADS) {
+      const u32 v = s_j[st];
+      if (!(v & 0x8000u)) {
+        const u32 w = s_j[v & 0xffffu];
+        s_j[st] = (w & 0xffffu) | ((v & 0xffff0000u) + (w & 0xffff0000u));
+      }
+    }
+    __syncthreads();
+  }
+  for (u32 st = threadIdx.x; st < GS_STATES; st += GS_THREADS) {
+    const u32 i0 = lo + (st >> 1);
+    if (i0 >= hi || ((st & 1) && i0 == 0)) continue;     // not an entry state of this segment
+    u32 v = s_j[st];
+    while (!(v & 0x8000u)) {
+      const u32 w = s_j[v & 0xffffu];
+      v = (w & 0xffffu) | ((v & 0xffff0000u) + (w & 0xffff0000u));
+    }
+    P.extab[(u64)seg * GS_STATES + st] = (v & 0x7fffu) | (v & 0xffff0000u);   // exit state | symbols << 16
+  }
 }
 
 __global__ __launch_bounds__(64) void k_greedy_link(GreedySegParams P) {

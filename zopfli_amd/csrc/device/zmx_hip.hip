@@ -456,7 +456,7 @@ int zmx_lz77_greedy(zmx_ctx* c, zmx_tables* t, int slot, uint32_t* nsym, uint32_
   gp.extab = t->d_extab;
   gp.seginfo = t->d_seginfo;
   const unsigned nseg = t->seg_off[t->nb];
-  if (nseg) hipLaunchKernelGGL(k_greedy_exits, dim3(nseg), dim3(576), 0, c->stream, gp);
+  if (nseg) hipLaunchKernelGGL(k_greedy_exits, dim3(nseg), dim3(GS_THREADS), 0, c->stream, gp);
   hipLaunchKernelGGL(k_greedy_link, dim3(static_cast<unsigned>(t->nb)), dim3(64), 0, c->stream, gp);
   if (nseg) hipLaunchKernelGGL(k_greedy_emit, dim3(nseg), dim3(64), 0, c->stream, gp);
   HIPCHK(hipGetLastError());
@@ -558,7 +558,7 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
     tp.seg0 = t->seg_off[r.first];
     const unsigned nseg = t->seg_off[r.second] - t->seg_off[r.first];
-    if (nseg) hipLaunchKernelGGL(k_trace_exits, dim3(nseg), dim3(320), 0, c->stream, tp);
+    if (nseg) hipLaunchKernelGGL(k_trace_exits, dim3(nseg), dim3(TS_THREADS), 0, c->stream, tp);
     hipLaunchKernelGGL(k_trace_link, dim3(nblk), dim3(64), 0, c->stream, tp);
     if (nseg) hipLaunchKernelGGL(k_trace_emit, dim3(nseg), dim3(64), 0, c->stream, tp);
     HIPCHK(hipGetLastError());

@@ -57,8 +57,15 @@ __device__ __forceinline__ u32 ts_find_block(const u32* seg_off, u32 nb, u32 seg
   return lo;
 }
 
-__global__ __launch_bounds__(320) void k_trace_exits(TraceSegParams P) {
-  __shared__ __align__(16) u16 s_la[TS_SEG + 8];
+// Pointer jumping: J[h] = (where a run of steps from cell h ends, how many steps it is).  After
+// TS_ROUNDS rounds of J[h] = J[h] o J[end of J[h]] over all cells every entry is 2^TS_ROUNDS steps
+// per lookup away from its exit, instead of one dependent LDS read per symbol.  Updates are
+// in place: a concurrently updated J[t] is a valid run from t either way (32-bit words).
+#define TS_ROUNDS 6
+#define TS_THREADS 512u
+
+__global__ __launch_bounds__(TS_THREADS) void k_trace_exits(TraceSegParams P) {
+  __shared__ u32 s_j[TS_SEG + 1];   // index h - lo: cell code (inside: h' - lo; left: 0x8000 | lo - h') | steps << 16
   const u32 seg = P.seg0 + blockIdx.x;
   const u32 b = ts_find_block(P.seg_off, P.nb_total, seg);
   const BlockDesc bd = P.blocks[b];
@@ -66,23 +73,34 @@ __global__ __launch_bounds__(320) void k_trace_exits(TraceSegParams P) {
   u32 lo, hi;
   ts_bounds(B, seg - P.seg_off[b], lo, hi);
   const u16* la = P.la + bd.la_off;
-  // cells lo .. hi (cell lo itself is never read: the walk stops at heads <= lo)
-  const u32 a0 = lo & ~7u;   // 16-byte aligned (la rows are padded to 8 entries)
-  for (u32 i = threadIdx.x; i * 8 <= hi - a0; i += blockDim.x) {
-    reinterpret_cast<uint4*>(s_la)[i] = *reinterpret_cast<const uint4*>(la + a0 + i * 8);
+  const u32 n = hi - lo;             // cells lo + 1 .. hi
+  for (u32 x = threadIdx.x + 1; x <= n; x += TS_THREADS) {
+    const u32 h = lo + x;
+    u32 len = la[h];
+    if (len == 0) len = 1;                   // never-reached cell: keep moving (flagged by k_trace_emit if on the path)
+    if (len > h) len = h;
+    const u32 t = h - len;
+    s_j[x] = (t > lo ? t - lo : 0x8000u | (lo - t)) | (1u << 16);
   }
   __syncthreads();
-  const u32 j = threadIdx.x;
-  if (j < TS_ENT && hi - lo > j) {          // entry head e = hi - j > lo
-    u32 h = hi - j, cnt = 0;
-    while (h > lo) {
-      u32 len = s_la[h - a0];
-      if (len == 0) len = 1;                 // never-reached cell: keep moving (flagged by k_trace_emit if on the path)
-      if (len > h) len = h;
-      h -= len;
-      ++cnt;
+  for (int r = 0; r < TS_ROUNDS; ++r) {
+    for (u32 x = threadIdx.x + 1; x <= n; x += TS_THREADS) {
+      const u32 v = s_j[x];
+      if (!(v & 0x8000u)) {
+        const u32 w = s_j[v & 0xffffu];
+        s_j[x] = (w & 0xffffu) | ((v & 0xffff0000u) + (w & 0xffff0000u));
+      }
     }
-    P.extab[(u64)seg * TS_ENT + j] = (lo - h) | (cnt << 16);
+    __syncthreads();
+  }
+  const u32 j = threadIdx.x;
+  if (j < TS_ENT && n > j) {                // entry head e = hi - j > lo
+    u32 v = s_j[n - j];
+    while (!(v & 0x8000u)) {
+      const u32 w = s_j[v & 0xffffu];
+      v = (w & 0xffffu) | ((v & 0xffff0000u) + (w & 0xffff0000u));
+    }
+    P.extab[(u64)seg * TS_ENT + j] = (v & 0x7fffu) | (v & 0xffff0000u);   // (lo - exit) | symbols << 16
   }
 }
 

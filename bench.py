@@ -29,7 +29,8 @@ sys.path.insert(0, ROOT)
 
 MB = 1000000
 WINDOW = 32768
-PMC_PROFILE = "r01_v4_bench100MB_pmc.json"
+PMC_PROFILE = "r01_v5_bench100MB_pmc.json"
+SHADER_CLOCK_HZ = 2.4e9   # MI355X peak engine clock; s_memtime counts at this rate (measured)
 
 
 def cpu_baseline(sample, options):
@@ -113,12 +114,17 @@ def main():
         crc_box = [0]
         th = threading.Thread(target=lambda: crc_box.__setitem__(0, zlib.crc32(shard)))
         th.start()  # the checksum does not depend on the device work
+        ta = time.perf_counter()
         blob = ctx.deflate_range(options, instart, inend, final)
+        tb = time.perf_counter()
         for k, v in api.last_timing(lib).items():
             timing_acc[k] = timing_acc.get(k, 0.0) + v
         th.join()
         blobs = gather_blobs(blob)
         crcs = gather_crc(crc_box[0])
+        tc = time.perf_counter()
+        timing_acc["deflate_range_call"] = timing_acc.get("deflate_range_call", 0.0) + (tb - ta)
+        timing_acc["gather"] = timing_acc.get("gather", 0.0) + (tc - tb)
         if rank != 0:
             return None
         stream = ctx.merge(blobs, header)
@@ -126,7 +132,9 @@ def main():
         for c in crcs[1:]:
             crc = crc32_combine(crc, c, size)
         total = size * world
-        return stream + crc.to_bytes(4, "little") + (total & 0xffffffff).to_bytes(4, "little")
+        out = stream + crc.to_bytes(4, "little") + (total & 0xffffffff).to_bytes(4, "little")
+        timing_acc["merge"] = timing_acc.get("merge", 0.0) + (time.perf_counter() - tc)
+        return out
 
     def sync():
         if world > 1:
@@ -193,6 +201,13 @@ def main():
                         "traffic_unit": "GB per launch (rocprofv3 PMC, profiles/" + PMC_PROFILE + ")",
                         "algorithmic_gb_per_launch": round(per_launch_bytes / 1e9, 3),
                         "avg_launch_ms": round(ksec / launches * 1e3, 3), "launches_per_step": launches / args.steps}
+            # what really bounds k_dp3: one wave per master block walks a chain of dependent updates,
+            # 8 VALU instructions per position at the 5.8 cycles a lone wave needs per instruction
+            # (tools/ubench_chain.hip)
+            block = min(size, MB)
+            cyc = (ksec / launches) * SHADER_CLOCK_HZ / block
+            roofline["chain"] = {"cycles_per_position": round(cyc, 1), "issue_floor_cycles_per_position": 46.4,
+                                 "frac_of_issue_floor": round(46.4 / cyc, 3), "clock_ghz": SHADER_CLOCK_HZ / 1e9}
         line = {
             "metric": "input MB/s at numiterations=15 (gzip, bit-exact vs reference)",
             "value": round(value, 4), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

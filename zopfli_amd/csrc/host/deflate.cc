@@ -227,6 +227,11 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
 }
 
 void MergeChunks(const std::vector<Chunk>& chunks, const unsigned char* in, BitStream* stream) {
+  size_t total = stream->bytes.size() + 16;
+  for (const Chunk& c : chunks) {
+    total += c.kind == Chunk::kBits ? c.nbits / 8 + 1 : (c.end - c.start) + 5 * ((c.end - c.start) / 65535 + 1);
+  }
+  stream->bytes.reserve(total);   // one allocation instead of a doubling chain of copies
   for (const Chunk& c : chunks) {
     if (c.kind == Chunk::kBits) {
       stream->AppendBits(c.bits.data(), c.nbits);

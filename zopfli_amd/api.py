@@ -25,7 +25,31 @@ class ZmxBlock(ctypes.Structure):
 _lib = None
 _libc = ctypes.CDLL(None)
 _libc.free.argtypes = [ctypes.c_void_p]
+_libc.malloc.argtypes = [ctypes.c_size_t]
+_libc.malloc.restype = ctypes.c_void_p
+_libc.realloc.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+_libc.realloc.restype = ctypes.c_void_p
 _u8p = ctypes.POINTER(ctypes.c_ubyte)
+
+
+def _pow2ceil(n):
+    cap = 1
+    while cap < n:
+        cap <<= 1
+    return cap
+
+
+def _owned_array(addr, size):
+    """A numpy uint8 view of a malloc'ed buffer that frees it when the array is collected."""
+    import weakref
+
+    import numpy as np
+    if size == 0:
+        _libc.free(addr)
+        return np.zeros(0, dtype=np.uint8)
+    buf = (ctypes.c_ubyte * size).from_address(addr)
+    weakref.finalize(buf, _libc.free, addr)
+    return np.frombuffer(buf, dtype=np.uint8)
 
 
 def bind(lib):
@@ -63,7 +87,7 @@ def bind(lib):
                                            P(ctypes.c_uint16)]
     lib.zmx_length_array_download.argtypes = [vp, vp, sz, P(ctypes.c_uint16)]
     lib.zmx_deflate_range.argtypes = [vp, opt, sz, sz, ctypes.c_int, P(_u8p), P(sz)]
-    lib.zmx_chunks_merge.argtypes = [P(ctypes.c_char_p), P(sz), sz, P(ctypes.c_ubyte), P(_u8p), P(sz)]
+    lib.zmx_chunks_merge.argtypes = [P(vp), P(sz), sz, P(ctypes.c_ubyte), P(_u8p), P(sz)]
     lib.zmx_last_timing.argtypes = [P(ctypes.c_double)]
     lib.zmx_last_kernel_timing.argtypes = [P(ctypes.c_double)]
     lib.zmx_last_host_timing.argtypes = [P(ctypes.c_double)]
@@ -165,22 +189,45 @@ class Context:
         self._check(self.lib.zmx_tables_build(self.handle, arr, len(blocks), ctypes.byref(t)), "zmx_tables_build")
         return Tables(self, t, list(blocks))
 
-    def deflate_range(self, options, instart, inend, final=1):
-        """zmx_deflate_range: serialised chunks of ZopfliDeflate over resident bytes [instart, inend)."""
+    def deflate_range(self, options, instart, inend, final=1, as_array=False):
+        """zmx_deflate_range: serialised chunks of ZopfliDeflate over resident bytes [instart, inend).
+        as_array=True returns a numpy view of the library's malloc'ed blob (no copy)."""
         blob, size = _u8p(), ctypes.c_size_t(0)
         self._check(self.lib.zmx_deflate_range(self.handle, ctypes.byref(options), instart, inend, final,
                                                ctypes.byref(blob), ctypes.byref(size)), "zmx_deflate_range")
+        if as_array:
+            return _owned_array(ctypes.cast(blob, ctypes.c_void_p).value, size.value)
         return _take(blob, size)
 
-    def merge(self, blobs, prefix=b""):
-        """zmx_chunks_merge after `prefix` (e.g. a gzip header); returns prefix + deflate stream."""
+    def merge(self, blobs, prefix=b"", trailer=b"", as_array=False):
+        """zmx_chunks_merge after `prefix` (e.g. a gzip header), then `trailer`: prefix + deflate
+        stream + trailer.  Blobs may be bytes or uint8 numpy arrays (not copied); the stream is
+        assembled in one malloc'ed buffer (the (out, outsize) convention of the reference, capacity
+        = next power of two) and returned as bytes, or as a numpy view of it with as_array=True."""
+        import numpy as np
         n = len(blobs)
-        arr = (ctypes.c_char_p * n)(*blobs)
-        sizes = (ctypes.c_size_t * n)(*[len(b) for b in blobs])
+        keep = [b if isinstance(b, np.ndarray) else np.frombuffer(b, dtype=np.uint8) for b in blobs]
+        arr = (ctypes.c_void_p * n)(*[k.ctypes.data for k in keep])
+        sizes = (ctypes.c_size_t * n)(*[k.size for k in keep])
         out, size, bp = _u8p(), ctypes.c_size_t(0), ctypes.c_ubyte(0)
+        if prefix:
+            addr = _libc.malloc(_pow2ceil(len(prefix)))
+            ctypes.memmove(addr, prefix, len(prefix))
+            out, size = ctypes.cast(addr, _u8p), ctypes.c_size_t(len(prefix))
         self._check(self.lib.zmx_chunks_merge(arr, sizes, n, ctypes.byref(bp), ctypes.byref(out),
                                               ctypes.byref(size)), "zmx_chunks_merge")
-        return prefix + _take(out, size)
+        addr, total = ctypes.cast(out, ctypes.c_void_p).value, size.value
+        if trailer:
+            new = total + len(trailer)
+            if addr is None or _pow2ceil(new) > (_pow2ceil(total) if total else 0):
+                addr = _libc.realloc(addr, _pow2ceil(new))
+            ctypes.memmove(addr + total, trailer, len(trailer))
+            total = new
+        if as_array:
+            return _owned_array(addr, total)
+        data = ctypes.string_at(addr, total) if total else b""
+        _libc.free(addr)
+        return data
 
 
 class Tables:

@@ -19,6 +19,7 @@
 #include "zmx_trace.h"
 #include "zmx_greedy.h"
 #include "zopfli_amd.h"
+#include "../host/thread_pool.h"
 
 namespace {
 
@@ -69,6 +70,8 @@ struct zmx_ctx {
   std::vector<std::pair<void*, size_t>> pool_free;
   size_t pool_free_bytes = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  u32* h_stage = nullptr;    // pinned staging for store downloads (grow-only)
+  size_t stage_cap = 0;      // in u32
 };
 
 struct zmx_tables {
@@ -217,6 +220,7 @@ void zmx_ctx_destroy(zmx_ctx* c) {
   (void)hipFree(c->d_in);
   (void)hipFree(c->d_scratch);
   (void)hipFree(c->d_rows);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
   for (auto& f : c->pool_free) (void)hipFree(f.first);
   for (auto& f : c->pool_live) (void)hipFree(f.first);
   for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -621,6 +625,46 @@ int zmx_store_download(zmx_ctx* c, zmx_tables* t, size_t block, int slot, uint16
     litlens[i] = static_cast<uint16_t>(tmp[i] & 0xffffu);
     dists[i] = static_cast<uint16_t>(tmp[i] >> 16);
   }
+  return 0;
+}
+
+int zmx_store_download_batch(zmx_ctx* c, zmx_tables* t, size_t n, const size_t* block, const int32_t* slot,
+                             const size_t* nsym, uint16_t* const* litlens, uint16_t* const* dists) {
+  std::vector<size_t> off(n + 1, 0);
+  for (size_t i = 0; i < n; ++i) {
+    if (block[i] >= t->nb || (slot[i] != 0 && slot[i] != 1)) return FailMsg("zmx_store_download_batch: bad block or slot");
+    if (t->store_begin[slot[i]][block[i]] + nsym[i] > t->bsize[block[i]])
+      return FailMsg("zmx_store_download_batch: nsym exceeds the store");
+    off[i + 1] = off[i] + nsym[i];
+  }
+  if (off[n] == 0) return 0;
+  HIPCHK(hipSetDevice(c->device));
+  if (off[n] > c->stage_cap) {
+    if (c->h_stage) HIPCHK(hipHostFree(c->h_stage));
+    c->h_stage = nullptr;
+    c->stage_cap = 0;
+    const size_t cap = off[n] + off[n] / 4;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), cap * sizeof(u32), hipHostMallocDefault));
+    c->stage_cap = cap;
+  }
+  // every store in one go into pinned memory, one synchronisation, then the split into the
+  // reference's two u16 arrays on the host workers
+  for (size_t i = 0; i < n; ++i) {
+    if (nsym[i] == 0) continue;
+    const u32* src = t->d_store[slot[i]] + t->blocks[block[i]].pos_off + t->store_begin[slot[i]][block[i]];
+    HIPCHK(hipMemcpyAsync(c->h_stage + off[i], src, nsym[i] * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(hipStreamSynchronize(c->stream));
+  const u32* stage = c->h_stage;
+  zamd::ParallelFor(n, [&](size_t i) {
+    const u32* s = stage + off[i];
+    uint16_t* ll = litlens[i];
+    uint16_t* dd = dists[i];
+    for (size_t k = 0; k < nsym[i]; ++k) {
+      ll[k] = static_cast<uint16_t>(s[k] & 0xffffu);
+      dd[k] = static_cast<uint16_t>(s[k] >> 16);
+    }
+  });
   return 0;
 }
 

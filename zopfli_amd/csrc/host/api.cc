@@ -85,19 +85,7 @@ int RunParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const std::v
 // Appends merged chunks at (*out, *outsize, *bp), reference conventions.
 void EmitChunks(const std::vector<zamd::Chunk>& chunks, const unsigned char* in, unsigned char* bp,
                 unsigned char** out, size_t* outsize) {
-  zamd::BitStream bs;
-  bs.bp = *bp & 7;
-  if (bs.bp != 0 && *outsize > 0) bs.bytes.push_back((*out)[*outsize - 1]);
-  else bs.bp = 0;
-  const bool shared_byte = !bs.bytes.empty();
-  zamd::MergeChunks(chunks, in, &bs);
-  if (shared_byte) {
-    (*out)[*outsize - 1] = bs.bytes[0];
-    zamd::AppendToOutput(bs.bytes.data() + 1, bs.bytes.size() - 1, out, outsize);
-  } else {
-    zamd::AppendToOutput(bs.bytes.data(), bs.bytes.size(), out, outsize);
-  }
-  *bp = static_cast<unsigned char>(bs.bp);
+  zamd::MergeChunks(chunks, in, bp, out, outsize);
 }
 
 void ResetTiming() {
@@ -271,9 +259,12 @@ int zmx_deflate_range(zmx_ctx* ctx, const ZopfliOptions* options, size_t instart
     i += size;
   } while (i < inend);
   std::vector<zamd::Chunk> chunks;
+  const auto tr0 = std::chrono::steady_clock::now();
   const int rc = RunParts(ctx, *options, 2, parts, &chunks);
   if (rc) return rc;
   const auto ts0 = std::chrono::steady_clock::now();
+  if (std::getenv("ZOPFLI_AMD_PROF"))
+    std::fprintf(stderr, "zmx_deflate_range: RunParts %.1f ms\n", std::chrono::duration<double>(ts0 - tr0).count() * 1e3);
   const std::vector<uint8_t> v = zamd::SerializeChunks(chunks, zmx_internal_input_host(ctx));
   *blob = static_cast<unsigned char*>(std::malloc(v.size() ? v.size() : 1));
   if (!*blob) return -1;

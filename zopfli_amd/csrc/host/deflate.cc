@@ -1,6 +1,7 @@
 #include "deflate.h"
 
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -118,9 +119,12 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
       all_blocks.push_back({s, e});
     }
   }
+  static const bool trace_phases = std::getenv("ZOPFLI_AMD_PROF") != nullptr;
+  const double tp0 = Now();
   std::vector<SymbolRun> runs;
   rc = Lz77OptimalBatch(ctx, options, all_blocks, &runs);
   if (rc) return rc;
+  const double tp1 = Now();
 
   // ---- 3. join the blocks, second split attempt, per-block type costs
   std::vector<zmx_block> fixed_requests;
@@ -172,9 +176,11 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
   }
 
   // ---- 4. fixed-tree re-parse where it may win (deflate.c:770-781)
+  const double tp2 = Now();
   std::vector<SymbolRun> fixed_runs;
   rc = Lz77OptimalFixedBatch(ctx, fixed_requests, &fixed_runs);
   if (rc) return rc;
+  const double tp3 = Now();
 
   // ---- 5. pick the block type and encode
   const double t5 = Now();
@@ -220,45 +226,150 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
   });
   ThreadTiming().encode += Now() - t5;
 
+  const double tp4 = Now();
   for (size_t p = 0; p < np; ++p) {
     for (auto& c : st[p].chunks) chunks->push_back(std::move(c));
+  }
+  if (trace_phases) {
+    std::fprintf(stderr, "DeflateParts: optimal batch %.1f ms, join/split %.1f ms, fixed batch %.1f ms (%zu requests), "
+                 "encode %.1f ms, chunk move %.1f ms\n", (tp1 - tp0) * 1e3, (tp2 - tp1) * 1e3, (tp3 - tp2) * 1e3,
+                 fixed_requests.size(), (tp4 - tp3) * 1e3, (Now() - tp4) * 1e3);
   }
   return 0;
 }
 
-void MergeChunks(const std::vector<Chunk>& chunks, const unsigned char* in, BitStream* stream) {
-  size_t total = stream->bytes.size() + 16;
-  for (const Chunk& c : chunks) {
-    total += c.kind == Chunk::kBits ? c.nbits / 8 + 1 : (c.end - c.start) + 5 * ((c.end - c.start) / 65535 + 1);
+namespace {
+
+// Copies bits [s0, s0 + n) of `src` (LSB-first) to dst[0 .. n / 8): n is a multiple of 8.
+void CopyBitRun(const uint8_t* src, size_t src_bytes, size_t s0, size_t n, uint8_t* dst) {
+  const size_t nb = n / 8, byte0 = s0 / 8;
+  const unsigned r = static_cast<unsigned>(s0 & 7);
+  if (r == 0) {
+    std::memcpy(dst, src + byte0, nb);
+    return;
   }
-  stream->bytes.reserve(total);   // one allocation instead of a doubling chain of copies
-  for (const Chunk& c : chunks) {
+  size_t i = 0;
+  for (; i + 8 <= nb && byte0 + i + 9 <= src_bytes; i += 8) {   // 8 output bytes from 9 source bytes
+    uint64_t v;
+    std::memcpy(&v, src + byte0 + i, 8);
+    const uint64_t out = (v >> r) | (static_cast<uint64_t>(src[byte0 + i + 8]) << (64 - r));
+    std::memcpy(dst + i, &out, 8);
+  }
+  for (; i < nb; ++i) {
+    const unsigned lo = src[byte0 + i];
+    const unsigned hi = byte0 + i + 1 < src_bytes ? src[byte0 + i + 1] : 0u;
+    dst[i] = static_cast<uint8_t>((lo >> r) | (hi << (8 - r)));
+  }
+}
+
+// bits [s0, s0 + n) of src, n <= 8, in the low bits of the result
+unsigned PeekBits(const uint8_t* src, size_t src_bytes, size_t s0, unsigned n) {
+  const size_t byte0 = s0 / 8;
+  const unsigned r = static_cast<unsigned>(s0 & 7);
+  unsigned v = src[byte0];
+  if (byte0 + 1 < src_bytes) v |= static_cast<unsigned>(src[byte0 + 1]) << 8;
+  return (v >> r) & ((1u << n) - 1u);
+}
+
+}  // namespace
+
+// Joins the chunks at the running bit position of `stream`.  Every chunk's place in the output is
+// known from a prefix sum of bit lengths, so the chunks are shifted into place in parallel (each
+// writes only the bytes it owns entirely); the <= 2 bytes a chunk shares with its neighbours are
+// OR-ed in afterwards.  Stored blocks follow AddNonCompressedBlock (deflate.c:625-665): pieces of
+// at most 65535 bytes, each byte-aligned after its 3 header bits.
+void MergeChunks(const std::vector<Chunk>& chunks, const unsigned char* in, unsigned char* bp,
+                 unsigned char** outp, size_t* outsize) {
+  struct Place { size_t bit0; };
+  std::vector<Place> place(chunks.size());
+  // bit position 0 = the first bit of (*outp)[0]; *bp bits of the last byte are used
+  unsigned bp0 = *bp & 7u;
+  if (*outsize == 0) bp0 = 0;
+  const size_t begin = bp0 ? (*outsize - 1) * 8 + bp0 : *outsize * 8;
+  size_t cur = begin;
+  for (size_t i = 0; i < chunks.size(); ++i) {
+    const Chunk& c = chunks[i];
+    place[i].bit0 = cur;
     if (c.kind == Chunk::kBits) {
-      stream->AppendBits(c.bits.data(), c.nbits);
-      continue;
+      cur += c.nbits;
+    } else {
+      size_t pos = c.start;
+      for (;;) {
+        size_t piece = 65535;
+        if (pos + piece > c.end) piece = c.end - pos;
+        cur = (cur + 3 + 7) / 8 * 8 + 8 * (4 + piece);
+        if (pos + piece >= c.end) break;
+        pos += piece;
+      }
     }
-    // AddNonCompressedBlock (deflate.c:625-665): pieces of at most 65535 bytes,
-    // each byte-aligned after its 3 header bits.
-    const unsigned char* src = c.raw.empty() ? in : c.raw.data() - c.start;
-    size_t pos = c.start;
+  }
+  const size_t newsize = (cur + 7) / 8;
+  ReserveOutput(newsize - *outsize, outp, outsize);
+  uint8_t* const out = *outp;
+
+  ParallelFor(chunks.size(), [&](size_t i) {
+    const Chunk& c = chunks[i];
+    const size_t b0 = place[i].bit0;
+    if (c.kind == Chunk::kBits) {
+      // bytes entirely inside [b0, b0 + nbits)
+      const size_t first = (b0 + 7) / 8, last = (b0 + c.nbits) / 8;
+      if (last > first) CopyBitRun(c.BitData(), c.BitBytes(), first * 8 - b0, (last - first) * 8, out + first);
+      return;
+    }
+    const unsigned char* src = c.view ? c.view - c.start : c.raw.empty() ? in : c.raw.data() - c.start;
+    size_t bit = b0, pos = c.start;
     for (;;) {
       size_t piece = 65535;
       if (pos + piece > c.end) piece = c.end - pos;
       const bool last = pos + piece >= c.end;
-      stream->AppendBit(c.final_block && last);
-      stream->AppendBit(0);
-      stream->AppendBit(0);
-      stream->bp = 0;  // rest of the byte is padding
+      uint8_t* p = out + (bit + 3 + 7) / 8;            // after the header bits and the padding
       const unsigned len = static_cast<unsigned>(piece), nlen = ~len & 0xffffu;
-      stream->AppendByteAligned(static_cast<uint8_t>(len & 255));
-      stream->AppendByteAligned(static_cast<uint8_t>(len >> 8));
-      stream->AppendByteAligned(static_cast<uint8_t>(nlen & 255));
-      stream->AppendByteAligned(static_cast<uint8_t>(nlen >> 8));
-      stream->bytes.insert(stream->bytes.end(), src + pos, src + pos + piece);
+      p[0] = static_cast<uint8_t>(len & 255);
+      p[1] = static_cast<uint8_t>(len >> 8);
+      p[2] = static_cast<uint8_t>(nlen & 255);
+      p[3] = static_cast<uint8_t>(nlen >> 8);
+      std::memcpy(p + 4, src + pos, piece);
+      bit = static_cast<size_t>(p + 4 + piece - out) * 8;
       if (last) break;
       pos += piece;
     }
+  });
+
+  // shared bytes, in stream order
+  for (size_t i = 0; i < chunks.size(); ++i) {
+    const Chunk& c = chunks[i];
+    const size_t b0 = place[i].bit0;
+    if (c.kind == Chunk::kBits) {
+      if (c.nbits == 0) continue;
+      const size_t e = b0 + c.nbits;
+      const size_t first = (b0 + 7) / 8, last = e / 8;
+      if (last < first) {                              // the whole chunk sits inside one byte
+        out[b0 / 8] |= static_cast<uint8_t>(PeekBits(c.BitData(), c.BitBytes(), 0, static_cast<unsigned>(c.nbits)) << (b0 & 7));
+        continue;
+      }
+      if (b0 & 7) {                                    // head: the free bits of the byte b0 falls in
+        const unsigned n = 8 - static_cast<unsigned>(b0 & 7);
+        out[b0 / 8] |= static_cast<uint8_t>(PeekBits(c.BitData(), c.BitBytes(), 0, n) << (b0 & 7));
+      }
+      if (e & 7) {                                     // tail: what is left after the last whole byte
+        const unsigned n = static_cast<unsigned>(e & 7);
+        out[last] |= static_cast<uint8_t>(PeekBits(c.BitData(), c.BitBytes(), c.nbits - n, n));
+      }
+    } else {
+      size_t bit = b0, pos = c.start;                  // BFINAL of every piece; BTYPE 00 is already zero
+      for (;;) {
+        size_t piece = 65535;
+        if (pos + piece > c.end) piece = c.end - pos;
+        const bool last = pos + piece >= c.end;
+        if (c.final_block && last) out[bit / 8] |= static_cast<uint8_t>(1u << (bit & 7));
+        bit = ((bit + 3 + 7) / 8 + 4 + piece) * 8;
+        if (last) break;
+        pos += piece;
+      }
+    }
   }
+  *outsize = newsize;
+  *bp = static_cast<unsigned char>(cur & 7);
 }
 
 namespace {
@@ -283,12 +394,12 @@ std::vector<uint8_t> SerializeChunks(const std::vector<Chunk>& chunks, const uns
     blob.push_back(c.final_block ? 1 : 0);
     if (c.kind == Chunk::kBits) {
       PutU64(&blob, c.nbits);
-      PutU64(&blob, c.bits.size());
-      blob.insert(blob.end(), c.bits.begin(), c.bits.end());
+      PutU64(&blob, c.BitBytes());
+      blob.insert(blob.end(), c.BitData(), c.BitData() + c.BitBytes());
     } else {
       PutU64(&blob, 0);
       PutU64(&blob, c.end - c.start);
-      const unsigned char* src = c.raw.empty() ? in + c.start : c.raw.data();
+      const unsigned char* src = c.view ? c.view : c.raw.empty() ? in + c.start : c.raw.data();
       blob.insert(blob.end(), src, src + (c.end - c.start));
     }
   }
@@ -309,14 +420,15 @@ bool DeserializeChunks(const unsigned char* blob, size_t size, std::vector<Chunk
     if (c.kind == Chunk::kBits) {
       if (off + b > size || (a + 7) / 8 > b) return false;
       c.nbits = a;
-      c.bits.assign(blob + off, blob + off + b);
+      c.view = blob + off;
+      c.view_bytes = b;
       off += b;
     } else if (c.kind == Chunk::kStored) {
       if (off + b > size) return false;
       c.start = 0;
       c.end = b;
-      c.raw.assign(blob + off, blob + off + b);
-      if (b == 0) c.raw.clear();
+      c.view = blob + off;
+      c.view_bytes = b;
       off += b;
     } else {
       return false;
@@ -324,6 +436,24 @@ bool DeserializeChunks(const unsigned char* blob, size_t size, std::vector<Chunk
     chunks->push_back(std::move(c));
   }
   return off == size;
+}
+
+void ReserveOutput(size_t n, unsigned char** out, size_t* outsize) {
+  if (n == 0) return;
+  const size_t newsize = *outsize + n;
+  size_t cap = 1;
+  while (cap < newsize) cap <<= 1;
+  size_t oldcap = 0;
+  if (*outsize > 0) {
+    oldcap = 1;
+    while (oldcap < *outsize) oldcap <<= 1;
+  }
+  if (cap > oldcap || *out == nullptr) {
+    void* p = std::realloc(*out, cap);
+    if (!p) std::exit(-1);  // the reference also exits on allocation failure
+    *out = static_cast<unsigned char*>(p);
+  }
+  std::memset(*out + *outsize, 0, n);
 }
 
 void AppendToOutput(const uint8_t* data, size_t n, unsigned char** out, size_t* outsize) {

@@ -25,6 +25,12 @@ struct Chunk {
   size_t nbits = 0;
   size_t start = 0, end = 0;    // kStored: raw input range ...
   std::vector<uint8_t> raw;     // ... or, after (de)serialisation, the bytes themselves
+  // A deserialised chunk does not copy: it points into the blob it came from (which must outlive it).
+  const uint8_t* view = nullptr;   // kBits: the packed bits; kStored: the raw bytes
+  size_t view_bytes = 0;
+
+  const uint8_t* BitData() const { return view ? view : bits.data(); }
+  size_t BitBytes() const { return view ? view_bytes : bits.size(); }
 };
 
 struct Part {
@@ -37,12 +43,19 @@ struct Part {
 int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const std::vector<Part>& parts,
                  std::vector<Chunk>* chunks);
 
-// Appends chunks to a (bytes, bp) stream; `in` is the base of the resident input.
-void MergeChunks(const std::vector<Chunk>& chunks, const unsigned char* in, BitStream* stream);
+// Appends chunks at (*out, *outsize, *bp), reference conventions (deflate.h:50-53, util.h:135-155);
+// `in` is the base of the resident input (stored chunks that still refer to it).
+void MergeChunks(const std::vector<Chunk>& chunks, const unsigned char* in, unsigned char* bp,
+                 unsigned char** out, size_t* outsize);
 
 // Stored chunks are serialised with their raw bytes (taken from `in`).
 std::vector<uint8_t> SerializeChunks(const std::vector<Chunk>& chunks, const unsigned char* in);
+// The chunks are views into `blob`.
 bool DeserializeChunks(const unsigned char* blob, size_t size, std::vector<Chunk>* chunks);
+
+// Makes room for `n` more bytes after *outsize (capacity rule of ZOPFLI_APPEND_DATA); the new
+// bytes are zero.  *outsize is not changed.
+void ReserveOutput(size_t n, unsigned char** out, size_t* outsize);
 
 // Appends `n` bytes to a reference-style growable array (util.h:135-155).
 void AppendToOutput(const uint8_t* data, size_t n, unsigned char** out, size_t* outsize);

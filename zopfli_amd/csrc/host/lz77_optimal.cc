@@ -101,11 +101,27 @@ struct BlockIter {
   uint32_t best_nsym = 0;
 };
 
-int Download(zmx_ctx* ctx, zmx_tables* t, size_t b, int slot, uint32_t nsym, SymbolRun* run) {
-  run->litlens.resize(nsym);
-  run->dists.resize(nsym);
-  if (nsym == 0) return 0;
-  return zmx_store_download(ctx, t, b, slot, run->litlens.data(), run->dists.data(), nsym);
+// Stores slot[b] of every block b with slot[b] >= 0, nsym[b] symbols each, into (*out)[b].
+int DownloadAll(zmx_ctx* ctx, zmx_tables* t, const std::vector<int32_t>& slot, const std::vector<uint32_t>& nsym,
+                std::vector<SymbolRun>* out) {
+  std::vector<size_t> block, n;
+  std::vector<int32_t> sl;
+  std::vector<uint16_t*> ll, dd;
+  ParallelFor(slot.size(), [&](size_t b) {   // first touch of ~0.6 B per input byte: not on one thread
+    if (slot[b] < 0) return;
+    (*out)[b].litlens.resize(nsym[b]);
+    (*out)[b].dists.resize(nsym[b]);
+  });
+  for (size_t b = 0; b < slot.size(); ++b) {
+    if (slot[b] < 0) continue;
+    SymbolRun& run = (*out)[b];
+    block.push_back(b);
+    sl.push_back(slot[b]);
+    n.push_back(nsym[b]);
+    ll.push_back(run.litlens.data());
+    dd.push_back(run.dists.data());
+  }
+  return zmx_store_download_batch(ctx, t, block.size(), block.data(), sl.data(), n.data(), ll.data(), dd.data());
 }
 
 }  // namespace
@@ -127,7 +143,7 @@ int Lz77GreedyBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks, std::vec
   ThreadTiming().tables += t1 - t0;
   std::vector<uint32_t> nsym(nb), hist(nb * ZMX_HIST);
   rc = zmx_lz77_greedy(ctx, t, 0, nsym.data(), hist.data());
-  for (size_t b = 0; b < nb && !rc; ++b) rc = Download(ctx, t, b, 0, nsym[b], &(*out)[b]);
+  if (!rc) rc = DownloadAll(ctx, t, std::vector<int32_t>(nb, 0), nsym, out);
   ThreadTiming().greedy += Now() - t1;
   zmx_tables_free(ctx, t);
   return rc;
@@ -222,8 +238,11 @@ int Lz77OptimalBatch(zmx_ctx* ctx, const ZopfliOptions& options, const std::vect
   }
 
   const double tdl = Now();
-  for (size_t b = 0; b < nb && !rc; ++b) {
-    if (it[b].best_slot >= 0) rc = Download(ctx, t, b, it[b].best_slot, it[b].best_nsym, &(*out)[b]);
+  {
+    std::vector<int32_t> best_slot(nb);
+    std::vector<uint32_t> best_nsym(nb);
+    for (size_t b = 0; b < nb; ++b) { best_slot[b] = it[b].best_slot; best_nsym[b] = it[b].best_nsym; }
+    if (!rc) rc = DownloadAll(ctx, t, best_slot, best_nsym, out);
   }
   ThreadTiming().download += Now() - tdl;
   zmx_tables_free(ctx, t);
@@ -255,7 +274,7 @@ int Lz77OptimalFixedBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks, st
     mincost[b] = mc;
   }
   rc = zmx_squeeze_run(ctx, t, cost.data(), mincost.data(), slot.data(), nsym.data(), hist.data());
-  for (size_t b = 0; b < nb && !rc; ++b) rc = Download(ctx, t, b, 0, nsym[b], &(*out)[b]);
+  if (!rc) rc = DownloadAll(ctx, t, std::vector<int32_t>(nb, 0), nsym, out);
   ThreadTiming().squeeze += Now() - t1;
   zmx_tables_free(ctx, t);
   return rc;

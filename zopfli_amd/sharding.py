@@ -26,9 +26,11 @@ def shard_ranges(insize, world):
 
 
 def gather_bytes(blob, rank, world, device, dist):
-    """Variable-size gather of one bytes object per rank to rank 0: sizes by all_gather, payload by
-    one gather of max-padded uint8 tensors.  Returns the list on rank 0, None elsewhere."""
+    """Variable-size gather of one bytes object (or uint8 array) per rank to rank 0: sizes by
+    all_gather, payload by one gather of max-padded uint8 tensors.  Returns the list (uint8 arrays
+    when world > 1) on rank 0, None elsewhere."""
     import torch
+    import numpy as np
     if world == 1:
         return [blob]
     n = torch.tensor([len(blob)], dtype=torch.int64, device=device)
@@ -37,13 +39,14 @@ def gather_bytes(blob, rank, world, device, dist):
     sizes = [int(s.item()) for s in sizes]
     cap = max(max(sizes), 1)
     buf = torch.zeros(cap, dtype=torch.uint8, device=device)
-    if blob:
-        buf[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+    if len(blob):
+        src = blob if isinstance(blob, np.ndarray) else np.frombuffer(blob, dtype=np.uint8)
+        buf[:len(blob)] = torch.from_numpy(src if src.flags.writeable else src.copy()).to(device)
     out = [torch.empty(cap, dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
     dist.gather(buf, out, dst=0)
     if rank != 0:
         return None
-    return [out[r][:sizes[r]].cpu().numpy().tobytes() for r in range(world)]
+    return [out[r][:sizes[r]].cpu().numpy() for r in range(world)]   # uint8 arrays: zmx_chunks_merge reads them in place
 
 
 def crc32_combine(crc1, crc2, len2):
@@ -99,8 +102,8 @@ def gzip_sharded(ctx, options, data, rank, world, device, dist):
     meta = gather_bytes(crc.to_bytes(4, "little"), rank, world, device, dist)
     if rank != 0:
         return None
-    stream = ctx.merge([b for b in blobs if b], GZIP_HEADER)
     total_crc = 0
     for r in range(world):
-        total_crc = crc32_combine(total_crc, int.from_bytes(meta[r], "little"), ranges[r][1] - ranges[r][0])
-    return stream + total_crc.to_bytes(4, "little") + (len(data) & 0xffffffff).to_bytes(4, "little")
+        total_crc = crc32_combine(total_crc, int.from_bytes(bytes(meta[r]), "little"), ranges[r][1] - ranges[r][0])
+    trailer = total_crc.to_bytes(4, "little") + (len(data) & 0xffffffff).to_bytes(4, "little")
+    return ctx.merge([b for b in blobs if len(b)], GZIP_HEADER, trailer)

@@ -63,6 +63,7 @@
 
 #define D3_NB 2u         // tile-building waves (waves 2..); wave 0 = the chain, wave 1 = the walk and the ring
 #define D3_SPAN 896u     // rows of four consecutive steps fit in the ring (4 * 896 + slack <= 4096)
+#define D3_DESC_CLEAN (1u << 25)   // descriptor word 0: a whole group, no flagged / two-register / bad-edge position
 #define D3_EV_NONE 0u
 #define D3_EV_SHORTCUT 1u
 #define D3_EV_GROUP_END 2u
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
   __shared__ uint2 s_tab[D3_NB][64];
   // step descriptors, written by wave 1 a step ahead of the builders, two ahead of the chain wave:
   // [0] q | n << 8 | event << 16 | last << 24 [1] base [2..3] m_r1 [4..5] m_bad
-  __shared__ u32 s_desc[3][8];
+  __shared__ __align__(8) u32 s_desc[3][8];
   __shared__ uint2 s_tabc[3][64];   // {roff, kend} of the step's group
   __shared__ float s_xc[DP_XN];
   __shared__ u16 s_xl[DP_XN];
@@ -248,17 +249,26 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
     __syncthreads();   // iteration 0: wave 1 walks step 0
     __syncthreads();   // iteration 1: the builders' first step, nothing to consume yet
     u32 it = 2;        // this wave works on step it - 2
+    // the first two words of the next step's descriptor are requested a step early (they were
+    // written two barriers ago); the masks are read only for a step that is not a clean group
+    uint2 nd = *reinterpret_cast<const uint2*>(s_desc[0]);
     for (;;) {
       const u64 tw0 = PROF ? (u64)__builtin_readcyclecounter() : 0ull;
       // the step as wave 1 described it (the consumer never looks at dph[] itself)
       u32 dv[6];
+      dv[0] = (u32)__builtin_amdgcn_readfirstlane((int)nd.x);
+      dv[1] = (u32)__builtin_amdgcn_readfirstlane((int)nd.y);
+      nd = *reinterpret_cast<const uint2*>(s_desc[(it - 1) % 3]);
+      dv[2] = dv[3] = dv[4] = dv[5] = 0;
+      if (!(dv[0] & D3_DESC_CLEAN)) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) dv[i] = s_desc[(it - 2) % 3][i];
+        for (int i = 2; i < 6; ++i) dv[i] = s_desc[(it - 2) % 3][i];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) dv[i] = (u32)__builtin_amdgcn_readfirstlane((int)dv[i]);
+        for (int i = 2; i < 6; ++i) dv[i] = (u32)__builtin_amdgcn_readfirstlane((int)dv[i]);
+      }
       D3Step S;
       S.q = dv[0] & 255u; S.n = (dv[0] >> 8) & 255u; S.event = (dv[0] >> 16) & 255u; S.base = dv[1]; S.a_cur = 0;
-      const bool last = (dv[0] >> 24) != 0;
+      const bool last = ((dv[0] >> 24) & 1u) != 0;
       struct { u64 m_r1, m_bad; } G;   // the step's group, as wave 1 described it
       G.m_r1 = ((u64)dv[3] << 32) | dv[2];
       G.m_bad = ((u64)dv[5] << 32) | dv[4];
@@ -513,7 +523,8 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
         if (cur.n) s_tabc[it % 3][lane] = make_uint2(G.roff, G.kend);
         if (lane == 0) {
           u32* d = s_desc[it % 3];
-          d[0] = cur.q | (cur.n << 8) | (cur.event << 16) | ((more ? 0u : 1u) << 24);
+          const bool clean = cur.q == 0 && cur.n == 64 && (G.m_r1 | G.m_bad) == 0;
+          d[0] = cur.q | (cur.n << 8) | (cur.event << 16) | ((more ? 0u : 1u) << 24) | (clean ? D3_DESC_CLEAN : 0u);
           d[1] = cur.base;
           d[2] = (u32)G.m_r1; d[3] = (u32)(G.m_r1 >> 32);
           d[4] = (u32)G.m_bad; d[5] = (u32)(G.m_bad >> 32);
@@ -540,7 +551,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) dv[i] = (u32)__builtin_amdgcn_readfirstlane((int)dv[i]);
       const u32 sq = dv[0] & 255u, sn = (dv[0] >> 8) & 255u, sev = (dv[0] >> 16) & 255u;
-      const bool last = (dv[0] >> 24) != 0;
+      const bool last = ((dv[0] >> 24) & 1u) != 0;
       const u64 m_r1 = ((u64)dv[3] << 32) | dv[2], m_bad = ((u64)dv[5] << 32) | dv[4];
       if (sn && sev != D3_EV_BUBBLE && sev != D3_EV_PRIME && !(PROF && P.debug_nofetch)) {
         const uint2 tc = s_tabc[(it - 1) % 3][lane];

@@ -307,8 +307,15 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
         l[0] = lt ? base + 32 + lt : l[0];
         reach = reach > 63 ? reach : 63;
         n_fast += 64;
-        p0 = 64;
         if (PROF) { tp[0] += D3_TICK() - tk; np[0] += 64; }
+        // its event is D3_EV_GROUP_END (64 positions, none flagged): retire the second window
+        { D3_RETIRE32(base + 32) }
+        wo = 0;
+        if (PROF) { t_work += (u64)__builtin_readcyclecounter() - tw0; ++n_steps; }
+        __syncthreads();
+        ++it;
+        if (last) break;
+        continue;
       }
       for (; p0 < S.q + S.n; ++bi) {
         const u64 tk = D3_TICK();

@@ -553,10 +553,15 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
     for (;;) {
       const u64 tk0 = D3_TICK();
       u32 dv[6];
+      dv[0] = (u32)__builtin_amdgcn_readfirstlane((int)s_desc[(it - 1) % 3][0]);
+      dv[2] = dv[3] = dv[4] = dv[5] = 0;
+      const bool clean = (dv[0] & D3_DESC_CLEAN) != 0;
+      if (!clean) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) dv[i] = s_desc[(it - 1) % 3][i];
+        for (int i = 2; i < 6; ++i) dv[i] = s_desc[(it - 1) % 3][i];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) dv[i] = (u32)__builtin_amdgcn_readfirstlane((int)dv[i]);
+        for (int i = 2; i < 6; ++i) dv[i] = (u32)__builtin_amdgcn_readfirstlane((int)dv[i]);
+      }
       const u32 sq = dv[0] & 255u, sn = (dv[0] >> 8) & 255u, sev = (dv[0] >> 16) & 255u;
       const bool last = ((dv[0] >> 24) & 1u) != 0;
       const u64 m_r1 = ((u64)dv[3] << 32) | dv[2], m_bad = ((u64)dv[5] << 32) | dv[4];
@@ -568,6 +573,32 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
         double* t1 = s_t1[(it - 1) & 1];
         double* t2 = s_t2[(it - 1) & 1];
         const char* ring0 = reinterpret_cast<const char*>(s_ring + DP_FRONT);
+        if (clean && D3_NB == 2) {
+          // a whole group of single-register positions: this wave's 16 positions of each window in
+          // one pass (32 rows in flight)
+          const u32 pa = 16u * my, pb = pa + 32u;
+          uint2 ta[16], tb[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) { ta[u] = s_tab[my][pa + u]; tb[u] = s_tab[my][pb + u]; }
+          double va[16], vb[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            va[u] = reinterpret_cast<const double*>(ring0 + (int)ta[u].x)[lane];        // row[x] = edge k = x - p
+            vb[u] = reinterpret_cast<const double*>(ring0 + (int)tb[u].x)[lane + 32u];
+          }
+          const u32 da = lane - pa - 1, db = lane + 32u - pb - 1;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            t1[(pa + u) * 64 + lane] = da - u < ta[u].y ? va[u] : kInf;
+            t1[(pb + u) * 64 + lane] = db - u < tb[u].y ? vb[u] : kInf;
+          }
+          const u64 tk1c = D3_TICK();
+          __syncthreads();
+          if (PROF) { tq[2] += tk1c - tk0; tq[3] += D3_TICK() - tk1c; }
+          ++it;
+          if (last) break;
+          continue;
+        }
         u32 blk = 0;
         for (u32 p0 = sq; p0 < sq + sn; p0 += 8) {
           if (!d3_fast(sq + sn, m_bad, p0)) continue;   // (a non-fast block is at most 8 positions: the walk realigns after it)

@@ -265,11 +265,8 @@ int zmx_deflate_range(zmx_ctx* ctx, const ZopfliOptions* options, size_t instart
   const auto ts0 = std::chrono::steady_clock::now();
   if (std::getenv("ZOPFLI_AMD_PROF"))
     std::fprintf(stderr, "zmx_deflate_range: RunParts %.1f ms\n", std::chrono::duration<double>(ts0 - tr0).count() * 1e3);
-  const std::vector<uint8_t> v = zamd::SerializeChunks(chunks, zmx_internal_input_host(ctx));
-  *blob = static_cast<unsigned char*>(std::malloc(v.size() ? v.size() : 1));
+  *blob = zamd::SerializeChunks(chunks, zmx_internal_input_host(ctx), blobsize);
   if (!*blob) return -1;
-  std::memcpy(*blob, v.data(), v.size());
-  *blobsize = v.size();
   zamd::ThreadTiming().serialize += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
   return 0;
 }

@@ -373,9 +373,6 @@ void MergeChunks(const std::vector<Chunk>& chunks, const unsigned char* in, unsi
 }
 
 namespace {
-void PutU64(std::vector<uint8_t>* v, uint64_t x) {
-  for (int i = 0; i < 8; ++i) v->push_back(static_cast<uint8_t>(x >> (8 * i)));
-}
 uint64_t GetU64(const unsigned char* p) {
   uint64_t x = 0;
   for (int i = 0; i < 8; ++i) x |= static_cast<uint64_t>(p[i]) << (8 * i);
@@ -386,23 +383,36 @@ uint64_t GetU64(const unsigned char* p) {
 // Blob layout: u64 count, then per chunk: u8 kind, u8 final, u64 a, u64 b and a
 // payload: bit chunks a = nbits, b = payload bytes; stored chunks a = 0,
 // b = payload bytes (the raw input bytes of the block).
-std::vector<uint8_t> SerializeChunks(const std::vector<Chunk>& chunks, const unsigned char* in) {
-  std::vector<uint8_t> blob;
-  PutU64(&blob, chunks.size());
-  for (const Chunk& c : chunks) {
-    blob.push_back(static_cast<uint8_t>(c.kind));
-    blob.push_back(c.final_block ? 1 : 0);
-    if (c.kind == Chunk::kBits) {
-      PutU64(&blob, c.nbits);
-      PutU64(&blob, c.BitBytes());
-      blob.insert(blob.end(), c.BitData(), c.BitData() + c.BitBytes());
-    } else {
-      PutU64(&blob, 0);
-      PutU64(&blob, c.end - c.start);
-      const unsigned char* src = c.view ? c.view : c.raw.empty() ? in + c.start : c.raw.data();
-      blob.insert(blob.end(), src, src + (c.end - c.start));
-    }
+unsigned char* SerializeChunks(const std::vector<Chunk>& chunks, const unsigned char* in, size_t* size) {
+  // every chunk's place follows from the payload sizes: headers serially, payloads in parallel
+  std::vector<size_t> off(chunks.size());
+  size_t total = 8;
+  for (size_t i = 0; i < chunks.size(); ++i) {
+    const Chunk& c = chunks[i];
+    off[i] = total;
+    total += 18 + (c.kind == Chunk::kBits ? c.BitBytes() : c.end - c.start);
   }
+  unsigned char* blob = static_cast<unsigned char*>(std::malloc(total ? total : 1));
+  if (!blob) return nullptr;
+  auto put64 = [](unsigned char* p, uint64_t x) { for (int k = 0; k < 8; ++k) p[k] = static_cast<uint8_t>(x >> (8 * k)); };
+  put64(blob, chunks.size());
+  ParallelFor(chunks.size(), [&](size_t i) {
+    const Chunk& c = chunks[i];
+    unsigned char* p = blob + off[i];
+    p[0] = static_cast<uint8_t>(c.kind);
+    p[1] = c.final_block ? 1 : 0;
+    if (c.kind == Chunk::kBits) {
+      put64(p + 2, c.nbits);
+      put64(p + 10, c.BitBytes());
+      std::memcpy(p + 18, c.BitData(), c.BitBytes());
+    } else {
+      put64(p + 2, 0);
+      put64(p + 10, c.end - c.start);
+      const unsigned char* src = c.view ? c.view : c.raw.empty() ? in + c.start : c.raw.data();
+      std::memcpy(p + 18, src, c.end - c.start);
+    }
+  });
+  *size = total;
   return blob;
 }
 

@@ -48,8 +48,9 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
 void MergeChunks(const std::vector<Chunk>& chunks, const unsigned char* in, unsigned char* bp,
                  unsigned char** out, size_t* outsize);
 
-// Stored chunks are serialised with their raw bytes (taken from `in`).
-std::vector<uint8_t> SerializeChunks(const std::vector<Chunk>& chunks, const unsigned char* in);
+// Stored chunks are serialised with their raw bytes (taken from `in`).  Returns a malloc'ed blob
+// (nullptr when out of memory).
+unsigned char* SerializeChunks(const std::vector<Chunk>& chunks, const unsigned char* in, size_t* size);
 // The chunks are views into `blob`.
 bool DeserializeChunks(const unsigned char* blob, size_t size, std::vector<Chunk>* chunks);
 

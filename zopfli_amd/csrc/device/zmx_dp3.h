@@ -46,12 +46,9 @@
     CS = (float)fmin(nc_, old_);                                             \
   }
 
-// Cells WB .. WB + 31 (lanes 0..31 of register 0) are final: write their lengths and move the
-// window of cell registers 32 cells on.
-#define D3_RETIRE32(WB)                                                      \
+// Move the window of cell registers 32 cells on.
+#define D3_ROT32()                                                           \
   {                                                                          \
-    const u32 jj_ = (WB) + lane;                                             \
-    if (lane < 32 && jj_ >= 1 && jj_ <= B) la[jj_] = (u16)(l[0] ? jj_ + 1 - l[0] : 0u); \
     if (reach < 64) {              /* only register 0 holds anything */      \
       c[0] = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(c[0]), __float_as_uint(1e30f), false, false)[1]); \
       l[0] = __builtin_amdgcn_permlane32_swap(l[0], 0u, false, false)[1];    \
@@ -59,6 +56,15 @@
       d3_rot32(c, l, lane);                                                  \
     }                                                                        \
     reach = reach >= 32 ? reach - 32 : 0;                                    \
+  }
+
+// Cells WB .. WB + 31 (lanes 0..31 of register 0) are final: write their lengths and move the
+// window on.
+#define D3_RETIRE32(WB)                                                      \
+  {                                                                          \
+    const u32 jj_ = (WB) + lane;                                             \
+    if (lane < 32 && jj_ >= 1 && jj_ <= B) la[jj_] = (u16)(l[0] ? jj_ + 1 - l[0] : 0u); \
+    D3_ROT32()                                                               \
   }
 
 #define D3_NB 2u         // tile-building waves (waves 2..); wave 0 = the chain, wave 1 = the walk and the ring
@@ -215,6 +221,9 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
   __shared__ uint2 s_tabc[3][64];   // {roff, kend} of the step's group
   __shared__ float s_xc[DP_XN];
   __shared__ u16 s_xl[DP_XN];
+  // "1 + source" of the 2 x 32 cells a clean step retires, per tile buffer: wave 1 turns them
+  // into length_array a step later (the chain wave only does one LDS write per window)
+  __shared__ u32 s_lout[2][128];
 
   const u32 tid = threadIdx.x;
   const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
       const u32 base = S.base;
       u32 p0 = S.q;
       u32 bi = 0;   // block index within the step
-      if (S.q == 0 && S.n == 64 && wo == 0 && (G.m_bad | G.m_r1) == 0) {
+      if (dv[0] & D3_DESC_CLEAN) {   // (q = 0: a new group, so wo = 0)
         // a whole group of single-register positions (the usual step): both windows' rows are
         // requested up front, the second window's arrive while the first one runs
         const u64 tk = D3_TICK();
@@ -296,8 +305,8 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
         }
         l[0] = lt ? base + lt : l[0];
         reach = reach > 63 ? reach : 63;
-        D3_RETIRE32(base)
-        wo = 32;
+        s_lout[it & 1][lane] = l[0];             // cells base .. base + 31 are final (lanes 0..31)
+        D3_ROT32()
         lt = 0;
 #pragma unroll
         for (int u = 0; u < 32; ++u) {
@@ -309,7 +318,8 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
         n_fast += 64;
         if (PROF) { tp[0] += D3_TICK() - tk; np[0] += 64; }
         // its event is D3_EV_GROUP_END (64 positions, none flagged): retire the second window
-        { D3_RETIRE32(base + 32) }
+        s_lout[it & 1][64 + lane] = l[0];        // cells base + 32 .. base + 63
+        D3_ROT32()
         wo = 0;
         if (PROF) { t_work += (u64)__builtin_readcyclecounter() - tw0; ++n_steps; }
         __syncthreads();
@@ -493,8 +503,19 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
     u32 a_prev = 0;          // a_cur of the step the chain wave works on during this iteration
     u32 it = 0, tail = 0;
     bool more = true;
+    // base and "clean" of the steps walked 1, 2, 3 iterations ago: the chain wave finished the
+    // oldest during the previous iteration and left its lengths in s_lout
+    u32 hb1 = 0, hb2 = 0, hb3 = 0;
+    bool hc1 = false, hc2 = false, hc3 = false;
+#define D3_STORE_LA()                                                        \
+    if (hc3) {                                                               \
+      const u32 v_ = s_lout[(it - 1) & 1][(lane >> 5) * 64 + (lane & 31)];   \
+      const u32 jj_ = hb3 + lane;                                            \
+      if (jj_ >= 1 && jj_ <= B) la[jj_] = (u16)(v_ ? jj_ + 1 - v_ : 0u);     \
+    }
     while (tail < 2) {       // two more barriers after the last step has been walked
       const u64 tk0 = D3_TICK();
+      D3_STORE_LA()
       // ---- the ring, for the step walked one iteration ago
       if (cur.event == D3_EV_PRIME) {
         const u32 a0 = cur.a_cur;
@@ -524,13 +545,15 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
       const u64 tk1 = D3_TICK();
       // ---- walk one step ahead and describe it
       cur.n = 0; cur.event = D3_EV_BUBBLE;
+      hb3 = hb2; hc3 = hc2; hb2 = hb1; hc2 = hc1; hc1 = false;
       if (more) {
         cur = d3_next(W, G, dbase, P.badpos + (bd.pos_off >> 5), (u32)(bd.pos_off & 31), B, lane);
         more = W.bubbles || W.base <= B;
         if (cur.n) s_tabc[it % 3][lane] = make_uint2(G.roff, G.kend);
+        const bool clean = cur.q == 0 && cur.n == 64 && (G.m_r1 | G.m_bad) == 0;
+        hb1 = cur.base; hc1 = clean;
         if (lane == 0) {
           u32* d = s_desc[it % 3];
-          const bool clean = cur.q == 0 && cur.n == 64 && (G.m_r1 | G.m_bad) == 0;
           d[0] = cur.q | (cur.n << 8) | (cur.event << 16) | ((more ? 0u : 1u) << 24) | (clean ? D3_DESC_CLEAN : 0u);
           d[1] = cur.base;
           d[2] = (u32)G.m_r1; d[3] = (u32)(G.m_r1 >> 32);
@@ -544,6 +567,8 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
       if (PROF) { tq[1] += tk1 - tk0; tq[0] += tk2 - tk1; tq[3] += D3_TICK() - tk2; }
       ++it;
     }
+    D3_STORE_LA()                                       // the last step
+#undef D3_STORE_LA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA in flight when the workgroup's LDS is released
   } else {
     // ================================================================= waves 2..: the tiles

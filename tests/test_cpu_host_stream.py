@@ -112,3 +112,94 @@ def test_master_block_chunks_merge(host):
     blobs = [ctx.deflate_range(opt, 0, 1000000, 0), ctx.deflate_range(opt, 1000000, len(data), 1)]
     assert ctx.merge(blobs) == whole
     ctx.close()
+
+
+def _blob(chunks):
+    """The chunk blob layout of zmx_deflate_range (deflate.cc): u64 count, then per chunk u8 kind,
+    u8 final, u64 a, u64 b, payload (bit chunks: a = nbits, b = payload bytes; stored: a = 0)."""
+    out = len(chunks).to_bytes(8, "little")
+    for kind, final, bits_or_raw in chunks:
+        if kind == 0:
+            bits = bits_or_raw
+            payload = bytearray((len(bits) + 7) // 8)
+            for i, b in enumerate(bits):
+                payload[i >> 3] |= b << (i & 7)
+            out += bytes([0, 0]) + len(bits).to_bytes(8, "little") + len(payload).to_bytes(8, "little") + bytes(payload)
+        else:
+            out += bytes([1, final]) + (0).to_bytes(8, "little") + len(bits_or_raw).to_bytes(8, "little") + bits_or_raw
+    return out
+
+
+def _merge_reference(chunks, prefix_bits):
+    """Bit-at-a-time model of AddBits / AddNonCompressedBlock (deflate.c:38-72, 625-665)."""
+    bits = list(prefix_bits)
+    for kind, final, payload in chunks:
+        if kind == 0:
+            bits += payload
+            continue
+        pos, n = 0, len(payload)
+        while True:
+            piece = min(65535, n - pos)
+            last = pos + piece >= n
+            bits += [1 if (final and last) else 0, 0, 0]
+            bits += [0] * (-len(bits) % 8)
+            for v in (piece & 255, piece >> 8, (~piece & 0xffff) & 255, (~piece & 0xffff) >> 8):
+                bits += [(v >> k) & 1 for k in range(8)]
+            for byte in payload[pos:pos + piece]:
+                bits += [(byte >> k) & 1 for k in range(8)]
+            if last:
+                break
+            pos += piece
+    out = bytearray((len(bits) + 7) // 8)
+    for i, b in enumerate(bits):
+        out[i >> 3] |= b << (i & 7)
+    return bytes(out), len(bits) & 7
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_chunks_merge_bit_offsets(host, seed):
+    """zmx_chunks_merge places every chunk by a prefix sum of bit lengths and shifts the chunks in
+    parallel: chunks shorter than a byte, chunks ending on byte boundaries, stored blocks after any
+    bit offset (incl. a header that straddles a byte) and multi-piece stored blocks."""
+    import ctypes
+    import random
+    rng = random.Random(seed)
+    chunks = []
+    for _ in range(rng.randint(1, 40)):
+        r = rng.random()
+        if r < 0.15:
+            n = rng.choice([0, 1, 5, 70000, 131070, 140000]) if seed % 2 else rng.choice([0, 1, 2, 300])
+            chunks.append((1, rng.randint(0, 1), bytes(rng.getrandbits(8) for _ in range(n))))
+        else:
+            n = rng.choice([0, 1, 2, 3, 5, 7, 8, 9, 15, 16, 17, 63, 64, 65, rng.randint(1, 3000)])
+            chunks.append((0, 0, [rng.getrandbits(1) for _ in range(n)]))
+    # split the chunk list over 1..3 blobs, as ranks would deliver it
+    cuts = sorted(rng.sample(range(len(chunks) + 1), min(2, len(chunks) + 1)))
+    parts = [chunks[:cuts[0]]] + [chunks[a:b] for a, b in zip(cuts, cuts[1:])] + [chunks[cuts[-1]:]]
+    blobs = [_blob(p) for p in parts]
+    for nprefix_bits in (0, 3, 8, 13):
+        prefix_bits = [rng.getrandbits(1) for _ in range(nprefix_bits)]
+        want, want_bp = _merge_reference(chunks, prefix_bits)
+        # seed (*out, *outsize, *bp) with the prefix, reference conventions
+        pre = bytearray((nprefix_bits + 7) // 8)
+        for i, b in enumerate(prefix_bits):
+            pre[i >> 3] |= b << (i & 7)
+        libc = ctypes.CDLL(None)
+        libc.malloc.restype = ctypes.c_void_p
+        libc.malloc.argtypes = [ctypes.c_size_t]
+        libc.free.argtypes = [ctypes.c_void_p]
+        cap = 1
+        while cap < len(pre):
+            cap <<= 1
+        addr = libc.malloc(cap) if pre else None
+        if pre:
+            ctypes.memmove(addr, bytes(pre), len(pre))
+        out = ctypes.cast(addr, ctypes.POINTER(ctypes.c_ubyte))
+        size, bp = ctypes.c_size_t(len(pre)), ctypes.c_ubyte(nprefix_bits & 7)
+        arr = (ctypes.c_void_p * len(blobs))(*[ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p).value for b in blobs])
+        sizes = (ctypes.c_size_t * len(blobs))(*[len(b) for b in blobs])
+        assert host.zmx_chunks_merge(arr, sizes, len(blobs), ctypes.byref(bp), ctypes.byref(out), ctypes.byref(size)) == 0
+        got = ctypes.string_at(out, size.value)
+        libc.free(ctypes.cast(out, ctypes.c_void_p))
+        assert bp.value == want_bp
+        assert got == want

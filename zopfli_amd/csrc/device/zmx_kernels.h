@@ -231,7 +231,8 @@ __global__ __launch_bounds__(64) void k_chain(const u8* __restrict__ in, const B
 #define MT 2048u
 #define MWIN_BYTES (32768u + MT + 288u)     // + slack for 16-byte alignment and 4-byte compares
 #define MATCH_THREADS 256
-#define SCRATCH_CPS 256u                     // per-lane overflow change points
+#define SCRATCH_CPS 256u
+#define MATCH_BATCH 8u                        // lanes that wait for a record write / a new position before the wave serves them                     // per-lane overflow change points
 
 struct MatchParams {
   const u8* in;
@@ -308,8 +309,39 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_match(MatchParams P) {
     ushort4 L = make_ushort4(0, 0, 0, 0);  // links of the candidate
     u32* rec = nullptr;
 
+    bool pending = false;          // the walk has ended, its record is not written yet
     for (;;) {
-      if (!active && !done) {
+      // Writing a record and fetching the next position are long, rarely needed code: a wave that
+      // ran them whenever one lane asked would execute them on almost every step with one or two
+      // lanes active.  Lanes queue up instead (MATCH_BATCH of them, or nobody left walking).
+      const u64 m_need = __ballot(pending || (!active && !done));
+      const bool service = m_need != 0 && ((u32)__popcll(m_need) >= MATCH_BATCH || !__any(active));
+      if (service && pending) {
+        pending = false;
+        rec[0] = bestlen | (bestdist << 16);
+        if (ncp <= 8) {
+          rec[1] = same_pos | (lds_byte(win, lp) << 16) | (ncp << 24);
+        } else {
+          rec[1] = same_pos | (lds_byte(win, lp) << 16) | (0xffu << 24);
+          const u32 off = atomicAdd(&P.counters[0], ncp);
+          if (off + ncp <= P.pool_cap) {
+            const u8* b = reinterpret_cast<const u8*>(rec) + 8;
+            u32 first[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) first[e] = ((u32)b[3 * e] + 3u) | (((u32)b[3 * e + 1] | ((u32)b[3 * e + 2] << 8)) << 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) P.pool[off + e] = first[e];
+            for (u32 e = 8; e < ncp; ++e) P.pool[off + e] = my_scratch[e];
+            rec[2] = off;
+            rec[3] = ncp;
+          } else {
+            atomicOr(&P.counters[1], 1u);  // host retries with a larger pool
+            rec[2] = 0;
+            rec[3] = 0;
+          }
+        }
+      }
+      if (service && !active && !done) {
         const u32 idx = atomicAdd(&s_next, 1u);
         if (idx >= ntile) {
           done = true;
@@ -402,28 +434,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_match(MatchParams P) {
             }
           }
           if (finish) {
-            rec[0] = bestlen | (bestdist << 16);
-            if (ncp <= 8) {
-              rec[1] = same_pos | (lds_byte(win, lp) << 16) | (ncp << 24);
-            } else {
-              rec[1] = same_pos | (lds_byte(win, lp) << 16) | (0xffu << 24);
-              const u32 off = atomicAdd(&P.counters[0], ncp);
-              if (off + ncp <= P.pool_cap) {
-                const u8* b = reinterpret_cast<const u8*>(rec) + 8;
-                u32 first[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) first[e] = ((u32)b[3 * e] + 3u) | (((u32)b[3 * e + 1] | ((u32)b[3 * e + 2] << 8)) << 16);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) P.pool[off + e] = first[e];
-                for (u32 e = 8; e < ncp; ++e) P.pool[off + e] = my_scratch[e];
-                rec[2] = off;
-                rec[3] = ncp;
-              } else {
-                atomicOr(&P.counters[1], 1u);  // host retries with a larger pool
-                rec[2] = 0;
-                rec[3] = 0;
-              }
-            }
+            pending = true;
             active = false;
           }
         }

@@ -163,6 +163,7 @@ def test_chunks_merge_bit_offsets(host, seed):
     bit offset (incl. a header that straddles a byte) and multi-piece stored blocks."""
     import ctypes
     import random
+    ctypes.CDLL(None).mallopt(-6, 0xA5)   # M_PERTURB: fresh malloc/realloc memory is not zero
     rng = random.Random(seed)
     chunks = []
     for _ in range(rng.randint(1, 40)):
@@ -203,3 +204,4 @@ def test_chunks_merge_bit_offsets(host, seed):
         libc.free(ctypes.cast(out, ctypes.c_void_p))
         assert bp.value == want_bp
         assert got == want
+    ctypes.CDLL(None).mallopt(-6, 0)

@@ -304,8 +304,34 @@ void MergeChunks(const std::vector<Chunk>& chunks, const unsigned char* in, unsi
     }
   }
   const size_t newsize = (cur + 7) / 8;
-  ReserveOutput(newsize - *outsize, outp, outsize);
+  const size_t keep = *outsize;   // bytes [0, keep) hold earlier output
+  ReserveOutput(newsize - *outsize, outp, outsize, /*zero=*/false);
   uint8_t* const out = *outp;
+  // Every new byte is either written whole by the chunk that owns it (below) or is one of the few
+  // bytes that are OR-ed together afterwards: only those are cleared (not the whole range).
+  auto clear = [&](size_t idx) { if (idx >= keep) out[idx] = 0; };
+  for (size_t i = 0; i < chunks.size(); ++i) {
+    const Chunk& c = chunks[i];
+    const size_t b0 = place[i].bit0;
+    if (c.kind == Chunk::kBits) {
+      if (c.nbits == 0) continue;
+      const size_t e = b0 + c.nbits;
+      if (e / 8 < (b0 + 7) / 8) { clear(b0 / 8); continue; }
+      if (b0 & 7) clear(b0 / 8);
+      if (e & 7) clear(e / 8);
+    } else {
+      size_t bit = b0, pos = c.start;
+      for (;;) {
+        size_t piece = 65535;
+        if (pos + piece > c.end) piece = c.end - pos;
+        clear(bit / 8);
+        clear((bit + 2) / 8);
+        bit = ((bit + 3 + 7) / 8 + 4 + piece) * 8;
+        if (pos + piece >= c.end) break;
+        pos += piece;
+      }
+    }
+  }
 
   ParallelFor(chunks.size(), [&](size_t i) {
     const Chunk& c = chunks[i];
@@ -448,7 +474,7 @@ bool DeserializeChunks(const unsigned char* blob, size_t size, std::vector<Chunk
   return off == size;
 }
 
-void ReserveOutput(size_t n, unsigned char** out, size_t* outsize) {
+void ReserveOutput(size_t n, unsigned char** out, size_t* outsize, bool zero) {
   if (n == 0) return;
   const size_t newsize = *outsize + n;
   size_t cap = 1;
@@ -463,7 +489,7 @@ void ReserveOutput(size_t n, unsigned char** out, size_t* outsize) {
     if (!p) std::exit(-1);  // the reference also exits on allocation failure
     *out = static_cast<unsigned char*>(p);
   }
-  std::memset(*out + *outsize, 0, n);
+  if (zero) std::memset(*out + *outsize, 0, n);
 }
 
 void AppendToOutput(const uint8_t* data, size_t n, unsigned char** out, size_t* outsize) {

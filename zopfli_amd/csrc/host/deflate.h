@@ -55,8 +55,8 @@ unsigned char* SerializeChunks(const std::vector<Chunk>& chunks, const unsigned 
 bool DeserializeChunks(const unsigned char* blob, size_t size, std::vector<Chunk>* chunks);
 
 // Makes room for `n` more bytes after *outsize (capacity rule of ZOPFLI_APPEND_DATA); the new
-// bytes are zero.  *outsize is not changed.
-void ReserveOutput(size_t n, unsigned char** out, size_t* outsize);
+// bytes are zeroed unless zero = false.  *outsize is not changed.
+void ReserveOutput(size_t n, unsigned char** out, size_t* outsize, bool zero = true);
 
 // Appends `n` bytes to a reference-style growable array (util.h:135-155).
 void AppendToOutput(const uint8_t* data, size_t n, unsigned char** out, size_t* outsize);

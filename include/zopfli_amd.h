@@ -106,6 +106,15 @@ int zmx_set_input(zmx_ctx* ctx, const unsigned char* in, size_t insize);
  * longest length, its distance and the sublen step function.  Replaces the
  * hash replay + longest-match cache (cache.c) of the reference. */
 int zmx_tables_build(zmx_ctx* ctx, const zmx_block* blocks, size_t nblocks, zmx_tables** tables);
+
+/* The same, for blocks that lie inside blocks of `parent` (both lists ascending), e.g. the deflate
+ * blocks a master block was split into (deflate.c:854-869) after the greedy pass over the master
+ * block (blocksplitter.c:296): ZopfliFindLongestMatch depends on the block only through its end
+ * (lz77.c:448-450, hash.c:107-108,121), so the parent's results are reused for every position but
+ * those near the new block ends.  `parent` stays valid for zmx_tables_free only.  parent = NULL
+ * is zmx_tables_build. */
+int zmx_tables_build_from(zmx_ctx* ctx, zmx_tables* parent, const zmx_block* blocks, size_t nblocks,
+                          zmx_tables** tables);
 void zmx_tables_free(zmx_ctx* ctx, zmx_tables* tables);
 
 /* ZopfliLZ77Greedy (lz77.c:544-630) on every block, into store slot `slot`

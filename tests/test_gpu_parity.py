@@ -64,6 +64,45 @@ def test_match_table(gpu_ctx, case):
         t.free()
 
 
+# (class, total size, parent blocks, sub-blocks)
+REUSE_CASES = [
+    ("T", 120000, [(0, 120000)], [(0, 50000), (50000, 50100), (50100, 120000)]),
+    ("Z", 200000, [(0, 100000), (100000, 200000)], [(0, 40001), (40001, 100000), (100000, 100300), (100300, 200000)]),
+    ("B", 60000, [(0, 60000)], [(0, 30000), (30000, 60000)]),          # hash switch + chain cap near the new end
+    ("M", 150000, [(0, 150000)], [(0, 3), (3, 5), (5, 5), (5, 70000), (70000, 150000)]),
+    ("P", 90000, [(20000, 90000)], [(20000, 55000), (55000, 90000)]),  # window before the parent's start
+]
+
+
+@pytest.mark.parametrize("case", REUSE_CASES, ids=lambda c: f"{c[0]}{c[1]}x{len(c[3])}")
+def test_match_table_reuse(gpu_ctx, case):
+    """zmx_tables_build_from (records copied from the enclosing blocks' tables, tiles near the new
+    block ends recomputed) == ZopfliFindLongestMatch at every position of every sub-block."""
+    cls, n, parents, blocks = case
+    data = generate(cls, n)
+    gpu_ctx.set_input(data)
+    pt = gpu_ctx.build_tables(parents)
+    t = gpu_ctx.build_tables(blocks, parent=pt)
+    pt.free()
+    try:
+        for b, (s, e) in enumerate(blocks):
+            o = ol.OracleTable(data, s, e)
+            bad = []
+            for pos in range(s, e):
+                gl, gd, gsub = t.find_longest_match(b, pos)
+                ol_, od, osub = o.find_longest_match(pos)
+                same = (gl == ol_ and gd == od) if ol_ >= 3 else (gl < 3 and ol_ < 3)
+                if same and ol_ >= 3:
+                    same = np.array_equal(gsub[3:ol_ + 1], osub[3:ol_ + 1])
+                if not same:
+                    bad.append((pos, (gl, gd), (ol_, od)))
+                    if len(bad) >= 5:
+                        break
+            assert not bad, f"block {b} [{s},{e}): first mismatches (pos, gpu, oracle) {bad}"
+    finally:
+        t.free()
+
+
 @pytest.mark.parametrize("case", TABLE_CASES, ids=_ids)
 def test_greedy(gpu_ctx, case):
     """k_greedy == ZopfliLZ77Greedy (lz77.c:544) + its histogram."""

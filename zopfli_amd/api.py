@@ -77,6 +77,7 @@ def bind(lib):
     lib.zmx_ctx_destroy.restype = None
     lib.zmx_set_input.argtypes = [vp, ctypes.c_char_p, sz]
     lib.zmx_tables_build.argtypes = [vp, P(ZmxBlock), sz, P(vp)]
+    lib.zmx_tables_build_from.argtypes = [vp, vp, P(ZmxBlock), sz, P(vp)]
     lib.zmx_tables_free.argtypes = [vp, vp]
     lib.zmx_tables_free.restype = None
     lib.zmx_lz77_greedy.argtypes = [vp, vp, ctypes.c_int, P(ctypes.c_uint32), P(ctypes.c_uint32)]
@@ -183,10 +184,15 @@ class Context:
         self._input = data
         self._check(self.lib.zmx_set_input(self.handle, data, len(data)), "zmx_set_input")
 
-    def build_tables(self, blocks):
+    def build_tables(self, blocks, parent=None):
+        """zmx_tables_build, or zmx_tables_build_from when `parent` (Tables over enclosing blocks) is given."""
         arr = (ZmxBlock * len(blocks))(*[ZmxBlock(s, e) for s, e in blocks])
         t = ctypes.c_void_p()
-        self._check(self.lib.zmx_tables_build(self.handle, arr, len(blocks), ctypes.byref(t)), "zmx_tables_build")
+        if parent is None:
+            self._check(self.lib.zmx_tables_build(self.handle, arr, len(blocks), ctypes.byref(t)), "zmx_tables_build")
+        else:
+            self._check(self.lib.zmx_tables_build_from(self.handle, parent.handle, arr, len(blocks), ctypes.byref(t)),
+                        "zmx_tables_build_from")
         return Tables(self, t, list(blocks))
 
     def deflate_range(self, options, instart, inend, final=1, as_array=False):

@@ -274,7 +274,13 @@ void zmx_tables_free(zmx_ctx* c, zmx_tables* t) {
   delete t;
 }
 
-static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_tables* t) {
+// `parent` (optional): a table set over blocks that contain the new ones.  The match record of a
+// position depends on its block only through the block end: limit = min(258, end -
+// pos), same[] truncated at the end, zero bytes in the hashes of the last two positions.  So the
+// records of a sub-block equal the parent's except where pos + 258 > end or pos lies in the run
+// of equal bytes that reaches the end — only the tiles holding such positions are recomputed,
+// everything else is copied.  Hash links (k_same, k_chain) are rebuilt: they are cheap.
+static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_tables* t, zmx_tables* parent = nullptr) {
   t->nb = nb;
   t->blocks.resize(nb);
   t->bsize.resize(nb);
@@ -306,6 +312,37 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   t->total_l = reg_off;
   t->tile_off = tile_off;
   if (nb == 0) return 0;
+
+  // ---- reuse of the parent's records
+  std::vector<u64> src_pos;
+  std::vector<u32> tile_list;
+  bool reuse = parent != nullptr && parent->nb > 0 && c->h_in != nullptr && parent->d_recs != nullptr &&
+               parent->total_b + pos_off < (3ull << 30);
+  if (reuse) {
+    src_pos.resize(nb);
+    size_t pb = 0;
+    for (size_t b = 0; b < nb && reuse; ++b) {
+      const BlockDesc& d = t->blocks[b];
+      while (pb < parent->nb && parent->blocks[pb].inend < d.inend) ++pb;   // both lists are ascending
+      if (pb == parent->nb || d.instart < parent->blocks[pb].instart || d.inend > parent->blocks[pb].inend) {
+        reuse = false;
+        break;
+      }
+      const BlockDesc& pd = parent->blocks[pb];
+      src_pos[b] = pd.pos_off + (d.instart - pd.instart);
+      const u64 B = d.inend - d.instart;
+      if (B == 0 || d.inend == pd.inend) continue;   // same end: every record is the same
+      // first position whose record may differ
+      u64 t0 = B > ZMX_MAX_MATCH ? d.inend - ZMX_MAX_MATCH : d.instart;
+      const unsigned char lastb = c->h_in[d.inend - 1];
+      u64 r = d.inend - 1;
+      while (r > d.instart && d.inend - r < 65600 && c->h_in[r - 1] == lastb) --r;
+      if (r < t0) t0 = r;
+      for (u32 tile = static_cast<u32>((t0 - d.instart) / MT); tile < tile_off[b + 1] - tile_off[b]; ++tile) {
+        tile_list.push_back(tile_off[b] + tile);
+      }
+    }
+  }
 
   HIPCHK(PoolAlloc(c, &t->d_blocks, nb));
   HIPCHK(PoolAlloc(c, &t->d_tile_off, nb + 1));
@@ -342,10 +379,66 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
 
   if (!c->d_scratch) HIPCHK(DevAlloc(&c->d_scratch, static_cast<size_t>(kMatchGrid) * MATCH_THREADS * SCRATCH_CPS));
 
+  if (reuse) {
+    // copy every record, adopt the parent's change-point pool (copied records point into it) and
+    // recompute the listed tiles; on pool overflow fall through to the full build
+    u64* d_src_pos = nullptr;
+    u32* d_tile_list = nullptr;
+    HIPCHK(PoolAlloc(c, &d_src_pos, nb));
+    HIPCHK(PoolAlloc(c, &d_tile_list, tile_list.size()));
+    HIPCHK(hipMemcpyAsync(d_src_pos, src_pos.data(), nb * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    if (!tile_list.empty()) {
+      HIPCHK(hipMemcpyAsync(d_tile_list, tile_list.data(), tile_list.size() * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+    }
+    CopyRecsParams cp;
+    cp.blocks = t->d_blocks;
+    cp.src_pos = d_src_pos;
+    cp.src = reinterpret_cast<const uint4*>(parent->d_recs);
+    cp.dst = reinterpret_cast<uint4*>(t->d_recs);
+    u64 max_b = 0;
+    for (size_t b = 0; b < nb; ++b) max_b = std::max<u64>(max_b, t->bsize[b]);
+    const unsigned gx = static_cast<unsigned>(std::min<u64>(std::max<u64>((max_b * 2 + 256 * 16 - 1) / (256 * 16), 1), 4096));
+    hipLaunchKernelGGL(k_copy_recs, dim3(gx, static_cast<unsigned>(nb)), dim3(256), 0, c->stream, cp);
+    HIPCHK(hipGetLastError());
+    // the pool cursor continues where the parent's stopped
+    HIPCHK(hipMemsetAsync(t->d_counters, 0, 16 * sizeof(u32), c->stream));
+    HIPCHK(hipMemcpyAsync(t->d_counters, parent->d_counters, sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+    MatchParams mp;
+    mp.in = c->d_in;
+    mp.blocks = t->d_blocks;
+    mp.tile_off = t->d_tile_off;
+    mp.nb = static_cast<u32>(nb);
+    mp.total_tiles = static_cast<u32>(tile_list.size());
+    mp.links = t->d_links;
+    mp.recs = t->d_recs;
+    mp.pool = parent->d_pool;
+    mp.pool_cap = parent->pool_cap;
+    mp.counters = t->d_counters;
+    mp.scratch = c->d_scratch;
+    mp.tile_list = d_tile_list;
+    if (mp.total_tiles > 0) {
+      hipLaunchKernelGGL(k_match, dim3(kMatchGrid), dim3(MATCH_THREADS), 0, c->stream, mp);
+      HIPCHK(hipGetLastError());
+    }
+    u32 counters[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(counters, t->d_counters, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    PoolFree(c, d_src_pos);
+    PoolFree(c, d_tile_list);
+    if ((counters[1] & 1u) == 0) {
+      t->d_pool = parent->d_pool;          // ownership moves: the parent must not be used for records again
+      t->pool_cap = parent->pool_cap;
+      parent->d_pool = nullptr;
+      parent->pool_cap = 0;
+    } else {
+      reuse = false;                       // pool overflow: build everything with a pool of our own
+    }
+  }
+
   // Change points beyond the 8 inline ones go to a pool; start with 4 entries per
   // position and grow on overflow (worst case 256 per position).
   u64 per_pos = 4;
-  for (;;) {
+  for (; !reuse;) {
     u64 cap = std::max<u64>(pos_off * per_pos, 1u << 16);
     if (cap > 0xfffffff0ull) cap = 0xfffffff0ull;
     PoolFree(c, t->d_pool);
@@ -365,6 +458,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     mp.pool_cap = t->pool_cap;
     mp.counters = t->d_counters;
     mp.scratch = c->d_scratch;
+    mp.tile_list = nullptr;
     if (mp.total_tiles > 0) {
       hipLaunchKernelGGL(k_match, dim3(kMatchGrid), dim3(MATCH_THREADS), 0, c->stream, mp);
       HIPCHK(hipGetLastError());
@@ -422,9 +516,13 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
 }
 
 int zmx_tables_build(zmx_ctx* c, const zmx_block* blocks, size_t nblocks, zmx_tables** out) {
+  return zmx_tables_build_from(c, nullptr, blocks, nblocks, out);
+}
+
+int zmx_tables_build_from(zmx_ctx* c, zmx_tables* parent, const zmx_block* blocks, size_t nblocks, zmx_tables** out) {
   HIPCHK(hipSetDevice(c->device));
   zmx_tables* t = new zmx_tables();
-  const int rc = BuildTables(c, blocks, nblocks, t);
+  const int rc = BuildTables(c, blocks, nblocks, t, parent);
   if (rc) {
     zmx_tables_free(c, t);
     return rc;

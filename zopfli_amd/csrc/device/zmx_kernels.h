@@ -246,6 +246,7 @@ struct MatchParams {
   u32 pool_cap;
   u32* counters;         // [0] pool cursor, [1] error flags, [8..15] per-XCD tile cursors
   u32* scratch;          // gridDim.x * MATCH_THREADS * SCRATCH_CPS
+  const u32* tile_list;  // optional: the tiles to do (total_tiles entries); null = all of them
 };
 
 __device__ __forceinline__ u32 lds_byte(const u32* w, u32 a) { return (w[a >> 2] >> ((a & 3) * 8)) & 255u; }
@@ -271,8 +272,8 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_match(MatchParams P) {
       s_next = 0;
     }
     __syncthreads();
-    const u32 tile = s_tile;
-    if (tile >= t_end) break;
+    if (s_tile >= t_end) break;
+    const u32 tile = P.tile_list ? P.tile_list[s_tile] : s_tile;
 
     // block of this tile: largest b with tile_off[b] <= tile
     u32 lo = 0, hi = P.nb;
@@ -441,6 +442,23 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_match(MatchParams P) {
       }
     }
   }
+}
+
+// Match records of a block that lies inside a block of an earlier table: the records of all
+// positions but the last few (see BuildTablesFrom) are the same — copy them.
+struct CopyRecsParams {
+  const BlockDesc* blocks;   // the new blocks
+  const u64* src_pos;        // [nb] record index in `src` of each block's first position
+  const uint4* src;
+  uint4* dst;
+};
+
+__global__ __launch_bounds__(256) void k_copy_recs(CopyRecsParams P) {
+  const BlockDesc bd = P.blocks[blockIdx.y];
+  const u64 n = (u64)(bd.inend - bd.instart) * 2;   // uint4 per record: 2
+  const uint4* src = P.src + P.src_pos[blockIdx.y] * 2;
+  uint4* dst = P.dst + bd.pos_off * 2;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) dst[i] = src[i];
 }
 
 // ----------------------------------------------------------------------------

@@ -91,11 +91,12 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
   // ---- 1. first block split on a greedy parse of each part (deflate.c:845-850,
   //         blocksplitter.c:275)
   std::vector<std::vector<size_t>> split_bytes(np);
+  zmx_tables* split_tables = nullptr;   // the master blocks' match tables, reused for their deflate blocks
   if (options.blocksplitting) {
     std::vector<zmx_block> ranges(np);
     for (size_t p = 0; p < np; ++p) ranges[p] = {parts[p].instart, parts[p].inend};
     std::vector<SymbolRun> greedy;
-    rc = Lz77GreedyBatch(ctx, ranges, &greedy);
+    rc = Lz77GreedyBatch(ctx, ranges, &greedy, &split_tables);
     if (rc) return rc;
     const double t0 = Now();
     ParallelFor(np, [&](size_t p) {
@@ -122,7 +123,7 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
   static const bool trace_phases = std::getenv("ZOPFLI_AMD_PROF") != nullptr;
   const double tp0 = Now();
   std::vector<SymbolRun> runs;
-  rc = Lz77OptimalBatch(ctx, options, all_blocks, &runs);
+  rc = Lz77OptimalBatch(ctx, options, all_blocks, &runs, split_tables);
   if (rc) return rc;
   const double tp1 = Now();
 

@@ -131,9 +131,11 @@ Timing& ThreadTiming() {
   return t;
 }
 
-int Lz77GreedyBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks, std::vector<SymbolRun>* out) {
+int Lz77GreedyBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks, std::vector<SymbolRun>* out,
+                    zmx_tables** keep) {
   const size_t nb = blocks.size();
   out->assign(nb, SymbolRun());
+  if (keep) *keep = nullptr;
   if (nb == 0) return 0;
   zmx_tables* t = nullptr;
   double t0 = Now();
@@ -145,18 +147,23 @@ int Lz77GreedyBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks, std::vec
   rc = zmx_lz77_greedy(ctx, t, 0, nsym.data(), hist.data());
   if (!rc) rc = DownloadAll(ctx, t, std::vector<int32_t>(nb, 0), nsym, out);
   ThreadTiming().greedy += Now() - t1;
-  zmx_tables_free(ctx, t);
+  if (keep && !rc) *keep = t;
+  else zmx_tables_free(ctx, t);
   return rc;
 }
 
 int Lz77OptimalBatch(zmx_ctx* ctx, const ZopfliOptions& options, const std::vector<zmx_block>& blocks,
-                     std::vector<SymbolRun>* out) {
+                     std::vector<SymbolRun>* out, zmx_tables* parent) {
   const size_t nb = blocks.size();
   out->assign(nb, SymbolRun());
-  if (nb == 0) return 0;
+  if (nb == 0) {
+    if (parent) zmx_tables_free(ctx, parent);
+    return 0;
+  }
   zmx_tables* t = nullptr;
   double t0 = Now();
-  int rc = zmx_tables_build(ctx, blocks.data(), nb, &t);
+  int rc = zmx_tables_build_from(ctx, parent, blocks.data(), nb, &t);
+  if (parent) zmx_tables_free(ctx, parent);
   if (rc) return rc;
   double t1 = Now();
   ThreadTiming().tables += t1 - t0;

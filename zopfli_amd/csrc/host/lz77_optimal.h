@@ -24,13 +24,16 @@ struct Timing {
 };
 Timing& ThreadTiming();
 
-// ZopfliLZ77Greedy (lz77.c:544) for each block.
-int Lz77GreedyBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks, std::vector<SymbolRun>* out);
+// ZopfliLZ77Greedy (lz77.c:544) for each block.  With `keep`, the device tables of the blocks are
+// handed to the caller (to be passed to Lz77OptimalBatch or freed with zmx_tables_free).
+int Lz77GreedyBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks, std::vector<SymbolRun>* out,
+                    zmx_tables** keep = nullptr);
 
 // ZopfliLZ77Optimal (squeeze.c:446) for each block: best of `numiterations`
-// cost-model iterations seeded by a greedy parse.
+// cost-model iterations seeded by a greedy parse.  `parent` (optional, consumed): tables of blocks
+// that contain these ones — their match records are reused (zmx_tables_build_from).
 int Lz77OptimalBatch(zmx_ctx* ctx, const ZopfliOptions& options, const std::vector<zmx_block>& blocks,
-                     std::vector<SymbolRun>* out);
+                     std::vector<SymbolRun>* out, zmx_tables* parent = nullptr);
 
 // ZopfliLZ77OptimalFixed (squeeze.c:528): one DP run with the fixed-tree costs.
 int Lz77OptimalFixedBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks,

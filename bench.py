@@ -84,6 +84,11 @@ def main():
             dist.init_process_group(args.backend)
             device = torch.device("cpu")   # payload tensors of the gather live where the backend can reach them
 
+    # one process per GPU shares the host cores: the library's worker pool (<= 64 threads, read once
+    # when it starts) is sized so that the ranks of this node do not oversubscribe them
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if local_world > 1 and "ZOPFLI_AMD_THREADS" not in os.environ:
+        os.environ["ZOPFLI_AMD_THREADS"] = str(max(8, min(64, (os.cpu_count() or 64) // local_world)))
     lib = api.library()
     options = ZopfliOptions(args.numiterations, args.blocksplitting, 15)
     size = args.size

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "zmx_kernels.h"
+#include "zmx_match2.h"
 #include "zmx_dp3.h"
 #include "zmx_sq.h"
 #include "zmx_trace.h"
@@ -280,6 +281,13 @@ void zmx_tables_free(zmx_ctx* c, zmx_tables* t) {
 // records of a sub-block equal the parent's except where pos + 258 > end or pos lies in the run
 // of equal bytes that reaches the end — only the tiles holding such positions are recomputed,
 // everything else is copied.  Hash links (k_same, k_chain) are rebuilt: they are cheap.
+// ZOPFLI_AMD_MATCH=1 selects k_match, the first version of the match kernel (A/B reference).
+using MatchKernelFn = void (*)(MatchParams);
+static MatchKernelFn MatchKernel() {
+  static const bool old_kernel = [] { const char* e = std::getenv("ZOPFLI_AMD_MATCH"); return e && std::atoi(e) == 1; }();
+  return old_kernel ? k_match : k_match2;
+}
+
 static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_tables* t, zmx_tables* parent = nullptr) {
   t->nb = nb;
   t->blocks.resize(nb);
@@ -417,7 +425,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     mp.scratch = c->d_scratch;
     mp.tile_list = d_tile_list;
     if (mp.total_tiles > 0) {
-      hipLaunchKernelGGL(k_match, dim3(kMatchGrid), dim3(MATCH_THREADS), 0, c->stream, mp);
+      hipLaunchKernelGGL(MatchKernel(), dim3(kMatchGrid), dim3(MATCH_THREADS), 0, c->stream, mp);
       HIPCHK(hipGetLastError());
     }
     u32 counters[2] = {0, 0};
@@ -460,7 +468,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     mp.scratch = c->d_scratch;
     mp.tile_list = nullptr;
     if (mp.total_tiles > 0) {
-      hipLaunchKernelGGL(k_match, dim3(kMatchGrid), dim3(MATCH_THREADS), 0, c->stream, mp);
+      hipLaunchKernelGGL(MatchKernel(), dim3(kMatchGrid), dim3(MATCH_THREADS), 0, c->stream, mp);
       HIPCHK(hipGetLastError());
     }
     u32 counters[2] = {0, 0};

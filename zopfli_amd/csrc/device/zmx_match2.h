@@ -1,0 +1,214 @@
+// k_match2: the match table kernel (ZopfliFindLongestMatch(limit 258, sublen) for every position,
+// lz77.c:407-542) with the hot loop written for the VALU issue rate.  Included only by zmx_hip.hip,
+// after zmx_kernels.h (same MatchParams, window staging and record format as k_match).
+//
+// k_match is VALU-bound (78 % of the issue rate, profiles/r01_v7) on a per-lane state machine whose
+// compiled form spends most of its instructions on copies between divergent branches.  Here a step
+// of the wave is straight-line code for the common case — the candidate fails the one-byte test
+// (lz77.c:478-479) and the lane moves down its chain: one LDS byte, the hash-switch test
+// (:509-519), one 8-byte link load — with the rare cases (byte compare :297, a new change point
+// :495-505, writing the record, fetching the next position) as skipped-when-empty side blocks.
+#pragma once
+
+#define M2_IDLE 0u      // needs a position
+#define M2_WALK 1u      // at a candidate, not compared yet
+#define M2_CMP 2u       // comparing bytes with the candidate
+#define M2_PEND 3u      // walk ended, record not written yet
+#define M2_DONE 4u      // the tile has no more positions
+
+__global__ __launch_bounds__(MATCH_THREADS) void k_match2(MatchParams P) {
+  __shared__ __align__(16) u32 win[MWIN_BYTES / 4 + 4];
+  __shared__ u32 s_next, s_tile;
+
+  const u32 tid = threadIdx.x;
+  const u32 xcd = blockIdx.x & 7;
+  const u32 t_begin = (u32)(((u64)P.total_tiles * xcd) / 8);
+  const u32 t_end = (u32)(((u64)P.total_tiles * (xcd + 1)) / 8);
+  u32* my_scratch = P.scratch + ((u64)blockIdx.x * MATCH_THREADS + tid) * SCRATCH_CPS;
+
+  for (;;) {
+    __syncthreads();  // previous tile fully consumed before the window is overwritten
+    if (tid == 0) {
+      s_tile = t_begin + atomicAdd(&P.counters[8 + xcd], 1u);
+      s_next = 0;
+    }
+    __syncthreads();
+    if (s_tile >= t_end) break;
+    const u32 tile = P.tile_list ? P.tile_list[s_tile] : s_tile;
+
+    // block of this tile: largest b with tile_off[b] <= tile
+    u32 lo = 0, hi = P.nb;
+    while (hi - lo > 1) {
+      const u32 mid = (lo + hi) >> 1;
+      if (P.tile_off[mid] <= tile) lo = mid; else hi = mid;
+    }
+    const BlockDesc bd = P.blocks[lo];
+    const u64 p0 = bd.instart + (u64)(tile - P.tile_off[lo]) * MT;
+    const u64 p1 = (p0 + MT < bd.inend) ? p0 + MT : bd.inend;
+    const u32 ntile = (u32)(p1 - p0);
+
+    // stage bytes [p0 - 32768, p1 + 258) (clipped to [0, inend)) at LDS offset (abs - wb)
+    const long long wb = ((long long)p0 - (long long)ZMX_WINDOW) & ~15ll;  // 16-byte aligned base, may be < 0
+    const u64 hi_abs = (p1 + ZMX_MAX_MATCH < bd.inend) ? p1 + ZMX_MAX_MATCH : bd.inend;
+    const u32 nvec = (u32)(((long long)hi_abs - wb + 15) >> 4);
+    for (u32 v = tid; v < nvec; v += MATCH_THREADS) {
+      const long long a = wb + (long long)v * 16;
+      uint4 x = make_uint4(0, 0, 0, 0);
+      if (a >= 0) x = *reinterpret_cast<const uint4*>(P.in + a);  // input is padded past its end
+      reinterpret_cast<uint4*>(win)[v] = x;
+    }
+    __syncthreads();
+
+    const uint2* lk = reinterpret_cast<const uint2*>(P.links + bd.reg_off);  // index: abs - ws; {prev1 | prev2 << 16, same | ..}
+    const u32 li0 = (u32)(p0 - bd.ws);            // link index of the tile's first position
+    const u32 lp0 = (u32)((long long)p0 - wb);    // its LDS byte offset
+    const u32 rem0 = (u32)((bd.inend - p0 < 70000) ? bd.inend - p0 : 70000);   // bytes to the block end, saturated
+    u32* const rec0 = P.recs + (bd.pos_off + (p0 - bd.instart)) * 8;
+
+    // ---- per-lane walk state (all 32-bit)
+    u32 st = M2_IDLE;
+    u32 lp = 0, lc = 0;            // LDS byte offsets of the position and of the candidate
+    u32 li = 0;                    // link index of the position
+    u32 limit = 0, bestlen = 0, bestdist = 0, dist = 0, ncp = 0, same_pos = 0, cur = 0, size_rem = 0;
+    u32 byte0 = 0, pbyte = 0;      // in[pos], in[pos + bestlen]
+    u32 hits_left = 0, chain = 1;
+    uint2 L = make_uint2(0, 0);    // link record of the candidate
+    u32* rec = rec0;
+
+    for (;;) {
+      // ---- service: record writes and refills, queued (MATCH_BATCH lanes, or nobody left walking)
+      const u64 m_need = __ballot(st == M2_PEND || st == M2_IDLE);
+      const u64 m_run = __ballot(st == M2_WALK || st == M2_CMP);
+      if (m_need != 0 && ((u32)__popcll(m_need) >= MATCH_BATCH || m_run == 0)) {
+        if (st == M2_PEND) {
+          st = M2_IDLE;
+          rec[0] = bestlen | (bestdist << 16);
+          if (ncp <= 8) {
+            rec[1] = same_pos | (byte0 << 16) | (ncp << 24);
+          } else {
+            rec[1] = same_pos | (byte0 << 16) | (0xffu << 24);
+            const u32 off = atomicAdd(&P.counters[0], ncp);
+            if (off + ncp <= P.pool_cap) {
+              const u8* b = reinterpret_cast<const u8*>(rec) + 8;
+              u32 first[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) first[e] = ((u32)b[3 * e] + 3u) | (((u32)b[3 * e + 1] | ((u32)b[3 * e + 2] << 8)) << 16);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) P.pool[off + e] = first[e];
+              for (u32 e = 8; e < ncp; ++e) P.pool[off + e] = my_scratch[e];
+              rec[2] = off;
+              rec[3] = ncp;
+            } else {
+              atomicOr(&P.counters[1], 1u);  // host retries with a larger pool
+              rec[2] = 0;
+              rec[3] = 0;
+            }
+          }
+        }
+        if (st == M2_IDLE) {
+          const u32 idx = atomicAdd(&s_next, 1u);
+          if (idx >= ntile) {
+            st = M2_DONE;
+          } else {
+            lp = lp0 + idx;
+            li = li0 + idx;
+            size_rem = rem0 - idx;               // saturated: only compared with 3 and 258
+            rec = rec0 + (u64)idx * 8;
+            const uint2 Lp = lk[li];
+            same_pos = Lp.y & 0xffffu;
+            byte0 = lds_byte(win, lp);
+            ncp = 0;
+            bestlen = 1; bestdist = 0; chain = 1; hits_left = ZMX_MAX_CHAIN_HITS;
+            if (size_rem < 3) {                      // lz77.c:440-446
+              rec[0] = 0;
+              rec[1] = same_pos | (byte0 << 16);
+            } else {
+              limit = size_rem < ZMX_MAX_MATCH ? size_rem : ZMX_MAX_MATCH;  // lz77.c:448-450
+              dist = Lp.x & 0xffffu;
+              if (dist == 0) {                       // empty chain
+                rec[0] = 1;
+                rec[1] = same_pos | (byte0 << 16);
+              } else {
+                lc = lp - dist;
+                L = lk[li - dist];
+                pbyte = lds_byte(win, lp + 1);
+                st = M2_WALK;
+              }
+            }
+          }
+        }
+        continue;   // states changed: take the ballots again
+      }
+      if (m_run == 0) {
+        if (m_need == 0) break;                      // every lane is done
+        continue;
+      }
+
+      // ---- the candidate's one-byte test (lz77.c:478-479)
+      const bool walk = st == M2_WALK;
+      const u32 cb = lds_byte(win, walk ? lc + bestlen : 0u);
+      const bool pass = walk && (bestlen >= size_rem || cb == pbyte);
+      bool ev = walk && !pass;                       // rejected: nothing to record, move on
+      if (pass) {
+        // lz77.c:481-490: skip the common run (pure acceleration)
+        cur = 0;
+        if (same_pos > 2 && lds_byte(win, lc) == byte0) {
+          const u32 lz = L.y & 0xffffu;
+          const u32 s = same_pos < lz ? same_pos : lz;
+          cur = s < limit ? s : limit;
+        }
+        st = M2_CMP;
+      }
+      bool fin = false;
+      if (st == M2_CMP) {  // GetMatch (lz77.c:297), 4 bytes per step
+        const u32 rem = limit - cur;
+        bool end = rem == 0;
+        if (!end) {
+          const u32 x = lds_u32_unaligned(win, lp + cur) ^ lds_u32_unaligned(win, lc + cur);
+          u32 m = x ? (u32)(__ffs((int)x) - 1) >> 3 : 4u;
+          if (m > rem) m = rem;
+          cur += m;
+          end = m < 4 || cur >= limit;
+        }
+        if (end) {
+          ev = true;
+          st = M2_WALK;
+          if (cur > bestlen) {  // lz77.c:495-505: new change point of sublen
+            // (a 2-byte "match" only moves bestlength; sublen[2] is never read)
+            if (cur >= 3) {
+              if (ncp < 8) {
+                u8* b = reinterpret_cast<u8*>(rec) + 8 + 3 * ncp;
+                b[0] = (u8)(cur - 3);
+                b[1] = (u8)(dist & 255);
+                b[2] = (u8)(dist >> 8);
+              } else if (ncp < SCRATCH_CPS) {
+                my_scratch[ncp] = cur | (dist << 16);
+              }
+              ++ncp;
+            }
+            bestlen = cur;
+            bestdist = dist;
+            fin = cur >= limit;
+            if (cur < size_rem) pbyte = lds_byte(win, lp + cur);
+          }
+        }
+      }
+      if (ev) {
+        if (!fin) {
+          // lz77.c:509-519: switch to the run-length hash; on chain 1 the 3-byte
+          // hashes are equal, so val2 equality is equality of ((same-3)&255)
+          const u32 lz = L.y & 0xffffu;
+          if (chain == 1 && bestlen >= same_pos && ((lz - 3u) & 255u) == ((same_pos - 3u) & 255u)) chain = 2;
+          const u32 step = chain == 1 ? (L.x & 0xffffu) : (L.x >> 16);
+          lc -= step;
+          dist += step;
+          --hits_left;
+          // lz77.c:521-523 (end of chain), :464 (window), :527-530 (hit cap)
+          fin = step == 0 || dist >= ZMX_WINDOW || hits_left == 0;
+          if (!fin) L = lk[li - dist];
+        }
+        if (fin) st = M2_PEND;
+      }
+    }
+  }
+}

@@ -287,6 +287,7 @@ static MatchKernelFn MatchKernel() {
   static const bool old_kernel = [] { const char* e = std::getenv("ZOPFLI_AMD_MATCH"); return e && std::atoi(e) == 1; }();
   return old_kernel ? k_match : k_match2;
 }
+static unsigned MatchThreads() { return MatchKernel() == k_match ? MATCH_THREADS : M2_THREADS; }
 
 static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_tables* t, zmx_tables* parent = nullptr) {
   t->nb = nb;
@@ -385,7 +386,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     HIPCHK(hipGetLastError());
   }
 
-  if (!c->d_scratch) HIPCHK(DevAlloc(&c->d_scratch, static_cast<size_t>(kMatchGrid) * MATCH_THREADS * SCRATCH_CPS));
+  if (!c->d_scratch) HIPCHK(DevAlloc(&c->d_scratch, static_cast<size_t>(kMatchGrid) * M2_THREADS * SCRATCH_CPS));
 
   if (reuse) {
     // copy every record, adopt the parent's change-point pool (copied records point into it) and
@@ -425,7 +426,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     mp.scratch = c->d_scratch;
     mp.tile_list = d_tile_list;
     if (mp.total_tiles > 0) {
-      hipLaunchKernelGGL(MatchKernel(), dim3(kMatchGrid), dim3(MATCH_THREADS), 0, c->stream, mp);
+      hipLaunchKernelGGL(MatchKernel(), dim3(kMatchGrid), dim3(MatchThreads()), 0, c->stream, mp);
       HIPCHK(hipGetLastError());
     }
     u32 counters[2] = {0, 0};
@@ -468,7 +469,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     mp.scratch = c->d_scratch;
     mp.tile_list = nullptr;
     if (mp.total_tiles > 0) {
-      hipLaunchKernelGGL(MatchKernel(), dim3(kMatchGrid), dim3(MATCH_THREADS), 0, c->stream, mp);
+      hipLaunchKernelGGL(MatchKernel(), dim3(kMatchGrid), dim3(MatchThreads()), 0, c->stream, mp);
       HIPCHK(hipGetLastError());
     }
     u32 counters[2] = {0, 0};

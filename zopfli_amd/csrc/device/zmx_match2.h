@@ -10,13 +10,14 @@
 // :495-505, writing the record, fetching the next position) as skipped-when-empty side blocks.
 #pragma once
 
+#define M2_THREADS 512   // 8 waves share one staged window: twice k_match's waves per CU for the same LDS
 #define M2_IDLE 0u      // needs a position
 #define M2_WALK 1u      // at a candidate, not compared yet
 #define M2_CMP 2u       // comparing bytes with the candidate
 #define M2_PEND 3u      // walk ended, record not written yet
 #define M2_DONE 4u      // the tile has no more positions
 
-__global__ __launch_bounds__(MATCH_THREADS) void k_match2(MatchParams P) {
+__global__ __launch_bounds__(M2_THREADS) void k_match2(MatchParams P) {
   __shared__ __align__(16) u32 win[MWIN_BYTES / 4 + 4];
   __shared__ u32 s_next, s_tile;
 
@@ -24,7 +25,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_match2(MatchParams P) {
   const u32 xcd = blockIdx.x & 7;
   const u32 t_begin = (u32)(((u64)P.total_tiles * xcd) / 8);
   const u32 t_end = (u32)(((u64)P.total_tiles * (xcd + 1)) / 8);
-  u32* my_scratch = P.scratch + ((u64)blockIdx.x * MATCH_THREADS + tid) * SCRATCH_CPS;
+  u32* my_scratch = P.scratch + ((u64)blockIdx.x * M2_THREADS + tid) * SCRATCH_CPS;
 
   for (;;) {
     __syncthreads();  // previous tile fully consumed before the window is overwritten
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void k_match2(MatchParams P) {
     const long long wb = ((long long)p0 - (long long)ZMX_WINDOW) & ~15ll;  // 16-byte aligned base, may be < 0
     const u64 hi_abs = (p1 + ZMX_MAX_MATCH < bd.inend) ? p1 + ZMX_MAX_MATCH : bd.inend;
     const u32 nvec = (u32)(((long long)hi_abs - wb + 15) >> 4);
-    for (u32 v = tid; v < nvec; v += MATCH_THREADS) {
+    for (u32 v = tid; v < nvec; v += M2_THREADS) {
       const long long a = wb + (long long)v * 16;
       uint4 x = make_uint4(0, 0, 0, 0);
       if (a >= 0) x = *reinterpret_cast<const uint4*>(P.in + a);  // input is padded past its end

@@ -1,23 +1,28 @@
-// k_dp3: the DP chain of k_dp with its row fetching / masking moved to three producer
-// waves of the same workgroup.  Included only by zmx_hip.hip, after zmx_kernels.h.
+// k_dp3: GetBestLengths (squeeze.c:217-309) of one LZ77OptimalRun — the serial DP chain, one
+// workgroup of four waves (one per SIMD) per block.  Included only by zmx_hip.hip, after
+// zmx_kernels.h.  DESIGN.md section 4 has the reasoning and the measurements.
 //
-// A lone wave issues about one instruction per 4.3 cycles; in k_dp 8 of the ~26
-// instructions per position (and both LDS round trips) only fetch and mask row values.
-// Here every wave of the workgroup walks the SAME deterministic sequence of steps — a step
-// is a run of positions of one 64-position group whose edge rows span at most D3_SPAN ring
-// slots; where it ends (span, group end, long-run shortcut, block end) depends only on
-// dph[], never on DP values — so no wave has to tell another where it is:
+// A lone wave issues about one VALU instruction per 5.8 cycles and the chain is a million dependent
+// positions per 1 MB block, so everything that is not the chain runs somewhere else.  The block
+// is cut into STEPS — runs of positions of one 64-position group whose edge rows span at most
+// D3_SPAN ring slots; where a step ends (span, group end, long-run shortcut, block end) depends
+// only on dph[], never on DP values — and the waves work on consecutive steps like a pipeline,
+// with one s_barrier per step as the only synchronisation:
 //
-//   wave 0 (consumer)   runs one step behind: reads ready-made 64-lane rows (+inf outside the
-//                       row) of a step from an LDS tile and runs the chain; positions that
-//                       need more than two cell registers, ragged tails and shortcuts use
-//                       k_dp's generic path straight from the ring.
-//   waves 1..3          build the tile of the step (8-position blocks round-robin); wave 1
-//                       also keeps the LDS row ring filled by LDS-DMA.
-//   one s_barrier per step; tiles are double buffered.
+//   wave 1 (the walk and the ring)   walks step i: reads dph[] and k_edges' bad-edge bitmap,
+//                       publishes a 6-word descriptor and the group's {row offset, kend}; keeps the
+//                       32 KB LDS row ring filled by LDS-DMA for step i - 1; turns the lengths the
+//                       chain wave left in LDS for step i - 3 into length_array.
+//   waves 2..3 (tiles)  build the tile of step i - 1: ready-made 64-lane rows (+inf outside the
+//                       row, lane = cell of the 32-cell window) in a double-buffered LDS tile.
+//   wave 0 (the chain)  runs step i - 2: cells in registers (lane l owns cells w + 64 s + l of a
+//                       window that moves 32 cells at a time), 8 VALU instructions per position on
+//                       the usual path; positions that need more than two cell registers, flagged
+//                       or bad-edge positions, ragged tails and shortcuts use k_dp's generic path
+//                       straight from the ring.
 //
-// After a shortcut (and at the start) the ring restarts at a new place: the walk inserts
-// two bubble steps so that nobody reads the ring while wave 1 primes it.
+// After a shortcut (and at the start) the ring restarts at a new place: the walk inserts two
+// bubble steps so that nobody reads the ring while wave 1 primes it.
 #pragma once
 
 // On a fast block the mincost test of squeeze.c:293 is provably a no-op: the producers verify

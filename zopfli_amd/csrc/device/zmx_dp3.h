@@ -25,11 +25,12 @@
 // bubble steps so that nobody reads the ring while wave 1 primes it.
 #pragma once
 
-// On a fast block the mincost test of squeeze.c:293 is provably a no-op: the producers verify
-// that every match edge of the block costs at least mincost (w >= mincost); rounding is monotone,
+// On the fast paths the mincost test of squeeze.c:293 is provably a no-op: k_edges verifies that
+// every match edge of the position costs at least mincost (w >= mincost); rounding is monotone,
 // so fl(w + cj) >= fl(mincost + cj), hence "newCost < costs[j+k]" already implies
-// "costs[j+k] > mincostaddcostj".  A block with an edge below mincost (possible only through
-// rounding in the cost model) is flagged and takes the generic path, which tests literally.
+// "costs[j+k] > mincostaddcostj".  A position with an edge below mincost (possible only through
+// rounding in the cost model) is reported in k_edges' bitmap and takes the generic path, which
+// tests literally.  (This form, with the source position in a register, is used by k_sq only.)
 #define D3_RELAX(CS, LS, WV)                                                 \
   {                                                                          \
     const double old_ = (double)(CS);                                        \

@@ -143,7 +143,8 @@ __global__ __launch_bounds__(256) void k_same(const u8* __restrict__ in, const B
 //      bit equals mine" — so a lane's previous occurrence is the nearest lower lane of
 //      its key group, else the old head; the last lane of each group writes the head.
 //      Positions older than 32767 are unreachable (hash.c:110-114 + window aliasing),
-//      so every chunk warms up from 32768 positions before its first emitted position.
+//      so every chunk warms up from 32768 positions before its first emitted position;
+//      warm-up steps only settle the heads (write, read back, the overwritten retry).
 // ----------------------------------------------------------------------------
 #define CH_EMIT 32768u
 #define CH_TILE 1024u
@@ -190,6 +191,21 @@ __global__ __launch_bounds__(64) void k_chain(const u8* __restrict__ in, const B
       const u32 i = i0 + lane;
       const bool act = i < tn;
       const u32 key = act ? (u32)keys[i] : 0u;
+      if (t0 + i0 + 64 <= e0) {
+        // warm-up step (nothing of it is emitted): only the heads matter — the highest position of
+        // every key.  All lanes write, one per key gets through; whoever is above the survivor
+        // writes again (one round unless two positions of the step share a key).
+        const u32 r = cur0 + i;
+        bool todo = act;
+        while (__any(todo)) {
+          if (todo) head[key] = (u16)r;
+          wave_lds_sync();
+          const u32 w = act ? (u32)head[key] : 0xffffu;
+          wave_lds_sync();
+          todo = act && w < r;
+        }
+        continue;
+      }
       const u32 old = act ? (u32)head[key] : (u32)ZMX_NONE16;
       u64 grp = __ballot(act);                       // lanes of this step with my key
 #pragma unroll

@@ -70,6 +70,8 @@
   {                                                                          \
     const u32 jj_ = (WB) + lane;                                             \
     if (lane < 32 && jj_ >= 1 && jj_ <= B) la[jj_] = (u16)(l[0] ? jj_ + 1 - l[0] : 0u); \
+    /* wave 1 stores the lengths of a clean-flagged step from s_lout whichever path ran it */ \
+    if ((WB) - base <= 32u) s_lout[it & 1][((WB) - base) * 2 + lane] = l[0]; \
     D3_ROT32()                                                               \
   }
 
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
       const u32 base = S.base;
       u32 p0 = S.q;
       u32 bi = 0;   // block index within the step
-      if (dv[0] & D3_DESC_CLEAN) {   // (q = 0: a new group, so wo = 0)
+      if ((dv[0] & D3_DESC_CLEAN) && reach < 64) {   // (q = 0: a new group, so wo = 0; only register 0 is live)
         // a whole group of single-register positions (the usual step): both windows' rows are
         // requested up front, the second window's arrive while the first one runs
         const u64 tk = D3_TICK();
@@ -310,9 +312,9 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
           D3_RELAX_K(c[0], lt, wa[u], (u32)(u + 1))
         }
         l[0] = lt ? base + lt : l[0];
-        reach = reach > 63 ? reach : 63;
         s_lout[it & 1][lane] = l[0];             // cells base .. base + 31 are final (lanes 0..31)
-        D3_ROT32()
+        c[0] = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(c[0]), __float_as_uint(1e30f), false, false)[1]);
+        l[0] = __builtin_amdgcn_permlane32_swap(l[0], 0u, false, false)[1];
         lt = 0;
 #pragma unroll
         for (int u = 0; u < 32; ++u) {
@@ -320,12 +322,13 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
           D3_RELAX_K(c[0], lt, wb[u], (u32)(u + 1))
         }
         l[0] = lt ? base + 32 + lt : l[0];
-        reach = reach > 63 ? reach : 63;
         n_fast += 64;
         if (PROF) { tp[0] += D3_TICK() - tk; np[0] += 64; }
         // its event is D3_EV_GROUP_END (64 positions, none flagged): retire the second window
         s_lout[it & 1][64 + lane] = l[0];        // cells base + 32 .. base + 63
-        D3_ROT32()
+        c[0] = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(c[0]), __float_as_uint(1e30f), false, false)[1]);
+        l[0] = __builtin_amdgcn_permlane32_swap(l[0], 0u, false, false)[1];
+        reach = 31;                              // cells up to window cell 63 were written, the window moved twice
         wo = 0;
         if (PROF) { t_work += (u64)__builtin_readcyclecounter() - tw0; ++n_steps; }
         __syncthreads();

@@ -99,7 +99,7 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
     rc = Lz77GreedyBatch(ctx, ranges, &greedy, &split_tables);
     if (rc) return rc;
     const double t0 = Now();
-    ParallelFor(np, [&](size_t p) {
+    ParallelForWide(np, [&](size_t p) {
       Lz77Store s = StoreFromRun(greedy[p], parts[p].instart);
       std::vector<size_t> pts;
       BlockSplitLz77(s, static_cast<size_t>(options.blocksplittingmax), &pts);
@@ -131,7 +131,7 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
   std::vector<zmx_block> fixed_requests;
   std::vector<std::pair<size_t, size_t>> fixed_owner;  // (part, final index)
   const double t3 = Now();
-  ParallelFor(np, [&](size_t p) {
+  ParallelForWide(np, [&](size_t p) {
     PartState& s = st[p];
     const size_t npoints = s.blocks.size() - 1;
     double totalcost = 0;
@@ -185,7 +185,7 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
 
   // ---- 5. pick the block type and encode
   const double t5 = Now();
-  ParallelFor(np, [&](size_t p) {
+  ParallelForWide(np, [&](size_t p) {
     PartState& s = st[p];
     for (size_t i = 0; i < s.finals.size(); ++i) {
       const FinalBlock& f = s.finals[i];

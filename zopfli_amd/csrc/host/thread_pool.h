@@ -31,10 +31,29 @@ inline unsigned HostThreads() {
   return n;
 }
 
+// Threads of the second, wider pool: for the few long per-master-block phases of a call (block
+// split, block type costs, encoding), where one task per thread beats two rounds on fewer threads
+// and the wake-up cost is paid three times per call, not twice per squeeze run.
+inline unsigned WideThreads() {
+  static const unsigned n = [] {
+    if (std::getenv("ZOPFLI_AMD_THREADS")) return HostThreads();   // an explicit budget covers both pools
+    const unsigned hc = std::thread::hardware_concurrency();
+    const unsigned cap = 128;
+    const unsigned w = hc ? (hc < cap ? hc : cap) : 1u;
+    return w > HostThreads() ? w : HostThreads();
+  }();
+  return n;
+}
+
 class WorkerPool {
  public:
   static WorkerPool& Get() {
     static WorkerPool* pool = new WorkerPool(HostThreads());  // leaked on purpose: no join at exit
+    return *pool;
+  }
+  static WorkerPool& Wide() {
+    if (WideThreads() == HostThreads()) return Get();
+    static WorkerPool* pool = new WorkerPool(WideThreads());
     return *pool;
   }
 
@@ -118,6 +137,22 @@ void ParallelFor(size_t n, Fn&& fn) {
     g_inside_parallel_for = was;
   };
   WorkerPool::Get().Run(n, body);
+}
+
+// The same on the wide pool when there are more tasks than the regular pool has threads.
+template <typename Fn>
+void ParallelForWide(size_t n, Fn&& fn) {
+  if (n <= HostThreads() || g_inside_parallel_for) {
+    ParallelFor(n, fn);
+    return;
+  }
+  const std::function<void(size_t)> body = [&](size_t i) {
+    const bool was = g_inside_parallel_for;
+    g_inside_parallel_for = true;
+    fn(i);
+    g_inside_parallel_for = was;
+  };
+  WorkerPool::Wide().Run(n, body);
 }
 
 }  // namespace zamd

@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=100 * MB, help="bytes per GPU (default: the 100 MB workload)")
     ap.add_argument("--blocksplitting", type=int, default=0, help="0 = configs[1] (default), 1 = configs[2]")
+    ap.add_argument("--cls", default="T", choices=list("TXRZBPM"),
+                    help="synthetic input class (zopfli_amd/csrc/tools/datagen.c): T text-like (default, enwik8 "
+                         "stand-in), X markup-like, M mixed corpus (Silesia stand-in), ...")
     ap.add_argument("--numiterations", type=int, default=15)
     ap.add_argument("--cpu-sample", type=int, default=8 * MB)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -94,11 +97,13 @@ def main():
     size = args.size
     assert size % MB == 0 or world == 1, "shards must be whole master blocks"
 
-    # ---- synthetic input: shard r = class T, seed 1 + r
-    shard = generate("T", size, seed=1 + rank)
+    # ---- synthetic input: shard r = class `cls`, seed = the class's default seed + r
+    from zopfli_amd.datagen import DEFAULT_SEED
+    seed0 = DEFAULT_SEED[args.cls]
+    shard = generate(args.cls, size, seed=seed0 + rank)
     prefix = b""
     if rank > 0:
-        prefix = generate("T", size, seed=rank)[-WINDOW:]  # tail of the previous shard = dictionary
+        prefix = generate(args.cls, size, seed=seed0 + rank - 1)[-WINDOW:]  # tail of the previous shard = dictionary
     resident = prefix + shard
     ctx = Context(dev_index, lib)
     ctx.set_input(resident)  # H2D, outside the timed region
@@ -173,11 +178,11 @@ def main():
         if world == 1:
             roundtrip = gzip.decompress(out) == shard
             sha = hashlib.sha256(out).hexdigest()
-            for name in ("vectors_big.json", "vectors.json"):
+            for name in ("vectors_big.json", "vectors_big2.json", "vectors.json"):
                 p = os.path.join(ROOT, "tests", "golden", name)
                 if os.path.exists(p):
                     for c in json.load(open(p)):
-                        if (c["input"].get("cls") == "T" and c["input"].get("seed") in (None, 1)
+                        if (c["input"].get("cls") == args.cls and c["input"].get("seed") in (None, seed0)
                                 and c["insize"] == size and c["format"] == 0
                                 and c["numiterations"] == args.numiterations
                                 and c["blocksplitting"] == args.blocksplitting and c["blocksplittingmax"] == 15):
@@ -220,7 +225,7 @@ def main():
             "value": round(value, 4), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 (f32/f64 cost DP)", "data": "synthetic",
-            "config": {"workload": f"class-T text-like {size} B per GPU (enwik8 stand-in), numiterations="
+            "config": {"workload": f"class-{args.cls} synthetic {size} B per GPU (T = text-like enwik8 stand-in), numiterations="
                                    f"{args.numiterations}, blocksplitting={args.blocksplitting}, gzip, "
                                    f"{'configs[1]' if args.blocksplitting == 0 else 'configs[2]'}",
                        "total_bytes": total, "master_blocks": (total + MB - 1) // MB,

@@ -1,7 +1,7 @@
 """Generates tests/golden/vectors.json from the REAL reference (oracle/_ref/libzopfli_ref.so,
 compiled from /root/reference by oracle/Makefile).  Run in the build container:
 
-    python tests/golden/make_golden.py [--big | --extra]
+    python tests/golden/make_golden.py [--big | --big2 | --extra]
 
 Each vector: synthetic class / size / seed (zopfli_amd.datagen) or a literal input, the
 ZopfliOptions used, the format, and the SHA-256 + length of the reference's output.
@@ -96,12 +96,28 @@ def cases(big):
     return cs
 
 
+def big2_cases():
+    """The bench shape on data that is not class T (round-1 verdict): markup-like X and the mixed
+    corpus M at 20 MB, numiterations 15, with and without block splitting; X also at 100 MB."""
+    cs = []
+    for cls in "XM":
+        for split in (0, 1):
+            cs.append({"input": {"kind": "class", "cls": cls, "size": 20000000}, "format": 0, "numiterations": 15,
+                       "blocksplitting": split, "blocksplittingmax": 15})
+    for split in (0, 1):
+        cs.append({"input": {"kind": "class", "cls": "X", "size": 100000000}, "format": 0, "numiterations": 15,
+                   "blocksplitting": split, "blocksplittingmax": 15})
+    return cs
+
+
 def main():
     big = "--big" in sys.argv
     extra = "--extra" in sys.argv
-    path = os.path.join(HERE, "vectors_extra.json" if extra else "vectors_big.json" if big else "vectors.json")
-    cs = extra_cases() if extra else cases(big)
-    if big and not extra:
+    big2 = "--big2" in sys.argv
+    path = os.path.join(HERE, "vectors_big2.json" if big2 else "vectors_extra.json" if extra else
+                        "vectors_big.json" if big else "vectors.json")
+    cs = big2_cases() if big2 else extra_cases() if extra else cases(big)
+    if big and not extra and not big2:
         cs = [c for c in cs if c["input"].get("size", 0) >= 20000000]
     with mp.Pool(min(8, len(cs))) as pool:
         done = pool.map(run, cs, chunksize=1)

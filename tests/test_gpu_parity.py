@@ -209,18 +209,27 @@ def test_deflate_part_vs_reference(gpu_lib, btype):
     assert a == b
 
 
-def test_full_size_round_trip(gpu_lib):
-    """BASELINE config-2 shape at 20 MB (20 master blocks, numiterations 15, blocksplitting 0):
-    round trip through zlib + the reference's SHA-256 when the big golden file is present."""
-    data = generate("T", 20000000)
-    out = api.compress(data, 0, ZopfliOptions(15, 0), lib=gpu_lib)
+def _big_cases():
+    out = []
+    for name in ("vectors_big.json", "vectors_big2.json"):
+        path = os.path.join(os.path.dirname(GOLDEN), name)
+        if os.path.exists(path):
+            with open(path) as f:
+                out += [c for c in json.load(f) if c["insize"] == 20000000]
+    return out
+
+
+@pytest.mark.parametrize("case", _big_cases(), ids=_gid)
+def test_full_size_round_trip(gpu_lib, case):
+    """The bench shapes at 20 MB (20 master blocks, numiterations 15) on text-like, markup-like and
+    mixed data, with and without block splitting (BASELINE configs 2 and 3): round trip through zlib
+    and the reference's SHA-256 (tests/golden/vectors_big*.json, written by make_golden.py --big / --big2)."""
+    data = _input(case["input"])
+    opt = ZopfliOptions(case["numiterations"], case["blocksplitting"], case["blocksplittingmax"])
+    out = api.compress(data, case["format"], opt, lib=gpu_lib)
     assert gzip.decompress(out) == data
-    big = os.path.join(os.path.dirname(__file__), "golden", "vectors_big.json")
-    if os.path.exists(big):
-        with open(big) as f:
-            for c in json.load(f):
-                if c["insize"] == 20000000 and c["blocksplitting"] == 0 and c["format"] == 0:
-                    assert hashlib.sha256(out).hexdigest() == c["sha256"]
+    assert len(out) == case["outsize"]
+    assert hashlib.sha256(out).hexdigest() == case["sha256"]
 
 
 def test_row_budget_ranges():

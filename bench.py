@@ -119,6 +119,7 @@ def main():
         return None if parts is None else [int.from_bytes(bytes(p), "little") for p in parts]
 
     timing_acc = {}
+    seg_acc = {}
 
     def step():
         crc_box = [0]
@@ -129,6 +130,8 @@ def main():
         tb = time.perf_counter()
         for k, v in api.last_timing(lib).items():
             timing_acc[k] = timing_acc.get(k, 0.0) + v
+        for k, v in api.last_seg_stats(lib).items():
+            seg_acc[k] = seg_acc.get(k, 0.0) + v
         th.join()
         blobs = gather_blobs(blob)
         crcs = gather_crc(crc_box[0])
@@ -155,6 +158,7 @@ def main():
     for _ in range(args.warmup):
         step()
     timing_acc.clear()
+    seg_acc.clear()
     sync()
     t0 = time.perf_counter()
     out = None
@@ -232,6 +236,7 @@ def main():
                        "sharding": "master blocks, contiguous per rank, RCCL gather of bit chunks"},
             "output_bytes": len(out), "roundtrip_ok": roundtrip, "bitexact_vs_reference": bitexact,
             "roofline": roofline,
+            "chain_tasks_per_step": {k: round(v / args.steps, 1) for k, v in seg_acc.items()},
             "breakdown_s_per_step": {k: round(v / args.steps, 4) for k, v in timing_acc.items()
                                      if k != "squeeze_launches"},
         }

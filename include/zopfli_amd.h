@@ -183,6 +183,13 @@ int zmx_last_kernel_timing(double* out4);
  * [1] chunk serialisation (zmx_deflate_range). */
 int zmx_last_host_timing(double* out2);
 
+/* The chain's tasks (GetBestLengths cut into verified stretches, zmx_dp4.h) since the last Zopfli* /
+ * zmx_deflate_range call started: [0] tasks [1] accepted as computed [2] re-run because the entry
+ * state differed [3] because the guessed level left the binade [4] because a weight could tie
+ * [5] positions re-run serially [6] re-run because the entry values differed by more than a shift
+ * [7] block positions of all squeeze runs. */
+int zmx_last_seg_stats(double* out8);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,7 @@ int zmx_set_input(zmx_ctx* ctx, const unsigned char* in, size_t insize) {
 size_t zmx_internal_input_size(zmx_ctx* ctx) { return ctx->input.size(); }
 const unsigned char* zmx_internal_input_host(zmx_ctx* ctx) { return ctx->input.data(); }
 void zmx_internal_kernel_stats(double* a, double* b, int) { a[0] = a[1] = a[2] = 0; *b = 0; }
+void zmx_internal_seg_stats(double* a, int) { for (int i = 0; i < 8; ++i) a[i] = 0; }
 
 int zmx_tables_build(zmx_ctx* ctx, const zmx_block* blocks, size_t nblocks, zmx_tables** tables) {
   zmx_tables* t = new zmx_tables();

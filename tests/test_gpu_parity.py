@@ -163,6 +163,31 @@ def test_squeeze_runs(gpu_ctx, case):
         t.free()
 
 
+# (environment, what the task statistics must show)
+CHAIN_ENVS = [
+    ({}, lambda st: st["tasks"] > 100 and st["accepted"] > 0),
+    ({"ZOPFLI_AMD_SPEC": "4"}, lambda st: st["tasks"] > 100 and st["accepted"] > 0),        # speculative pass on the 4-wave pipeline
+    ({"ZOPFLI_AMD_SEG_L": "0"}, lambda st: st["tasks"] == 0),                                   # the serial chain
+    ({"ZOPFLI_AMD_SEG_WARM": "64", "ZOPFLI_AMD_SEG_HEAD": "0"}, lambda st: st["rerun_state"] > 0),                           # warm-up too short: states differ
+    ({"ZOPFLI_AMD_SEG_SCALE": "1.9"}, lambda st: st["rerun_level"] + st["rerun_values"] > 0),                         # wrong binade guessed
+    ({"ZOPFLI_AMD_SEG_L": "1024", "ZOPFLI_AMD_SEG_WARM": "256", "ZOPFLI_AMD_SEG_HEAD": "4096"}, lambda st: st["tasks"] > 400),
+]
+
+
+@pytest.mark.parametrize("env,expect", CHAIN_ENVS, ids=lambda v: "-".join(f"{k[15:]}{x}" for k, x in v.items()) if isinstance(v, dict) else "")
+def test_chain_task_paths(env, expect):
+    """GetBestLengths cut into verified tasks (zmx_dp4.h): whatever the task geometry and however wrong
+    the guessed levels, length_array and the stores equal the oracle's on every class — and the
+    statistics show that the path under test (accept, re-run from the true state, serial) really ran."""
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(__file__), "seg_probe.py")
+    r = subprocess.run([sys.executable, probe], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    st = json.loads(r.stdout.strip().splitlines()[-1])
+    assert expect(st), st
+
+
 def _golden(lo, hi):
     out = []
     for name in ("vectors.json", "vectors_extra.json"):

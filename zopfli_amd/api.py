@@ -92,6 +92,7 @@ def bind(lib):
     lib.zmx_last_timing.argtypes = [P(ctypes.c_double)]
     lib.zmx_last_kernel_timing.argtypes = [P(ctypes.c_double)]
     lib.zmx_last_host_timing.argtypes = [P(ctypes.c_double)]
+    lib.zmx_last_seg_stats.argtypes = [P(ctypes.c_double)]
     return lib
 
 
@@ -156,6 +157,15 @@ def last_timing(lib=None):
     lib.zmx_last_host_timing(h)
     d["download"], d["serialize"] = h[0], h[1]
     return d
+
+
+def last_seg_stats(lib=None):
+    """zmx_last_seg_stats: how the chain's tasks of the last call fared."""
+    lib = lib or library()
+    t = (ctypes.c_double * 8)()
+    lib.zmx_last_seg_stats(t)
+    keys = ["tasks", "accepted", "rerun_state", "rerun_level", "rerun_tie", "positions_rerun", "rerun_values", "positions"]
+    return dict(zip(keys, list(t)))
 
 
 class Context:

@@ -1,13 +1,36 @@
-// k_dp3: GetBestLengths (squeeze.c:217-309) of one LZ77OptimalRun — the serial DP chain, one
-// workgroup of four waves (one per SIMD) per block.  Included only by zmx_hip.hip, after
-// zmx_kernels.h.  DESIGN.md section 4 has the reasoning and the measurements.
+// k_dp4: GetBestLengths (squeeze.c:217-309) of one LZ77OptimalRun, cut into TASKS that run on all
+// CUs at once, with every task's result verified before it is used.  Included only by zmx_hip.hip,
+// after zmx_kernels.h.  DESIGN.md section 4 has the reasoning and the measurements.
 //
-// A lone wave issues about one VALU instruction per 5.8 cycles and the chain is a million dependent
-// positions per 1 MB block, so everything that is not the chain runs somewhere else.  The block
-// is cut into STEPS — runs of positions of one 64-position group whose edge rows span at most
-// D3_SPAN ring slots; where a step ends (span, group end, long-run shortcut, block end) depends
-// only on dph[], never on DP values — and the waves work on consecutive steps like a pipeline,
-// with one s_barrier per step as the only synchronisation:
+// The DP is a chain through float-rounded absolute costs (squeeze.c:243,281,299): position j + 1
+// needs costs[j + 1], which position j may just have written.  One wave per block walking a million
+// dependent positions was the whole launch time of round 1.  Two facts cut the chain:
+//
+//  * Translation.  While every value a stretch of the chain computes lies in one binade
+//    [2^e, 2^(e+1)), adding D (a multiple of the float ulp of that binade) to its entry state adds D
+//    to every value and changes no comparison: dbl(w + c + D) = dbl(w + c) + D because c and D are
+//    multiples of 2^(e-23), an even multiple of the double ulp 2^(e-52), and fl(x + D) = fl(x) + D
+//    unless x lies exactly half-way between two floats — which depends only on the edge weight w
+//    and e and is excluded per block and binade up front (zmx_hip.hip, tie mask).
+//  * Coalescence.  The state of the chain at position p (the <= 259 live cells, their values up
+//    to a common shift and the edges that reached them) is the same whether the chain started at 0
+//    or a few hundred positions before p from a single cell: all surviving paths pass through a
+//    common ancestor shortly before p.  That is a property of the data, not a theorem.
+//
+// So a block is cut into tasks of SEG_L positions.  Task s > 0 starts SEG_WARM positions early from
+// a single cell holding a guessed level, records its state when it reaches its first group at or
+// after pout ("entry"), writes length_array from there on and records its state where it stops
+// ("exit").  k_dpcheck compares exit[s - 1] with entry[s] cell by cell: same group base, same
+// source edges, values differing by one constant d.  k_dp4<FIX> (one workgroup per block) then
+// walks the tasks in order: the true shift of task s is the true shift of s - 1 plus d; if the
+// states matched and both the guessed and the shifted values of the task stay inside one binade
+// whose weights cannot tie, the task's length_array is exactly what the serial chain would have
+// written.  Any task that fails a test is run again from the true exit state of its predecessor
+// (no guess, no warm-up), which is the serial chain itself.  Nothing unverified is ever used.
+//
+// One task is the round-1 k_dp3 pipeline, one workgroup of four waves (one per SIMD), with one
+// s_barrier per STEP (a run of positions of one 64-position group whose edge rows span at most
+// D3_SPAN ring slots; where a step ends depends only on dph[], never on DP values):
 //
 //   wave 1 (the walk and the ring)   walks step i: reads dph[] and k_edges' bad-edge bitmap,
 //                       publishes a 6-word descriptor and the group's {row offset, kend}; keeps the
@@ -18,7 +41,7 @@
 //   wave 0 (the chain)  runs step i - 2: cells in registers (lane l owns cells w + 64 s + l of a
 //                       window that moves 32 cells at a time), 8 VALU instructions per position on
 //                       the usual path; positions that need more than two cell registers, flagged
-//                       or bad-edge positions, ragged tails and shortcuts use k_dp's generic path
+//                       or bad-edge positions, ragged tails and shortcuts take the generic path
 //                       straight from the ring.
 //
 // After a shortcut (and at the start) the ring restarts at a new place: the walk inserts two
@@ -30,16 +53,8 @@
 // so fl(w + cj) >= fl(mincost + cj), hence "newCost < costs[j+k]" already implies
 // "costs[j+k] > mincostaddcostj".  A position with an edge below mincost (possible only through
 // rounding in the cost model) is reported in k_edges' bitmap and takes the generic path, which
-// tests literally.  (This form, with the source position in a register, is used by k_sq only.)
-#define D3_RELAX(CS, LS, WV)                                                 \
-  {                                                                          \
-    const double old_ = (double)(CS);                                        \
-    const double nc_ = (WV) + cj;                    /* squeeze.c:278,297 */  \
-    const bool upd_ = nc_ < old_;                    /* :298 */              \
-    CS = upd_ ? (float)nc_ : CS;                                             \
-    LS = upd_ ? src1 : LS;                                                   \
-  }
-
+// tests literally.
+//
 // The hot form.  The source is recorded as a small constant K (1 + index of the position in its
 // block): the select takes an inline constant.  The new cost goes through v_min_f64 instead of
 // compare + select: (float)min(nc, (double)c) is (float)nc when nc < c and c itself otherwise
@@ -64,14 +79,18 @@
     reach = reach >= 32 ? reach - 32 : 0;                                    \
   }
 
+// The largest finite value this task has held in cell register 0 (per lane; reduced at the end).
+#define D4_TRACK_MAX() { vmax = fmaxf(vmax, c[0] < 1e29f ? c[0] : 0.0f); }
+
 // Cells WB .. WB + 31 (lanes 0..31 of register 0) are final: write their lengths and move the
-// window on.
+// window on.  Cells below la_lo belong to the previous task.
 #define D3_RETIRE32(WB)                                                      \
   {                                                                          \
     const u32 jj_ = (WB) + lane;                                             \
-    if (lane < 32 && jj_ >= 1 && jj_ <= B) la[jj_] = (u16)(l[0] ? jj_ + 1 - l[0] : 0u); \
+    if (lane < 32 && jj_ >= la_lo && jj_ <= B) la[jj_] = (u16)(l[0] ? jj_ + 1 - l[0] : 0u); \
     /* wave 1 stores the lengths of a clean-flagged step from s_lout whichever path ran it */ \
     if ((WB) - base <= 32u) s_lout[it & 1][((WB) - base) * 2 + lane] = l[0]; \
+    D4_TRACK_MAX()                                                           \
     D3_ROT32()                                                               \
   }
 
@@ -83,6 +102,33 @@
 #define D3_EV_GROUP_END 2u
 #define D3_EV_BUBBLE 3u  // nothing to do
 #define D3_EV_PRIME 4u   // wave 1 primes the ring at the start of the segment that follows
+
+#define SEG_CELLS 384u   // the six cell registers of the chain wave
+#define SEG_NONE 0xffffffffu
+
+// The state of the chain between two groups: the window of cell registers sits at `base`.
+struct SegSnap {
+  u32 base;              // block-relative position of the next group
+  u32 noshort;           // squeeze.c:273: the shortcut is not tested at `base` (it was just taken)
+  float vmax;            // exit snapshots: the largest finite cell value the task produced from its entry on
+  u32 pad;
+  float c[SEG_CELLS];    // cell values (1e30 = never reached)
+  u32 l[SEG_CELLS];      // 1 + block-relative position the cell was reached from (0 = never)
+};
+
+struct SegTask {
+  u32 block;             // block index in the table set
+  u32 q;                 // first position walked: pout - warm-up (0 for the first task of a block)
+  u32 pout;              // length_array is written from the first group base >= pout on
+  u32 pend;              // the walk stops at the first group base >= pend (B + 1: runs to the block end)
+};
+
+struct SegCheck {        // k_dpcheck: exit[t - 1] against entry[t]
+  double d;              // exit[t - 1].c - entry[t].c (the same for every reached cell when match is set)
+  float vmin;            // smallest cell value of entry[t]
+  u32 match;             // 1: same base, same shortcut state, same reached cells, same sources, one constant difference;
+                         // 0: the structure differs; 2: only the values differ (by more than one constant)
+};
 
 struct D3Group {          // the current group: lane l = position base + l
   u32 roff, kend, offend; // kend = 0 beyond the block end
@@ -136,7 +182,7 @@ __device__ __forceinline__ void d3_load_group(D3Walk& W, D3Group& G, const uint2
   // sits in lane (lane & 31) of the window, its edges reach cell register (kend + (lane & 31)) >> 6
   G.m_r1 = __ballot(G.kend + (lane & 31u) >= 64u);                    // needs cell register 1
   // not for the fast path: flagged, more than two registers, two registers in rows 0..31 (tile 2
-  // holds rows 32..63 only), or a match edge below mincost (k_edges' bitmap; see D3_RELAX)
+  // holds rows 32..63 only), or a match edge below mincost (k_edges' bitmap; see D3_RELAX_K)
   G.m_bad = G.m_short | __ballot(G.kend + (lane & 31u) >= 128u) | (G.m_r1 & 0xffffffffull) |
             __ballot(act && ((bw >> ((pos_off + cur) & 31u)) & 1u) != 0);
   W.have_group = true;
@@ -217,29 +263,117 @@ __device__ __forceinline__ bool d3_fast(u32 end, u64 m_bad, u32 p0) {
   return p0 + 8 <= end && (p0 & 31u) <= 24u && ((u32)(m_bad >> p0) & 255u) == 0;   // inside one window
 }
 
-template <bool PROF>
-__global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
-  __shared__ __align__(16) double s_ring[DP_FRONT + DP_RING + DP_MIRROR];
-  __shared__ __align__(16) double s_t1[2][64 * 64];   // register-0 rows, row = position in the group
-  __shared__ __align__(16) double s_t2[2][32 * 64];   // register-1 rows, row = position & 31
-  __shared__ uint2 s_tab[D3_NB][64];
-  // step descriptors, written by wave 1 a step ahead of the builders, two ahead of the chain wave:
-  // [0] q | n << 8 | event << 16 | last << 24 [1] base [2..3] m_r1 [4..5] m_bad
-  __shared__ __align__(8) u32 s_desc[3][8];
-  __shared__ uint2 s_tabc[3][64];   // {roff, kend} of the step's group
-  __shared__ float s_xc[DP_XN];
-  __shared__ u16 s_xl[DP_XN];
-  // "1 + source" of the 2 x 32 cells a clean step retires, per tile buffer: wave 1 turns them
-  // into length_array a step later (the chain wave only does one LDS write per window)
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min_f32(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exit state E of a task against the entry state N of the next one, by one wave
+__device__ __forceinline__ SegCheck d4_check(const SegSnap* E, const SegSnap* N, u32 lane) {
+  bool bad = E->base != N->base || E->noshort != N->noshort;
+  bool badv = false;
+  double dl[6];
+  bool fin[6];
+  float vmin = 3e38f;
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    const u32 i = 64u * s + lane;
+    const float ec = E->c[i], nc = N->c[i];
+    const bool ef = ec < 1e29f, nf = nc < 1e29f;
+    bad |= ef != nf || E->l[i] != N->l[i];
+    fin[s] = ef && nf;
+    dl[s] = (double)ec - (double)nc;          // exact in double
+    if (nf) vmin = fminf(vmin, nc);
+  }
+  // cell `base` is the next position: always reached
+  const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)__double_as_longlong(dl[0]), 0);
+  const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(__double_as_longlong(dl[0]) >> 32), 0);
+  const double d0 = __longlong_as_double((long long)(((u64)hi << 32) | lo));
+  const bool fin0 = __builtin_amdgcn_readlane(fin[0] ? 1 : 0, 0) != 0;
+#pragma unroll
+  for (int s = 0; s < 6; ++s) badv |= fin[s] && dl[s] != d0;
+  SegCheck r;
+  r.d = d0;
+  r.vmin = wave_min_f32(vmin);
+  r.match = (__any(bad) || !fin0) ? 0u : __any(badv) ? 2u : 1u;
+  return r;
+}
+
+struct Dp4Params {
+  const BlockDesc* blocks;
+  u32 block0;              // FIX: first block of this launch
+  u32 task0;               // SPEC / k_dpcheck: first task of this launch
+  const uint2* dph;
+  const double* cost;      // [nb_total][320]
+  const double* mincost;   // [nb_total]
+  const double* rows;
+  const u64* row_base;
+  const u64* block_edges;
+  u16* la;
+  u64* prof;               // optional [nb_total][ZMX_PROF_N] counters (ZOPFLI_AMD_PROF), else null
+  const u32* badpos;       // k_edges' bad-edge bitmap
+  const SegTask* tasks;
+  const u32* task_off;     // [nb_total + 1] first task of each block
+  float* lvl;              // [tasks] guessed value of cell q, refined by every run
+  const float* est_bits;   // [nb_total] estimated block cost in bits (first run of a table set), or null
+  SegSnap* entry;          // [tasks]
+  SegSnap* exit;           // [tasks]
+  SegCheck* chk;           // [tasks]
+  const float* wmax;       // [nb_total] no edge weight of the run exceeds this
+  const u32* tiemask;      // [nb_total] bit e: a weight of the run can tie in the float rounding of binade e
+  u32* stats;              // [8] tasks / accepted / re-run: state, level, tie / positions re-run / re-run: values
+  float level_scale;       // test hook (ZOPFLI_AMD_SEG_SCALE): the guessed levels are multiplied by this
+  const u32* order;        // SPEC: launch order of the tasks (the long head tasks first), indexed from task0
+};
+
+// What one pass of the four waves over a stretch of the chain does.
+struct D4Job {
+  u32 start;               // first group base
+  u32 noshort;             // walk state there
+  u32 pout;                // spec: the entry state is recorded at the first group base >= pout
+  u32 pend;                // the walk stops at the first group base >= pend
+  u32 la_lo;               // length_array is written for cells >= la_lo (SEG_NONE: from the entry on)
+  bool spec;
+  bool load;               // initial state from `init` (+ delta) instead of a single cell holding `level`
+  float level;
+  double delta;
+  const SegSnap* init;
+  SegSnap* entry;
+  SegSnap* exit;
+};
+
+#define D4_LDS_DECL                                                                                   \
+  __shared__ __align__(16) double s_ring[DP_FRONT + DP_RING + DP_MIRROR];                             \
+  __shared__ __align__(16) double s_t1[2][64 * 64];   /* register-0 rows, row = position in the group */ \
+  __shared__ __align__(16) double s_t2[2][32 * 64];   /* register-1 rows, row = position & 31 */      \
+  __shared__ uint2 s_tab[D3_NB][64];                                                                  \
+  /* step descriptors, written by wave 1 a step ahead of the builders, two ahead of the chain wave: */ \
+  /* [0] q | n << 8 | event << 16 | last << 24 [1] base [2..3] m_r1 [4..5] m_bad */                  \
+  __shared__ __align__(8) u32 s_desc[3][8];                                                           \
+  __shared__ uint2 s_tabc[3][64];   /* {roff, kend} of the step's group */                            \
+  __shared__ float s_xc[DP_XN];                                                                       \
+  __shared__ u16 s_xl[DP_XN];                                                                         \
+  /* "1 + source" of the 2 x 32 cells a clean step retires, per tile buffer: wave 1 turns them */     \
+  /* into length_array a step later (the chain wave only does one LDS write per window) */            \
   __shared__ u32 s_lout[2][128];
 
+// One job, by all four waves of the workgroup (every wave executes the same number of barriers).
+template <bool PROF>
+__device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u32 b, const BlockDesc& bd,
+                                           double (&s_ring)[DP_FRONT + DP_RING + DP_MIRROR], double (&s_t1)[2][64 * 64],
+                                           double (&s_t2)[2][32 * 64], uint2 (&s_tab)[D3_NB][64], u32 (&s_desc)[3][8],
+                                           uint2 (&s_tabc)[3][64], float (&s_xc)[DP_XN], u16 (&s_xl)[DP_XN],
+                                           u32 (&s_lout)[2][128]) {
   const u32 tid = threadIdx.x;
   const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
   const u32 lane = tid & 63;
-  const u32 b = P.block0 + blockIdx.x;
-  const BlockDesc bd = P.blocks[b];
   const u32 B = (u32)(bd.inend - bd.instart);
-  if (B == 0) return;
   const uint2* dbase = P.dph + bd.pos_off;
   u16* la = P.la + bd.la_off;
   const double* rows = P.rows + P.row_base[b];
@@ -255,10 +389,23 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
     // ================================================================= consumer
     float c[6];
     u32 l[6];
+    u32 reach;   // no cell beyond window cell `reach` has been written: registers above reach >> 6 are fresh
+    if (J.load) {
 #pragma unroll
-    for (int s = 0; s < 6; ++s) { c[s] = 1e30f; l[s] = 0; }
-    if (lane == 0) c[0] = 0.0f;
-    u32 reach = 0;   // no cell beyond window cell `reach` has been written: registers above reach >> 6 are fresh
+      for (int s = 0; s < 6; ++s) {
+        const float ec = J.init->c[64u * s + lane];
+        c[s] = ec < 1e29f ? (float)((double)ec + J.delta) : 1e30f;   // exact: both are multiples of the binade's ulp
+        l[s] = J.init->l[64u * s + lane];
+      }
+      reach = SEG_CELLS - 1;
+    } else {
+#pragma unroll
+      for (int s = 0; s < 6; ++s) { c[s] = 1e30f; l[s] = 0; }
+      if (lane == 0) c[0] = J.level;
+      reach = 0;
+    }
+    u32 la_lo = J.la_lo;
+    float vmax = 0.0f;
     u32 wo = 0;   // the cell registers cover cells base + wo + 64 s + lane: wo = 32 once the chain is past position 31 of the group
     u64 t_work = 0, n_fast = 0, n_slow = 0, n_steps = 0;
     u64 tp[5] = {0, 0, 0, 0, 0}, np[5] = {0, 0, 0, 0, 0};   // PROF: cycles and positions per path
@@ -296,6 +443,14 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
       const u32 base = S.base;
       u32 p0 = S.q;
       u32 bi = 0;   // block index within the step
+      if (J.spec && la_lo == SEG_NONE && S.q == 0 && base >= J.pout) {
+        // the first group at or after pout: the registers sit at its base.  From here on the task
+        // owns the length_array; what it holds now is compared with the predecessor's exit state.
+#pragma unroll
+        for (int s = 0; s < 6; ++s) { J.entry->c[64u * s + lane] = c[s]; J.entry->l[64u * s + lane] = l[s]; }
+        la_lo = base;
+        vmax = 0.0f;
+      }
       if ((dv[0] & D3_DESC_CLEAN) && reach < 64) {   // (q = 0: a new group, so wo = 0; only register 0 is live)
         // a whole group of single-register positions (the usual step): both windows' rows are
         // requested up front, the second window's arrive while the first one runs
@@ -313,6 +468,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
         }
         l[0] = lt ? base + lt : l[0];
         s_lout[it & 1][lane] = l[0];             // cells base .. base + 31 are final (lanes 0..31)
+        D4_TRACK_MAX()
         c[0] = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(c[0]), __float_as_uint(1e30f), false, false)[1]);
         l[0] = __builtin_amdgcn_permlane32_swap(l[0], 0u, false, false)[1];
         lt = 0;
@@ -326,6 +482,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
         if (PROF) { tp[0] += D3_TICK() - tk; np[0] += 64; }
         // its event is D3_EV_GROUP_END (64 positions, none flagged): retire the second window
         s_lout[it & 1][64 + lane] = l[0];        // cells base + 32 .. base + 63
+        D4_TRACK_MAX()
         c[0] = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(c[0]), __float_as_uint(1e30f), false, false)[1]);
         l[0] = __builtin_amdgcn_permlane32_swap(l[0], 0u, false, false)[1];
         reach = 31;                              // cells up to window cell 63 were written, the window moved twice
@@ -454,13 +611,14 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
         if (p >= 32 && wo == 0) { D3_RETIRE32(base) wo = 32; }
         const u32 pw = p - wo, wbase = base + wo;
         const u32 j = base + p;
-        if (lane < pw && wbase + lane >= 1) la[wbase + lane] = (u16)(l[0] ? wbase + lane + 1 - l[0] : 0u);
+        if (lane < pw && wbase + lane >= la_lo) la[wbase + lane] = (u16)(l[0] ? wbase + lane + 1 - l[0] : 0u);
         wave_lds_sync();
 #pragma unroll
         for (int s = 0; s < 6; ++s) {
           const u32 x = wbase + 64u * s + lane;
           s_xc[64 * s + lane] = c[s];
           s_xl[64 * s + lane] = (u16)(l[s] ? x + 1 - l[s] : 0u);
+          vmax = fmaxf(vmax, c[s] < 1e29f ? c[s] : 0.0f);
         }
         wave_lds_sync();
         // costs[j+t+258] = costs[j+t] + symbolcost for t = 0..257, unconditionally; cells
@@ -471,7 +629,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
           const u32 t = 64u * r + lane;
           nc4[r] = 1e30f;
           if (t < ZMX_MAX_MATCH) {
-            la[j + t] = s_xl[pw + t];
+            if (j + t >= la_lo) la[j + t] = s_xl[pw + t];
             nc4[r] = (float)((double)s_xc[pw + t] + symbolcost258);
           }
         }
@@ -491,19 +649,30 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
       ++it;
       if (last) break;
     }
-    if (lane == 0) la[0] = 0;
+    if (J.la_lo == 1 && lane == 0) la[0] = 0;   // the head of the block
+    if (J.exit) {
+      // the registers sit at the base the walk stopped at (wave 1 writes the header)
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {
+        J.exit->c[64u * s + lane] = c[s];
+        J.exit->l[64u * s + lane] = l[s];
+        vmax = fmaxf(vmax, c[s] < 1e29f ? c[s] : 0.0f);
+      }
+      vmax = wave_max_f32(vmax);
+      if (lane == 0) J.exit->vmax = vmax;
+    }
     if (PROF && P.prof && lane == 0) {
       u64* o = P.prof + (u64)b * ZMX_PROF_N;
-      o[0] = n_steps; o[1] = t_work; o[2] = n_fast; o[3] = n_slow; o[4] = B;
-      for (int i = 0; i < 5; ++i) { o[5 + 2 * i] = tp[i]; o[6 + 2 * i] = np[i]; }
+      atomicAdd(&o[0], n_steps); atomicAdd(&o[1], t_work); atomicAdd(&o[2], n_fast); atomicAdd(&o[3], n_slow);
+      atomicAdd(&o[4], n_fast + n_slow);
+      for (int i = 0; i < 5; ++i) { atomicAdd(&o[5 + 2 * i], tp[i]); atomicAdd(&o[6 + 2 * i], np[i]); }
     }
-    return;
-  }
-
-  // =================================================================== wave 1: the walk and the ring
-  u64 tq[4] = {0, 0, 0, 0};   // PROF: cycles in the walk / ring upkeep / tiles / barrier
-  if (wave == 1) {
+  } else if (wave == 1) {
+    // =================================================================== wave 1: the walk and the ring
+    u64 tq[4] = {0, 0, 0, 0};   // PROF: cycles in the walk / ring upkeep / tiles / barrier
     D3Walk W;
+    W.base = J.start;
+    W.noshort = J.noshort != 0;
     D3Group G;
     G.roff = G.kend = G.offend = 0; G.m_short = G.m_r1 = G.m_bad = 0; G.navail = 0;
     D3Step cur;              // the step the builders work on during this iteration (walked one iteration ago)
@@ -512,6 +681,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
     u32 a_prev = 0;          // a_cur of the step the chain wave works on during this iteration
     u32 it = 0, tail = 0;
     bool more = true;
+    u32 la_lo = J.la_lo;
     // base and "clean" of the steps walked 1, 2, 3 iterations ago: the chain wave finished the
     // oldest during the previous iteration and left its lengths in s_lout
     u32 hb1 = 0, hb2 = 0, hb3 = 0;
@@ -520,7 +690,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
     if (hc3) {                                                               \
       const u32 v_ = s_lout[(it - 1) & 1][(lane >> 5) * 64 + (lane & 31)];   \
       const u32 jj_ = hb3 + lane;                                            \
-      if (jj_ >= 1 && jj_ <= B) la[jj_] = (u16)(v_ ? jj_ + 1 - v_ : 0u);     \
+      if (jj_ >= la_lo && jj_ <= B) la[jj_] = (u16)(v_ ? jj_ + 1 - v_ : 0u); \
     }
     while (tail < 2) {       // two more barriers after the last step has been walked
       const u64 tk0 = D3_TICK();
@@ -556,8 +726,13 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
       cur.n = 0; cur.event = D3_EV_BUBBLE;
       hb3 = hb2; hc3 = hc2; hb2 = hb1; hc2 = hc1; hc1 = false;
       if (more) {
+        const u32 ns0 = W.noshort ? 1u : 0u;
         cur = d3_next(W, G, dbase, P.badpos + (bd.pos_off >> 5), (u32)(bd.pos_off & 31), B, lane);
-        more = W.bubbles || W.base <= B;
+        more = W.bubbles || W.base < J.pend;
+        if (J.spec && la_lo == SEG_NONE && cur.q == 0 && cur.base >= J.pout) {   // the chain wave records the cells
+          la_lo = cur.base;
+          if (lane == 0) { J.entry->base = cur.base; J.entry->noshort = ns0; }
+        }
         if (cur.n) s_tabc[it % 3][lane] = make_uint2(G.roff, G.kend);
         const bool clean = cur.q == 0 && cur.n == 64 && (G.m_r1 | G.m_bad) == 0;
         hb1 = cur.base; hc1 = clean;
@@ -578,9 +753,15 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
     }
     D3_STORE_LA()                                       // the last step
 #undef D3_STORE_LA
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA in flight when the workgroup's LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA in flight when the ring is reused
+    if (J.exit && lane == 0) { J.exit->base = W.base; J.exit->noshort = W.noshort ? 1u : 0u; }
+    if (PROF && P.prof && lane == 0) {
+      u64* o = P.prof + (u64)b * ZMX_PROF_N + 16;
+      for (int i = 0; i < 4; ++i) atomicAdd(&o[i], tq[i]);
+    }
   } else {
     // ================================================================= waves 2..: the tiles
+    u64 tq[4] = {0, 0, 0, 0};
     const u32 my = wave - 2;
     __syncthreads();         // iteration 0: wave 1 walks step 0
     u32 it = 1;              // this wave works on step it - 1
@@ -599,7 +780,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
       const u32 sq = dv[0] & 255u, sn = (dv[0] >> 8) & 255u, sev = (dv[0] >> 16) & 255u;
       const bool last = ((dv[0] >> 24) & 1u) != 0;
       const u64 m_r1 = ((u64)dv[3] << 32) | dv[2], m_bad = ((u64)dv[5] << 32) | dv[4];
-      if (sn && sev != D3_EV_BUBBLE && sev != D3_EV_PRIME && !(PROF && P.debug_nofetch)) {
+      if (sn && sev != D3_EV_BUBBLE && sev != D3_EV_PRIME) {
         const uint2 tc = s_tabc[(it - 1) % 3][lane];
         wave_lds_sync();
         s_tab[my][lane] = make_uint2(((tc.x & (DP_RING - 1)) - lane - 1) * 8u, tc.y);
@@ -687,10 +868,138 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp3(DpParams P) {
       if (last) break;
     }
     __syncthreads();         // the chain wave's last step
-  }
-  if (PROF && P.prof && wave <= 2 && lane == 0) {
-    u64* o = P.prof + (u64)b * ZMX_PROF_N + 16 + 8 * (wave - 1);
-    for (int i = 0; i < 4; ++i) o[i] = tq[i];
+    if (PROF && P.prof && wave == 2 && lane == 0) {
+      u64* o = P.prof + (u64)b * ZMX_PROF_N + 24;
+      for (int i = 0; i < 4; ++i) atomicAdd(&o[i], tq[i]);
+    }
   }
 #undef D3_TICK
+  // the LDS (ring, tiles, descriptors) is reused by the next job, and the snapshots written here are
+  // read back by the other waves (k_dp4_fix): make them visible beyond this wave's stores
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+// ---------------------------------------------------------------------------------------------
+// SPEC: one workgroup per task.  The first task of a block starts from the block's true initial
+// state (costs[0] = 0) and is exact; every other task starts SEG_WARM positions early from one
+// cell holding the level guessed for it.
+// ---------------------------------------------------------------------------------------------
+template <bool PROF>
+__global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_spec(Dp4Params P) {
+  D4_LDS_DECL
+  const u32 t = P.order[P.task0 + blockIdx.x];
+  const SegTask T = P.tasks[t];
+  const BlockDesc bd = P.blocks[T.block];
+  const u32 B = (u32)(bd.inend - bd.instart);
+  if (B == 0) return;
+  D4Job J;
+  J.start = T.q;
+  J.noshort = 0;
+  J.pout = T.pout;
+  J.pend = T.pend;
+  J.load = false;
+  J.delta = 0;
+  J.init = nullptr;
+  J.entry = &P.entry[t];
+  J.exit = &P.exit[t];
+  if (T.pout == 0) {       // the head of the block
+    J.spec = false;
+    J.la_lo = 1;
+    J.level = 0.0f;
+  } else {
+    J.spec = true;
+    J.la_lo = SEG_NONE;
+    J.level = P.est_bits ? P.est_bits[T.block] * ((float)T.q / (float)B) : P.lvl[t];
+    J.level *= P.level_scale;
+    if (!(J.level >= 16.0f)) J.level = 16.0f;
+    if (P.est_bits && threadIdx.x == 0) P.lvl[t] = J.level;
+  }
+  d4_run_job<PROF>(P, J, T.block, bd, s_ring, s_t1, s_t2, s_tab, s_desc, s_tabc, s_xc, s_xl, s_lout);
+}
+
+// exit[t - 1] against entry[t] for every task but the heads: one wave per task
+__global__ __launch_bounds__(64) void k_dpcheck(Dp4Params P) {
+  const u32 t = P.task0 + blockIdx.x;
+  if (P.tasks[t].pout == 0) return;
+  const SegCheck r = d4_check(&P.exit[t - 1], &P.entry[t], threadIdx.x);
+  if (threadIdx.x == 0) P.chk[t] = r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FIX: one workgroup per block walks the block's tasks in order, accepts every task whose entry
+// state is the true state up to a shift that keeps the task inside its binade, and runs the others
+// again from the true state — the serial chain, for exactly the stretches that need it.
+// ---------------------------------------------------------------------------------------------
+template <bool PROF>
+__global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
+  D4_LDS_DECL
+  const u32 b = P.block0 + blockIdx.x;
+  const BlockDesc bd = P.blocks[b];
+  const u32 B = (u32)(bd.inend - bd.instart);
+  if (B == 0) return;
+  const u32 t0 = P.task_off[b], t1 = P.task_off[b + 1];
+  const u32 lane = threadIdx.x & 63;
+  const bool lead = threadIdx.x == 0;
+  const double wmax = (double)P.wmax[b] + 1.0;
+  const u32 tiemask = P.tiemask[b];
+  double delta_prev = 0.0;     // what has to be added to exit[t - 1] to get the true values
+  bool rerun_prev = false;     // exit[t - 1] was rewritten by this workgroup: P.chk[t] is stale
+  u32 n_ok = 0, n_state = 0, n_level = 0, n_tie = 0, n_pos = 0, n_values = 0;
+  for (u32 t = t0 + 1; t < t1; ++t) {
+    SegCheck ck;
+    if (rerun_prev) ck = d4_check(&P.exit[t - 1], &P.entry[t], lane);   // every wave computes the same
+    else ck = P.chk[t];
+    const double delta = delta_prev + ck.d;
+    // the guess to start the next run of this task from
+    if (lead) P.lvl[t] = (float)((double)P.lvl[t] + delta);
+    bool ok = ck.match == 1;
+    u32 why = 0;
+    if (ok && delta != 0.0) {
+      const float vmin = ck.vmin;
+      const double vmax = (double)P.exit[t].vmax;
+      const int e = (int)((__float_as_uint(vmin) >> 23) & 255u) - 127;
+      const double lo = ldexp(1.0, e), hi = ldexp(1.0, e + 1);
+      const bool pure = vmin >= 16.0f && vmax + wmax < hi && (double)vmin + delta >= lo && vmax + wmax + delta < hi;
+      const bool tie = ((tiemask >> (e & 31)) & 1u) != 0;
+      if (!pure) { ok = false; why = 1; }
+      else if (tie) { ok = false; why = 2; }
+    }
+    if (ok) {
+      delta_prev = delta;
+      rerun_prev = false;
+      ++n_ok;
+      continue;
+    }
+    if (ck.match == 0) ++n_state; else if (ck.match == 2) ++n_values; else if (why == 1) ++n_level; else ++n_tie;
+    const SegTask T = P.tasks[t];
+    D4Job J;
+    J.start = P.exit[t - 1].base;
+    J.noshort = P.exit[t - 1].noshort;
+    J.pout = 0;
+    J.pend = T.pend;
+    J.la_lo = J.start;
+    J.spec = false;
+    J.load = true;
+    J.level = 0.0f;
+    J.delta = delta_prev;
+    J.init = &P.exit[t - 1];
+    J.entry = nullptr;
+    J.exit = &P.exit[t];
+    n_pos += (T.pend < B ? T.pend : B) - (J.start < B ? J.start : B);
+    __syncthreads();     // every wave has read the old exit[t] / exit[t - 1]
+    d4_run_job<PROF>(P, J, b, bd, s_ring, s_t1, s_t2, s_tab, s_desc, s_tabc, s_xc, s_xl, s_lout);
+    delta_prev = 0.0;
+    rerun_prev = true;
+  }
+  if (lead && P.stats) {
+    atomicAdd(&P.stats[0], t1 - t0);
+    atomicAdd(&P.stats[1], n_ok);
+    atomicAdd(&P.stats[2], n_state);
+    atomicAdd(&P.stats[3], n_level);
+    atomicAdd(&P.stats[4], n_tie);
+    atomicAdd(&P.stats[5], n_pos);
+    atomicAdd(&P.stats[6], n_values);
+  }
 }

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -15,8 +16,8 @@
 
 #include "zmx_kernels.h"
 #include "zmx_match2.h"
-#include "zmx_dp3.h"
-#include "zmx_sq.h"
+#include "zmx_dp4.h"
+#include "zmx_dp5.h"
 #include "zmx_trace.h"
 #include "zmx_greedy.h"
 #include "zopfli_amd.h"
@@ -26,8 +27,9 @@ namespace {
 
 std::string g_err;
 std::mutex g_stats_mutex;
-double g_kernel_seconds[3] = {0, 0, 0};  // k_edges, k_dp, k_trace (HIP events)
+double g_kernel_seconds[3] = {0, 0, 0};  // k_edges, chain kernels (k_dp4_spec + k_dpcheck + k_dp4_fix), k_trace (HIP events)
 double g_squeeze_launches = 0;
+double g_seg_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // tasks, accepted, re-run: state / level / tie, positions re-run, re-run: values, positions
 
 int Fail(const char* what, hipError_t e, const char* file, int line) {
   char buf[512];
@@ -62,8 +64,8 @@ struct zmx_ctx {
   u8* d_in = nullptr;
   size_t insize = 0, in_cap = 0;
   const unsigned char* h_in = nullptr;  // caller's buffer (borrowed until the next zmx_set_input)
-  u32* d_scratch = nullptr;  // k_match per-lane overflow change points
-  double* d_rows = nullptr;  // DP edge costs of the blocks of one k_edges/k_dp launch (grow-only)
+  u32* d_scratch = nullptr;  // k_match2 per-lane overflow change points
+  double* d_rows = nullptr;  // DP edge costs of the blocks of one k_edges / chain launch (grow-only)
   size_t rows_cap = 0;
   // table arrays are recycled between batches and calls: hipMalloc/hipFree of multi-GB arrays
   // cost more than the kernels that fill them
@@ -110,7 +112,22 @@ struct zmx_tables {
   u64 max_range_rows = 0;
   u32* d_counters = nullptr;  // 16 words, see MatchParams
   u32* d_flags = nullptr;     // 4 words
-  u64* d_prof = nullptr;      // nb * 8 cycle counters when ZOPFLI_AMD_PROF is set
+  u64* d_prof = nullptr;      // nb * ZMX_PROF_N counters when ZOPFLI_AMD_PROF is set
+  // the chain's tasks (zmx_dp4.h)
+  std::vector<SegTask> tasks;
+  std::vector<u32> task_off;  // [nb + 1]
+  SegTask* d_tasks = nullptr;
+  u32* d_task_off = nullptr;
+  u32* d_task_order = nullptr;
+  float* d_lvl = nullptr;
+  SegSnap* d_entry = nullptr;
+  SegSnap* d_exit = nullptr;
+  SegCheck* d_chk = nullptr;
+  float* d_runinfo = nullptr; // [3][nb]: wmax, tie mask (as bits), estimated block cost
+  u32* d_segstats = nullptr;  // 8 words
+  std::vector<u32> h_hist;    // the histograms of the last greedy parse / squeeze run (host copy)
+  bool have_hist = false;
+  u32 squeeze_runs = 0;
   // host cache for the parity probe
   std::vector<std::vector<u32>> probe_recs;
   std::vector<u32> probe_pool;
@@ -184,6 +201,12 @@ const char* zmx_last_error(void) { return g_err.c_str(); }
 
 size_t zmx_internal_input_size(zmx_ctx* ctx) { return ctx->insize; }
 const unsigned char* zmx_internal_input_host(zmx_ctx* ctx) { return ctx->h_in; }
+
+void zmx_internal_seg_stats(double* out8, int reset) {
+  std::lock_guard<std::mutex> lock(g_stats_mutex);
+  for (int i = 0; i < 8; ++i) out8[i] = g_seg_stats[i];
+  if (reset) for (int i = 0; i < 8; ++i) g_seg_stats[i] = 0;
+}
 
 void zmx_internal_kernel_stats(double* seconds3, double* squeeze_launches, int reset) {
   std::lock_guard<std::mutex> lock(g_stats_mutex);
@@ -272,6 +295,15 @@ void zmx_tables_free(zmx_ctx* c, zmx_tables* t) {
   PoolFree(c, t->d_counters);
   PoolFree(c, t->d_flags);
   PoolFree(c, t->d_prof);
+  PoolFree(c, t->d_tasks);
+  PoolFree(c, t->d_task_off);
+  PoolFree(c, t->d_task_order);
+  PoolFree(c, t->d_lvl);
+  PoolFree(c, t->d_entry);
+  PoolFree(c, t->d_exit);
+  PoolFree(c, t->d_chk);
+  PoolFree(c, t->d_runinfo);
+  PoolFree(c, t->d_segstats);
   delete t;
 }
 
@@ -281,13 +313,19 @@ void zmx_tables_free(zmx_ctx* c, zmx_tables* t) {
 // records of a sub-block equal the parent's except where pos + 258 > end or pos lies in the run
 // of equal bytes that reaches the end — only the tiles holding such positions are recomputed,
 // everything else is copied.  Hash links (k_same, k_chain) are rebuilt: they are cheap.
-// ZOPFLI_AMD_MATCH=1 selects k_match, the first version of the match kernel (A/B reference).
-using MatchKernelFn = void (*)(MatchParams);
-static MatchKernelFn MatchKernel() {
-  static const bool old_kernel = [] { const char* e = std::getenv("ZOPFLI_AMD_MATCH"); return e && std::atoi(e) == 1; }();
-  return old_kernel ? k_match : k_match2;
+static unsigned EnvU32(const char* name, unsigned dflt, unsigned lo, unsigned hi) {
+  const char* e = std::getenv(name);
+  if (!e) return dflt;
+  const long v = std::atol(e);
+  return v < static_cast<long>(lo) ? lo : v > static_cast<long>(hi) ? hi : static_cast<unsigned>(v);
 }
-static unsigned MatchThreads() { return MatchKernel() == k_match ? MATCH_THREADS : M2_THREADS; }
+// Task geometry of the chain (zmx_dp4.h): positions per task and warm-up positions before it.
+// ZOPFLI_AMD_SEG_L = 0 turns the cut off (one task per block: the serial chain).
+static unsigned SegL() { static const unsigned v = EnvU32("ZOPFLI_AMD_SEG_L", 4096, 0, 1u << 24) & ~63u; return v; }
+// The first task of a block is exact by construction and runs beside the others: let it cover the
+// stretch where the costs double every few thousand positions and no guess would stay in its binade.
+static unsigned SegHead() { static const unsigned v = EnvU32("ZOPFLI_AMD_SEG_HEAD", 32768, 0, 1u << 24) & ~63u; return v; }
+static unsigned SegWarm() { static const unsigned v = (EnvU32("ZOPFLI_AMD_SEG_WARM", 512, 64, 1u << 20) + 63u) & ~63u; return v; }
 
 static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_tables* t, zmx_tables* parent = nullptr) {
   t->nb = nb;
@@ -426,7 +464,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     mp.scratch = c->d_scratch;
     mp.tile_list = d_tile_list;
     if (mp.total_tiles > 0) {
-      hipLaunchKernelGGL(MatchKernel(), dim3(kMatchGrid), dim3(MatchThreads()), 0, c->stream, mp);
+      hipLaunchKernelGGL(k_match2, dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
       HIPCHK(hipGetLastError());
     }
     u32 counters[2] = {0, 0};
@@ -469,7 +507,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     mp.scratch = c->d_scratch;
     mp.tile_list = nullptr;
     if (mp.total_tiles > 0) {
-      hipLaunchKernelGGL(MatchKernel(), dim3(kMatchGrid), dim3(MatchThreads()), 0, c->stream, mp);
+      hipLaunchKernelGGL(k_match2, dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
       HIPCHK(hipGetLastError());
     }
     u32 counters[2] = {0, 0};
@@ -513,6 +551,52 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   t->ranges.emplace_back(first, static_cast<u32>(nb));
   t->max_range_rows = std::max(t->max_range_rows, cur);
   HIPCHK(hipMemcpyAsync(t->d_row_base, row_base.data(), nb * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+  // the chain's tasks (zmx_dp4.h): SEG_L positions each, the last one of a block takes the remainder
+  {
+    const u32 L = SegL(), warm = SegWarm();
+    const u32 head = std::max(SegHead(), L);
+    t->task_off.assign(nb + 1, 0);
+    t->tasks.clear();
+    for (size_t b = 0; b < nb; ++b) {
+      const u32 B = t->bsize[b];
+      // the head [0, head), then tasks of L positions; the last one takes the remainder
+      const u32 n = (L == 0 || B < head + L) ? 1u : 1u + (B - head) / L;
+      for (u32 s = 0; s < n; ++s) {
+        SegTask k;
+        k.block = static_cast<u32>(b);
+        k.pout = s == 0 ? 0u : head + (s - 1) * L;
+        k.q = s == 0 ? 0u : k.pout - std::min(warm, k.pout);
+        k.pend = s + 1 == n ? B + 1 : head + s * L;
+        t->tasks.push_back(k);
+      }
+      t->task_off[b + 1] = static_cast<u32>(t->tasks.size());
+    }
+    const size_t nt = t->tasks.size();
+    HIPCHK(PoolAlloc(c, &t->d_task_order, nt));
+    HIPCHK(PoolAlloc(c, &t->d_tasks, nt));
+    HIPCHK(PoolAlloc(c, &t->d_task_off, nb + 1));
+    HIPCHK(PoolAlloc(c, &t->d_lvl, nt));
+    HIPCHK(PoolAlloc(c, &t->d_entry, nt));
+    HIPCHK(PoolAlloc(c, &t->d_exit, nt));
+    HIPCHK(PoolAlloc(c, &t->d_chk, nt));
+    HIPCHK(PoolAlloc(c, &t->d_runinfo, 3 * nb));
+    HIPCHK(PoolAlloc(c, &t->d_segstats, 8));
+    HIPCHK(hipMemcpyAsync(t->d_tasks, t->tasks.data(), nt * sizeof(SegTask), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(t->d_task_off, t->task_off.data(), (nb + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(t->d_segstats, 0, 8 * sizeof(u32), c->stream));
+  }
+  {
+    // the tasks' launch order, per launch range: the heads (several times the length of the others) first
+    std::vector<u32> order(t->tasks.size());
+    for (const auto& r : t->ranges) {
+      u32 at = t->task_off[r.first];
+      for (u32 b = r.first; b < r.second; ++b) order[at++] = t->task_off[b];
+      for (u32 b = r.first; b < r.second; ++b)
+        for (u32 k = t->task_off[b] + 1; k < t->task_off[b + 1]; ++k) order[at++] = k;
+    }
+    HIPCHK(hipMemcpyAsync(t->d_task_order, order.data(), order.size() * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));   // `order` is a local
+  }
   // trace segments (zmx_trace.h)
   t->seg_off.assign(nb + 1, 0);
   for (size_t b = 0; b < nb; ++b) t->seg_off[b + 1] = t->seg_off[b] + (t->bsize[b] + TS_SEG - 1) / TS_SEG;
@@ -575,7 +659,47 @@ int zmx_lz77_greedy(zmx_ctx* c, zmx_tables* t, int slot, uint32_t* nsym, uint32_
   HIPCHK(hipMemcpyAsync(hist, t->d_hist, t->nb * ZMX_HIST * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   for (size_t b = 0; b < t->nb; ++b) t->store_begin[slot][b] = 0;
+  t->h_hist.assign(hist, hist + t->nb * ZMX_HIST);
+  t->have_hist = true;
   return 0;
+}
+
+// What the acceptance test of the chain's tasks (zmx_dp4.h) needs to know about a run's cost model:
+// an upper bound of every edge weight, the binades in which a weight can tie in the float rounding,
+// and a first guess of the block's cost.  The weights are the 256 literal costs and
+// ((lbits + dbits) + ll[lsym]) + d[dsym] for the 29 x 30 symbol pairs (squeeze.c:155).
+static void RunInfo(const double* cost, const u32* hist, u32 B, float* wmax_out, u32* tiemask_out, float* est_out) {
+  const double* ll = cost;
+  const double* d = cost + ZMX_NUM_LL;
+  auto lbits = [](int s) { return s < 265 || s == 285 ? 0 : (s - 261) / 4; };
+  auto dbits = [](int s) { return s < 4 ? 0 : s / 2 - 1; };
+  double w[256 + 29 * 30];
+  int n = 0;
+  for (int i = 0; i < 256; ++i) w[n++] = ll[i];
+  for (int ls = 257; ls <= 285; ++ls)
+    for (int ds = 0; ds < 30; ++ds) w[n++] = (static_cast<double>(lbits(ls) + dbits(ds)) + ll[ls]) + d[ds];
+  double wmax = 0;
+  for (int i = 0; i < n; ++i) wmax = std::max(wmax, w[i]);
+  u32 mask = 0;
+  for (int e = 4; e < 32; ++e) {
+    bool tie = false;
+    for (int i = 0; i < n && !tie; ++i) {
+      // dbl(w + c) = c + RNE(w / 2^(e-52)) 2^(e-52) for a float c of binade e; the float rounding of
+      // that sum ties iff the remainder modulo the float ulp 2^(e-23) is exactly half of it
+      const double r = std::nearbyint(std::ldexp(w[i], 52 - e));
+      tie = std::fmod(r, 536870912.0) == 268435456.0;
+    }
+    if (tie) mask |= 1u << e;
+  }
+  *wmax_out = static_cast<float>(wmax) + 1.0f;
+  *tiemask_out = mask;
+  double est = 2.5 * B;   // no parse to go by: the tasks' levels are refined by the run itself
+  if (hist) {
+    est = 0;
+    for (int i = 0; i < ZMX_NUM_LL; ++i) est += hist[i] * (ll[i] + (i > 256 ? lbits(i) : 0));
+    for (int i = 0; i < 30; ++i) est += hist[ZMX_NUM_LL + i] * (d[i] + dbits(i));
+  }
+  *est_out = static_cast<float>(est);
 }
 
 int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double* mincost, const int32_t* slot,
@@ -585,26 +709,43 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   for (size_t b = 0; b < t->nb; ++b) {
     if (slot[b] != 0 && slot[b] != 1) return FailMsg("zmx_squeeze_run: slot must be 0 or 1");
   }
-  HIPCHK(hipMemcpyAsync(t->d_cost, cost, t->nb * ZMX_HIST * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(t->d_mincost, mincost, t->nb * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(t->d_slot, slot, t->nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  // ZOPFLI_AMD_DP selects an A/B variant of the chain kernel: 1 = k_dp (one wave), 4 = k_sq (fused
-  // edge costs, slower: DESIGN.md section 7); anything else = k_dp3, the product path.
-  static const int dp_mode = [] { const char* e = std::getenv("ZOPFLI_AMD_DP"); return e ? std::atoi(e) : 0; }();
-  const bool need_rows = dp_mode != 4;
-  if (need_rows && t->max_range_rows > c->rows_cap) {
+  const size_t nb = t->nb;
+  // per-block facts about this run's cost model for the chain's acceptance test
+  std::vector<float> runinfo(3 * nb);
+  {
+    const u32* hh = t->have_hist ? t->h_hist.data() : nullptr;
+    float* wmax = runinfo.data();
+    u32* tiemask = reinterpret_cast<u32*>(runinfo.data() + nb);
+    float* est = runinfo.data() + 2 * nb;
+    zamd::ParallelFor(nb, [&](size_t b) {
+      RunInfo(cost + b * ZMX_HIST, hh ? hh + b * ZMX_HIST : nullptr, t->bsize[b], &wmax[b], &tiemask[b], &est[b]);
+    });
+  }
+  HIPCHK(hipMemcpyAsync(t->d_cost, cost, nb * ZMX_HIST * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(t->d_mincost, mincost, nb * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(t->d_slot, slot, nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(t->d_runinfo, runinfo.data(), 3 * nb * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  if (t->max_range_rows > c->rows_cap) {
     if (c->d_rows) HIPCHK(hipFree(c->d_rows));
     c->d_rows = nullptr;
     c->rows_cap = 0;
-    HIPCHK(DevAlloc(&c->d_rows, t->max_range_rows));
+    hipError_t e = DevAlloc(&c->d_rows, t->max_range_rows);
+    if (e != hipSuccess && !c->pool_free.empty()) {   // out of memory: drop the table cache and retry
+      for (auto& f : c->pool_free) (void)hipFree(f.first);
+      c->pool_free.clear();
+      c->pool_free_bytes = 0;
+      e = DevAlloc(&c->d_rows, t->max_range_rows);
+    }
+    HIPCHK(e);
     c->rows_cap = t->max_range_rows;
   }
   static const bool want_prof = std::getenv("ZOPFLI_AMD_PROF") != nullptr;
-  if (want_prof && !t->d_prof) HIPCHK(PoolAlloc(c, &t->d_prof, t->nb * ZMX_PROF_N));
+  if (want_prof && !t->d_prof) HIPCHK(PoolAlloc(c, &t->d_prof, nb * ZMX_PROF_N));
+  if (t->d_prof) HIPCHK(hipMemsetAsync(t->d_prof, 0, nb * ZMX_PROF_N * sizeof(u64), c->stream));
   EdgeParams ep;
   ep.blocks = t->d_blocks;
   ep.tile_off = t->d_tile_off;
-  ep.nb_total = static_cast<u32>(t->nb);
+  ep.nb_total = static_cast<u32>(nb);
   ep.recs = t->d_recs;
   ep.pool = t->d_pool;
   ep.dph = t->d_dph;
@@ -613,7 +754,8 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   ep.row_base = t->d_row_base;
   ep.mincost = t->d_mincost;
   ep.badpos = t->d_badpos;
-  DpParams cp;
+  ep.block_edges = t->d_block_edges;
+  Dp4Params cp;
   cp.blocks = t->d_blocks;
   cp.dph = t->d_dph;
   cp.cost = t->d_cost;
@@ -623,16 +765,28 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   cp.block_edges = t->d_block_edges;
   cp.la = t->d_la;
   cp.prof = t->d_prof;
-  cp.recs = t->d_recs;
-  cp.pool = t->d_pool;
   cp.badpos = t->d_badpos;
-  if (need_rows) HIPCHK(hipMemsetAsync(t->d_badpos, 0, t->badpos_words * sizeof(u32), c->stream));
-  static const bool nofetch = std::getenv("ZOPFLI_AMD_DEBUG_NOFETCH") != nullptr;
-  cp.debug_nofetch = nofetch ? 1 : 0;
+  cp.tasks = t->d_tasks;
+  cp.task_off = t->d_task_off;
+  cp.lvl = t->d_lvl;
+  cp.est_bits = t->squeeze_runs == 0 ? t->d_runinfo + 2 * nb : nullptr;
+  cp.entry = t->d_entry;
+  cp.exit = t->d_exit;
+  cp.chk = t->d_chk;
+  cp.wmax = t->d_runinfo;
+  cp.tiemask = reinterpret_cast<const u32*>(t->d_runinfo + nb);
+  cp.stats = t->d_segstats;
+  static const float level_scale = [] { const char* e = std::getenv("ZOPFLI_AMD_SEG_SCALE"); return e ? static_cast<float>(std::atof(e)) : 1.0f; }();
+  cp.level_scale = level_scale;
+  cp.order = t->d_task_order;
+  // ZOPFLI_AMD_SPEC=4: the speculative pass on k_dp4's four-wave pipeline (one task per CU) instead of
+  // k_dp5's one wave per task
+  static const bool spec4 = [] { const char* e = std::getenv("ZOPFLI_AMD_SPEC"); return e && std::atoi(e) == 4; }();
+  HIPCHK(hipMemsetAsync(t->d_badpos, 0, t->badpos_words * sizeof(u32), c->stream));
   TraceSegParams tp;
   tp.blocks = t->d_blocks;
   tp.seg_off = t->d_seg_off;
-  tp.nb_total = static_cast<u32>(t->nb);
+  tp.nb_total = static_cast<u32>(nb);
   tp.recs = t->d_recs;
   tp.pool = t->d_pool;
   tp.la = t->d_la;
@@ -645,25 +799,31 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   tp.extab = t->d_extab;
   tp.seginfo = t->d_seginfo;
   double ksec[3] = {0, 0, 0};
+  const dim3 dpdim(64 * (D3_NB + 2));
   for (const auto& r : t->ranges) {
     const unsigned nblk = r.second - r.first;
     const unsigned tiles = t->tile_off[r.second] - t->tile_off[r.first];
     ep.tile0 = t->tile_off[r.first];
     cp.block0 = r.first;
+    cp.task0 = t->task_off[r.first];
+    const unsigned ntask = t->task_off[r.second] - t->task_off[r.first];
     tp.block0 = r.first;
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    if (tiles && need_rows) hipLaunchKernelGGL(k_edges, dim3(tiles), dim3(256), 0, c->stream, ep);
+    if (tiles) hipLaunchKernelGGL(k_edges, dim3(tiles), dim3(256), 0, c->stream, ep);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
-    if (dp_mode == 1) {          // single-wave chain over k_edges' rows (A/B reference)
-      if (cp.prof) hipLaunchKernelGGL(k_dp<true>, dim3(nblk), dim3(64), 0, c->stream, cp);
-      else hipLaunchKernelGGL(k_dp<false>, dim3(nblk), dim3(64), 0, c->stream, cp);
-    } else if (dp_mode == 4) {   // experiment: edge costs computed by the producer waves (no k_edges, no rows[])
-      if (cp.prof) hipLaunchKernelGGL(k_sq<true>, dim3(nblk), dim3(64 * (SQ_NP + 1)), 0, c->stream, cp);
-      else hipLaunchKernelGGL(k_sq<false>, dim3(nblk), dim3(64 * (SQ_NP + 1)), 0, c->stream, cp);
-    } else {                     // the product path: producer waves stage k_edges' rows for the chain wave
-      if (cp.prof) hipLaunchKernelGGL(k_dp3<true>, dim3(nblk), dim3(64 * (D3_NB + 2)), 0, c->stream, cp);
-      else hipLaunchKernelGGL(k_dp3<false>, dim3(nblk), dim3(64 * (D3_NB + 2)), 0, c->stream, cp);
+    // the chain: every task speculatively on all CUs, then the per-block walk that accepts or re-runs
+    if (spec4) {
+      if (cp.prof) hipLaunchKernelGGL(k_dp4_spec<true>, dim3(ntask), dpdim, 0, c->stream, cp);
+      else hipLaunchKernelGGL(k_dp4_spec<false>, dim3(ntask), dpdim, 0, c->stream, cp);
+    } else {
+      if (cp.prof) hipLaunchKernelGGL(k_dp5_spec<true>, dim3(ntask), dim3(64), 0, c->stream, cp);
+      else hipLaunchKernelGGL(k_dp5_spec<false>, dim3(ntask), dim3(64), 0, c->stream, cp);
+    }
+    if (ntask > nblk) {
+      hipLaunchKernelGGL(k_dpcheck, dim3(ntask), dim3(64), 0, c->stream, cp);
+      if (cp.prof) hipLaunchKernelGGL(k_dp4_fix<true>, dim3(nblk), dpdim, 0, c->stream, cp);
+      else hipLaunchKernelGGL(k_dp4_fix<false>, dim3(nblk), dpdim, 0, c->stream, cp);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
@@ -681,38 +841,43 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
       ksec[i] += ms * 1e-3;
     }
   }
-  HIPCHK(hipMemcpyAsync(nsym, t->d_nsym, t->nb * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(hist, t->d_hist, t->nb * ZMX_HIST * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-  if (nofetch) std::fprintf(stderr, "DEBUG_NOFETCH: k_dp %.2f ms\n", ksec[1] * 1e3);
+  u32 segstats[8];
+  HIPCHK(hipMemcpyAsync(nsym, t->d_nsym, nb * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(hist, t->d_hist, nb * ZMX_HIST * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(segstats, t->d_segstats, sizeof(segstats), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemsetAsync(t->d_segstats, 0, sizeof(segstats), c->stream));
   const int rc = CheckFlags(c, t, "zmx_squeeze_run");
   if (rc) return rc;
+  t->h_hist.assign(hist, hist + nb * ZMX_HIST);
+  t->have_hist = true;
+  ++t->squeeze_runs;
   {
     std::lock_guard<std::mutex> lock(g_stats_mutex);
     for (int i = 0; i < 3; ++i) g_kernel_seconds[i] += ksec[i];
     g_squeeze_launches += 1;
+    for (int i = 0; i < 7; ++i) g_seg_stats[i] += segstats[i];
+    g_seg_stats[7] += static_cast<double>(t->total_b);
   }
-  for (size_t b = 0; b < t->nb; ++b) t->store_begin[slot[b]][b] = t->bsize[b] - nsym[b];
+  for (size_t b = 0; b < nb; ++b) t->store_begin[slot[b]][b] = t->bsize[b] - nsym[b];
   if (t->d_prof) {
-    std::vector<u64> pr(t->nb * ZMX_PROF_N);
+    std::vector<u64> pr(nb * ZMX_PROF_N);
     HIPCHK(hipMemcpy(pr.data(), t->d_prof, pr.size() * sizeof(u64), hipMemcpyDeviceToHost));
     double a[ZMX_PROF_N] = {};
-    for (size_t b = 0; b < t->nb; ++b)
+    for (size_t b = 0; b < nb; ++b)
       for (unsigned k = 0; k < ZMX_PROF_N; ++k) a[k] += static_cast<double>(pr[b * ZMX_PROF_N + k]);
-    std::fprintf(stderr, "squeeze prof: edges %.2f ms dp %.2f ms trace %.2f ms; chain wave busy %.1f cycles/position, "
-                 "%.0f steps, fast %.1f%% of %.0f positions\n",
+    std::fprintf(stderr, "squeeze prof: edges %.2f ms chain %.2f ms trace %.2f ms; chain wave busy %.1f cycles/position, "
+                 "%.0f steps, fast %.1f%% of %.0f positions walked (%zu in the blocks); tasks %u accepted %u re-run "
+                 "state %u values %u level %u tie %u (%u positions)\n",
                  ksec[0] * 1e3, ksec[1] * 1e3, ksec[2] * 1e3, a[1] / a[4], a[0],
-                 100.0 * a[2] / (a[2] + a[3] + 1e-9), a[4]);
-    if (dp_mode != 1 && dp_mode != 4) {
-      const char* nm[5] = {"32", "16", "8", "8 (two registers)", "generic"};
-      for (int i = 0; i < 5; ++i)
-        std::fprintf(stderr, "  path %-18s %5.1f%% of positions, %6.1f cycles/position\n", nm[i], 100.0 * a[6 + 2 * i] / a[4],
-                     a[5 + 2 * i] / (a[6 + 2 * i] + 1e-9));
-      for (int w = 0; w < 2; ++w)
-        std::fprintf(stderr, "  producer wave %d, cycles/step: walk %.0f ring %.0f tiles %.0f barrier %.0f\n", w + 1,
-                     a[16 + 8 * w] / a[0], a[17 + 8 * w] / a[0], a[18 + 8 * w] / a[0], a[19 + 8 * w] / a[0]);
-    } else if (a[8] > 0)
-      std::fprintf(stderr, "  producer wave 1, cycles/step: next %.0f decode %.0f fill %.0f passes %.0f barrier %.0f; "
-                   "%.2f passes/step\n", a[8] / a[0], a[9] / a[0], a[10] / a[0], a[11] / a[0], a[12] / a[0], a[13] / a[0]);
+                 100.0 * a[2] / (a[2] + a[3] + 1e-9), a[4], t->total_b, segstats[0], segstats[1], segstats[2],
+                 segstats[6], segstats[3], segstats[4], segstats[5]);
+    const char* nm[5] = {"32", "16", "8", "8 (two registers)", "generic"};
+    for (int i = 0; i < 5; ++i)
+      std::fprintf(stderr, "  path %-18s %5.1f%% of positions, %6.1f cycles/position\n", nm[i], 100.0 * a[6 + 2 * i] / a[4],
+                   a[5 + 2 * i] / (a[6 + 2 * i] + 1e-9));
+    for (int w = 0; w < 2; ++w)
+      std::fprintf(stderr, "  producer wave %d, cycles/step: walk %.0f ring %.0f tiles %.0f barrier %.0f\n", w + 1,
+                   a[16 + 8 * w] / a[0], a[17 + 8 * w] / a[0], a[18 + 8 * w] / a[0], a[19 + 8 * w] / a[0]);
   }
   return 0;
 }

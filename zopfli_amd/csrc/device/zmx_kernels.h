@@ -246,9 +246,8 @@ __global__ __launch_bounds__(64) void k_chain(const u8* __restrict__ in, const B
 // ----------------------------------------------------------------------------
 #define MT 2048u
 #define MWIN_BYTES (32768u + MT + 288u)     // + slack for 16-byte alignment and 4-byte compares
-#define MATCH_THREADS 256
-#define SCRATCH_CPS 256u
-#define MATCH_BATCH 8u                        // lanes that wait for a record write / a new position before the wave serves them                     // per-lane overflow change points
+#define SCRATCH_CPS 256u                      // per-lane overflow change points
+#define MATCH_BATCH 8u                        // lanes that wait for a record write / a new position before the wave serves them
 
 struct MatchParams {
   const u8* in;
@@ -261,7 +260,7 @@ struct MatchParams {
   u32* pool;
   u32 pool_cap;
   u32* counters;         // [0] pool cursor, [1] error flags, [8..15] per-XCD tile cursors
-  u32* scratch;          // gridDim.x * MATCH_THREADS * SCRATCH_CPS
+  u32* scratch;          // gridDim.x * M2_THREADS * SCRATCH_CPS
   const u32* tile_list;  // optional: the tiles to do (total_tiles entries); null = all of them
 };
 
@@ -269,195 +268,6 @@ __device__ __forceinline__ u32 lds_byte(const u32* w, u32 a) { return (w[a >> 2]
 __device__ __forceinline__ u32 lds_u32_unaligned(const u32* w, u32 a) {
   const u32 lo = w[a >> 2], hi = w[(a >> 2) + 1];
   return __builtin_amdgcn_alignbyte(hi, lo, a & 3);
-}
-
-__global__ __launch_bounds__(MATCH_THREADS) void k_match(MatchParams P) {
-  __shared__ __align__(16) u32 win[MWIN_BYTES / 4 + 4];
-  __shared__ u32 s_next, s_tile;
-
-  const u32 tid = threadIdx.x;
-  const u32 xcd = blockIdx.x & 7;
-  const u32 t_begin = (u32)(((u64)P.total_tiles * xcd) / 8);
-  const u32 t_end = (u32)(((u64)P.total_tiles * (xcd + 1)) / 8);
-  u32* my_scratch = P.scratch + ((u64)blockIdx.x * MATCH_THREADS + tid) * SCRATCH_CPS;
-
-  for (;;) {
-    __syncthreads();  // previous tile fully consumed before the window is overwritten
-    if (tid == 0) {
-      s_tile = t_begin + atomicAdd(&P.counters[8 + xcd], 1u);
-      s_next = 0;
-    }
-    __syncthreads();
-    if (s_tile >= t_end) break;
-    const u32 tile = P.tile_list ? P.tile_list[s_tile] : s_tile;
-
-    // block of this tile: largest b with tile_off[b] <= tile
-    u32 lo = 0, hi = P.nb;
-    while (hi - lo > 1) {
-      const u32 mid = (lo + hi) >> 1;
-      if (P.tile_off[mid] <= tile) lo = mid; else hi = mid;
-    }
-    const BlockDesc bd = P.blocks[lo];
-    const u64 p0 = bd.instart + (u64)(tile - P.tile_off[lo]) * MT;
-    const u64 p1 = (p0 + MT < bd.inend) ? p0 + MT : bd.inend;
-    const u32 ntile = (u32)(p1 - p0);
-
-    // stage bytes [p0 - 32768, p1 + 258) (clipped to [0, inend)) at LDS offset (abs - wb)
-    const long long wb = ((long long)p0 - (long long)ZMX_WINDOW) & ~15ll;  // 16-byte aligned base, may be < 0
-    const u64 hi_abs = (p1 + ZMX_MAX_MATCH < bd.inend) ? p1 + ZMX_MAX_MATCH : bd.inend;
-    const u32 nvec = (u32)(((long long)hi_abs - wb + 15) >> 4);
-    for (u32 v = tid; v < nvec; v += MATCH_THREADS) {
-      const long long a = wb + (long long)v * 16;
-      uint4 x = make_uint4(0, 0, 0, 0);
-      if (a >= 0) x = *reinterpret_cast<const uint4*>(P.in + a);  // input is padded past its end
-      reinterpret_cast<uint4*>(win)[v] = x;
-    }
-    __syncthreads();
-
-    const ushort4* lk = P.links + bd.reg_off;  // index: abs - ws
-    const u64 ws = bd.ws;
-
-    // ---- per-lane walk state
-    bool active = false, done = false, comparing = false;
-    u32 lp = 0, lc = 0;            // LDS byte offsets of pos and candidate
-    u32 limit = 0, bestlen = 0, bestdist = 0, dist = 0, ncp = 0, same_pos = 0, cur = 0, size_rem = 0;
-    int hits_left = 0, chain = 1;
-    u64 pos = 0;
-    ushort4 L = make_ushort4(0, 0, 0, 0);  // links of the candidate
-    u32* rec = nullptr;
-
-    bool pending = false;          // the walk has ended, its record is not written yet
-    for (;;) {
-      // Writing a record and fetching the next position are long, rarely needed code: a wave that
-      // ran them whenever one lane asked would execute them on almost every step with one or two
-      // lanes active.  Lanes queue up instead (MATCH_BATCH of them, or nobody left walking).
-      const u64 m_need = __ballot(pending || (!active && !done));
-      const bool service = m_need != 0 && ((u32)__popcll(m_need) >= MATCH_BATCH || !__any(active));
-      if (service && pending) {
-        pending = false;
-        rec[0] = bestlen | (bestdist << 16);
-        if (ncp <= 8) {
-          rec[1] = same_pos | (lds_byte(win, lp) << 16) | (ncp << 24);
-        } else {
-          rec[1] = same_pos | (lds_byte(win, lp) << 16) | (0xffu << 24);
-          const u32 off = atomicAdd(&P.counters[0], ncp);
-          if (off + ncp <= P.pool_cap) {
-            const u8* b = reinterpret_cast<const u8*>(rec) + 8;
-            u32 first[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) first[e] = ((u32)b[3 * e] + 3u) | (((u32)b[3 * e + 1] | ((u32)b[3 * e + 2] << 8)) << 16);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) P.pool[off + e] = first[e];
-            for (u32 e = 8; e < ncp; ++e) P.pool[off + e] = my_scratch[e];
-            rec[2] = off;
-            rec[3] = ncp;
-          } else {
-            atomicOr(&P.counters[1], 1u);  // host retries with a larger pool
-            rec[2] = 0;
-            rec[3] = 0;
-          }
-        }
-      }
-      if (service && !active && !done) {
-        const u32 idx = atomicAdd(&s_next, 1u);
-        if (idx >= ntile) {
-          done = true;
-        } else {
-          pos = p0 + idx;
-          lp = (u32)((long long)pos - wb);
-          size_rem = (u32)((bd.inend - pos < 65536) ? bd.inend - pos : 65536);
-          const ushort4 Lp = lk[pos - ws];
-          same_pos = Lp.z;
-          rec = P.recs + (bd.pos_off + (pos - bd.instart)) * 8;
-          ncp = 0;
-          bestlen = 1; bestdist = 0; chain = 1; hits_left = ZMX_MAX_CHAIN_HITS; comparing = false;
-          if (size_rem < 3) {                      // lz77.c:440-446
-            rec[0] = 0;
-            rec[1] = same_pos | (lds_byte(win, lp) << 16);
-          } else {
-            limit = size_rem < ZMX_MAX_MATCH ? size_rem : ZMX_MAX_MATCH;  // lz77.c:448-450
-            if (Lp.x == 0) {                       // empty chain
-              rec[0] = 1;
-              rec[1] = same_pos | (lds_byte(win, lp) << 16);
-            } else {
-              dist = Lp.x;
-              lc = lp - dist;
-              L = lk[pos - dist - ws];
-              active = true;
-            }
-          }
-        }
-      }
-      if (!__any(active)) {
-        if (__all(done)) break;
-        continue;
-      }
-      if (active) {
-        bool finish = false;
-        if (!comparing) {
-          // lz77.c:478-479: test the byte after the current best first
-          cur = 0;
-          if (bestlen >= size_rem || lds_byte(win, lp + bestlen) == lds_byte(win, lc + bestlen)) {
-            comparing = true;
-            // lz77.c:481-490: skip the common run (pure acceleration)
-            if (same_pos > 2 && lds_byte(win, lp) == lds_byte(win, lc)) {
-              u32 s = same_pos < L.z ? same_pos : L.z;
-              cur = s < limit ? s : limit;
-            }
-          }
-        }
-        if (comparing) {  // GetMatch (lz77.c:297), 4 bytes per step
-          const u32 rem = limit - cur;
-          if (rem == 0) {
-            comparing = false;
-          } else {
-            const u32 x = lds_u32_unaligned(win, lp + cur) ^ lds_u32_unaligned(win, lc + cur);
-            u32 m = x ? (u32)(__ffs((int)x) - 1) >> 3 : 4u;
-            if (m > rem) m = rem;
-            cur += m;
-            if (m < 4 || cur >= limit) comparing = false;
-          }
-        }
-        if (!comparing) {
-          if (cur > bestlen) {  // lz77.c:495-505: new change point of sublen
-            // (a 2-byte "match" only moves bestlength; sublen[2] is never read)
-            if (cur < 3) {
-            } else if (ncp < 8) {
-              u8* b = reinterpret_cast<u8*>(rec) + 8 + 3 * ncp;
-              b[0] = (u8)(cur - 3);
-              b[1] = (u8)(dist & 255);
-              b[2] = (u8)(dist >> 8);
-            } else if (ncp < SCRATCH_CPS) {
-              my_scratch[ncp] = cur | (dist << 16);
-            }
-            if (cur >= 3) ++ncp;
-            bestlen = cur;
-            bestdist = dist;
-            if (cur >= limit) finish = true;
-          }
-          if (!finish) {
-            // lz77.c:509-519: switch to the run-length hash; on chain 1 the 3-byte
-            // hashes are equal, so val2 equality is equality of ((same-3)&255)
-            if (chain == 1 && bestlen >= same_pos && (((u32)L.z - 3u) & 255u) == ((same_pos - 3u) & 255u)) chain = 2;
-            const u32 step = chain == 1 ? L.x : L.y;
-            if (step == 0) {
-              finish = true;                            // lz77.c:521-523
-            } else {
-              lc -= step;
-              dist += step;
-              --hits_left;
-              if (dist >= ZMX_WINDOW || hits_left <= 0) finish = true;  // lz77.c:464, 527-530
-              else L = lk[pos - dist - ws];
-            }
-          }
-          if (finish) {
-            pending = true;
-            active = false;
-          }
-        }
-      }
-    }
-  }
 }
 
 // Match records of a block that lies inside a block of an earlier table: the records of all
@@ -531,14 +341,8 @@ __device__ __forceinline__ uint2 greedy_window(const u32* rbase, u32 wb, u32 lan
 //     k_edges   (every run, all CUs)    cost(k, sublen[k]) of every edge
 //         (squeeze.c:146-157; depends on the run's cost model, not on the DP
 //         state), one lane per edge, written as doubles to rows[] in HBM.
-//     k_dp   (every run, one wave per block)  the serial part: the chain
-//         through the float-rounded absolute costs.  The live cells
-//         costs[j .. j+258] stay in registers (lane l owns cells base + 64 s +
-//         l of the current 64-position group), the cost of the expanding
-//         position is a v_readlane, edge rows stream HBM -> LDS ring by
-//         LDS-DMA one ring ahead, and 8 positions of row values are preloaded
-//         into registers so that no memory latency sits on the chain.
-//     zmx_dp3.h  k_dp3: the same chain with the row fetching on producer waves (default).
+//     zmx_dp4.h  (every run)  the chain through the float-rounded absolute costs, cut into
+//         verified tasks (k_dp4_spec / k_dpcheck / k_dp4_fix).
 //     zmx_trace.h  TraceBackwards + FollowPath + histogram, segmented (k_trace_exits /
 //         k_trace_link / k_trace_emit).
 // ----------------------------------------------------------------------------
@@ -608,6 +412,7 @@ struct EdgeParams {
   const u64* row_base;     // [nb_total] first row slot of each block (in doubles)
   const double* mincost;   // [nb_total]
   u32* badpos;             // bit per position (pos_off + p): a match edge of it costs less than mincost (zeroed per run)
+  const u64* block_edges;  // [nb_total] rows of each block
 };
 
 __global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
@@ -636,7 +441,7 @@ __global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
   const uint2* dbase = P.dph + bd.pos_off;
   double* rows = P.rows + P.row_base[b];
   // squeeze.c:293's mincost test is a no-op unless an edge costs less than mincost (possible only
-  // through rounding in the cost model): such positions are reported, k_dp3 tests them literally
+  // through rounding in the cost model): such positions are reported, the chain kernel tests them literally
   const double mincost = P.mincost[b];
 
   for (u32 i = tid; i < 288; i += 256) s_ll[i] = P.cost[(u64)b * 320 + i];
@@ -650,6 +455,8 @@ __global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
   __syncthreads();
   const double kInf = __longlong_as_double(0x7ff0000000000000ll);
   u8* mark = s_mark[wid];
+  // one +inf behind the block's rows: where k_dp5_spec points the lanes that lie outside a row
+  if (tp0 == 0 && tid == 0) rows[(P.block_edges[b] + 127u) & ~(u64)127u] = kInf;   // (DP_PIECE = 128)
 
   for (u32 g = wid; g < MT / 64; g += 4) {
     const u32 base = tp0 + g * 64;
@@ -772,7 +579,7 @@ __global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
   }
 }
 
-// ------------------------------------------------------------------ k_dp
+// ------------------------------------------- shared by the chain kernels (zmx_dp4.h)
 #define ZMX_PROF_N 32u                // u64 profiling counters per block (ZOPFLI_AMD_PROF)
 #define DP_RING 4096u                 // doubles in the LDS ring (32 KB)
 #define DP_PIECE 128u                 // doubles per LDS-DMA instruction (64 lanes x 16 B)
@@ -780,23 +587,6 @@ __global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
 #define DP_XN 704u                    // long-run shortcut staging: 384 cells
 #define DP_FRONT 64u                  // slack before the ring: masked-off lanes address up to 64 slots back
 #define DP_MIRROR 384u                // the first 3 pieces are mirrored behind the ring: a row never wraps
-
-struct DpParams {
-  const BlockDesc* blocks;
-  u32 block0;              // first block of this launch
-  const uint2* dph;
-  const double* cost;      // [nb_total][320]
-  const double* mincost;   // [nb_total]
-  const double* rows;
-  const u64* row_base;
-  const u64* block_edges;
-  u16* la;
-  u64* prof;               // optional [nb_total][8] cycle counters (ZOPFLI_AMD_PROF=1), else null
-  int debug_nofetch;       // timing experiment (profiling build only): producers build nothing, results are wrong
-  const u32* recs;         // k_sq: the match records and the change-point pool
-  const u32* pool;
-  const u32* badpos;       // k_edges' bad-edge bitmap (k_dp3)
-};
 
 // One position of the chain on cell register `CS` (round S): the edge values `WV`
 // were preloaded, invalid lanes hold +inf.  MCL = mincost (or -inf on the literal
@@ -823,251 +613,4 @@ __device__ __forceinline__ void dp_dma_piece(const double* lane_src, u32 lds_byt
       : "=&s"(keep)
       : "v"(lane_src), "s"(lds_byte_off)
       : "memory");
-}
-
-// Eight consecutive positions p0..p0+7 of a group, none with an edge beyond cell
-// register 1 (TWO) / 0 (!TWO): straight-line code.  The row values are fetched
-// first (one readlane + one ds_read per position and register), then the chain
-// runs on registers only.
-template <bool TWO>
-__device__ __forceinline__ void dp_fast_block(const double* ring0, const uint2* tab, u32 p0, u32 lane, u32 base,
-                                              double mincost, float& c0, u32& l0, float& c1, u32& l1) {
-  const double kInf = __longlong_as_double(0x7ff0000000000000ll);
-  double w0[8], w1[8], mcl0[8];
-  u32 ke8[8];
-  const u32 d0 = lane - p0 - 1;                         // k - 1 of register 0 at u = 0
-  // tab[p] = {byte offset of row[0] from ring0, kend} (an LDS broadcast read: a v_readlane would
-  // cost an SGPR round trip of ~35 cycles per position on a lone wave)
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const uint2 t = tab[p0 + u];
-    ke8[u] = t.y;
-    const double* row = reinterpret_cast<const double*>(reinterpret_cast<const char*>(ring0) + (int)t.x);
-    w0[u] = row[lane];                                  // row[lane] = edge k = lane - p
-    if (TWO) w1[u] = row[lane + 64];
-  }
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const u32 km1 = d0 - u;
-    w0[u] = km1 < ke8[u] ? w0[u] : kInf;
-    mcl0[u] = km1 == 0 ? -kInf : mincost;
-    if (TWO) w1[u] = km1 + 64 < ke8[u] ? w1[u] : kInf;
-  }
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const u32 p = p0 + u;
-    const double cj = (double)rdlane_f32(c0, p);
-    const u32 src1 = base + p + 1;
-    DP_RELAX(c0, l0, w0[u], mcl0[u])
-    if (TWO) {
-      const double mcl1 = lane + 63u == p ? -kInf : mincost;   // position 63's literal edge
-      DP_RELAX(c1, l1, w1[u], mcl1)
-    }
-  }
-}
-
-template <bool PROF>
-__global__ __launch_bounds__(64) void k_dp(DpParams P) {
-  __shared__ __align__(16) double s_ring[DP_FRONT + DP_RING + DP_MIRROR];
-  __shared__ float s_xc[DP_XN];
-  __shared__ u16 s_xl[DP_XN];
-  __shared__ uint2 s_tab[64];   // per position of the group: row byte offset from the ring start, kend
-
-  const u32 b = P.block0 + blockIdx.x;
-  const BlockDesc bd = P.blocks[b];
-  const u32 B = (u32)(bd.inend - bd.instart);
-  const u32 lane = threadIdx.x;
-  if (B == 0) return;
-  const uint2* dbase = P.dph + bd.pos_off;
-  u16* la = P.la + bd.la_off;
-  const double* rows = P.rows + P.row_base[b];
-  const u32 total_pad = (u32)((P.block_edges[b] + DP_PIECE - 1) & ~(u64)(DP_PIECE - 1));
-
-  const double mincost = P.mincost[b];
-  // squeeze.c:260: cost of (length 258, dist 1) = (0 + 0) + ll[285] + d[0]
-  const double symbolcost258 = (double)(0 + 0) + P.cost[(u64)b * 320 + 285] + P.cost[(u64)b * 320 + 288];
-  const double kInf = __longlong_as_double(0x7ff0000000000000ll);
-  const u32 ring_lds = (u32)(unsigned long)(__attribute__((address_space(3))) double*)s_ring;
-
-  u64 t_stage = 0, t_chain = 0, t_mark = 0, n_fast = 0, n_slow = 0, t_fast = 0, n_two = 0, t_two = 0;
-  const bool prof = PROF && P.prof != nullptr;   // the counters exist only in the profiling instantiation
-#define DP_TICK() (PROF ? (u64)__builtin_readcyclecounter() : 0ull)
-
-  // cost cells of the current group: c[s] of lane l = cell base + 64 s + l; l[s] = 1 + the
-  // position the cell was reached from (0 = never), so length_array = cell + 1 - l[s]
-  float c[6];
-  u32 l[6];
-#pragma unroll
-  for (int s = 0; s < 6; ++s) { c[s] = 1e30f; l[s] = 0; }
-  if (lane == 0) c[0] = 0.0f;
-
-  u32 base = 0;
-  u32 loaded_end = 0;          // rows [.., loaded_end) have been requested into the ring
-  bool noshort = false;        // the reference tests the shortcut once per loop iteration (squeeze.c:247-251)
-  u32 pf_base = 0xffffffffu;
-  uint2 pf_dh = make_uint2(0, 0);
-
-  while (base <= B) {
-    t_mark = DP_TICK();
-    const u32 navail = (B - base < 64u) ? B - base : 64u;
-    const u32 jj = base + lane;
-    const bool act = lane < navail;
-    uint2 dh = pf_dh;
-    if (pf_base != base) dh = dbase[jj < B ? jj : B - 1];   // first group, or a shortcut moved the group start
-    pf_base = base + 64;
-    pf_dh = dbase[jj + 64 < B ? jj + 64 : B - 1];            // next group, one group ahead (clamped, unconditional)
-
-    const u32 kend = act ? (dh.y & 0xffffu) : 0u;
-    const bool sflag = act && (dh.y >> 16) != 0;
-    const u32 roff = dh.x;
-    const u32 offend = roff + kend;
-    __syncthreads();   // the previous group's table is dead
-    s_tab[lane] = make_uint2(((roff & (DP_RING - 1)) - lane - 1) * 8u, kend);
-    const u64 m_short = __ballot(sflag);
-    const u64 m_r1 = __ballot(kend + lane >= 64u);     // position needs cell register 1
-    const u64 m_r2 = __ballot(kend + lane >= 128u);    // ... and 2 or more: generic path
-
-    u32 q = 0;
-    bool regroup = false;
-    while (q < navail) {
-      // ---- sub-chunk: positions q .. q+n-1 whose rows span at most DP_SPAN from a_cur
-      const u32 off_q = rdlane_u32(roff, q);
-      const u32 a_cur = off_q & ~(DP_PIECE - 1);
-      const u64 fit = __ballot(act && lane >= q && offend - a_cur <= DP_SPAN);
-      const u32 n = (u32)__popcll(fit);
-      const u32 need_end = (rdlane_u32(offend, q + n - 1) + DP_PIECE - 1) & ~(DP_PIECE - 1);
-      // everything requested so far has landed; top the ring up to a_cur + DP_RING
-      // (the youngest VMEM op of a group's first sub-chunk is the dph prefetch: leave it in flight)
-      if (q == 0) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      {
-        const u32 lim = a_cur + DP_RING < total_pad ? a_cur + DP_RING : total_pad;
-        const bool cold = loaded_end < need_end;
-        while (loaded_end < lim) {
-          const u32 slot = loaded_end & (DP_RING - 1);
-          dp_dma_piece(rows + loaded_end + lane * 2, ring_lds + (DP_FRONT + slot) * 8);
-          if (slot < DP_MIRROR) dp_dma_piece(rows + loaded_end + lane * 2, ring_lds + (DP_FRONT + DP_RING + slot) * 8);
-          loaded_end += DP_PIECE;
-        }
-        if (cold) {  // first sub-chunk of the block (or a jump after a shortcut)
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();
-        }
-      }
-      { const u64 t = DP_TICK(); t_stage += t - t_mark; t_mark = t; }
-
-      // ---- the serial chain over positions q .. q+n-1, 8 at a time
-      u32 p0 = q;
-      while (p0 < q + n) {
-        const bool full = p0 + 8 <= q + n;
-        const u32 sbits = (u32)(m_short >> p0) & 255u;
-        const u32 r2bits = (u32)(m_r2 >> p0) & 255u;
-        if (full && sbits == 0 && r2bits == 0) {
-          // ---- fast path: straight-line code, edge values preloaded
-          const u64 tf0 = DP_TICK();
-          if (((u32)(m_r1 >> p0) & 255u) != 0) {
-            dp_fast_block<true>(s_ring + DP_FRONT, s_tab, p0, lane, base, mincost, c[0], l[0], c[1], l[1]);
-            n_two += 8;
-            t_two += DP_TICK() - tf0;
-          } else {
-            dp_fast_block<false>(s_ring + DP_FRONT, s_tab, p0, lane, base, mincost, c[0], l[0], c[1], l[1]);
-          }
-          t_fast += DP_TICK() - tf0;
-          noshort = false;
-          n_fast += 8;
-          p0 += 8;
-          continue;
-        }
-        // ---- generic path (ragged tail, long matches, shortcut candidates)
-        const u32 pend = full ? p0 + 8 : q + n;
-        u32 p = p0;
-        for (; p < pend; ++p) {
-          if (((m_short >> p) & 1) && !noshort) { regroup = true; break; }
-          noshort = false;
-          const u32 ke = rdlane_u32(kend, p);
-          const u32 ro = rdlane_u32(roff, p);
-          const double cj = (double)rdlane_f32(c[0], p);
-          const u32 src1 = base + p + 1;
-          const u32 km1 = lane - p - 1;
-          const u32 smax = (ke + p) >> 6;
-#pragma unroll
-          for (int s = 0; s < 6; ++s) {
-            if ((u32)s <= smax) {
-              const u32 k1 = km1 + 64u * s;
-              if (k1 < ke) {
-                const double w = s_ring[DP_FRONT + ((ro + k1) & (DP_RING - 1))];
-                const double mcl = k1 == 0 ? -kInf : mincost;
-                DP_RELAX(c[s], l[s], w, mcl)
-              }
-            }
-          }
-        }
-        n_slow += p - p0;
-        p0 = p;
-        if (regroup) break;
-      }
-      { const u64 t = DP_TICK(); t_chain += t - t_mark; t_mark = t; }
-      if (regroup) {
-        // ---- long-run shortcut at position p0 of the group (squeeze.c:251-271)
-        const u32 p = p0;
-        const u32 j = base + p;
-        if (lane < p && base + lane >= 1) la[base + lane] = (u16)(l[0] ? base + lane + 1 - l[0] : 0u);
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 6; ++s) {
-          const u32 x = base + 64u * s + lane;
-          s_xc[64 * s + lane] = c[s];
-          s_xl[64 * s + lane] = (u16)(l[s] ? x + 1 - l[s] : 0u);
-        }
-        __syncthreads();
-        // costs[j+t+258] = costs[j+t] + symbolcost for t = 0..257, unconditionally; cells
-        // j..j+257 are consumed with the lengths they have now
-        float nc4[5];
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-          const u32 t = 64u * r + lane;
-          nc4[r] = 1e30f;
-          if (t < ZMX_MAX_MATCH) {
-            la[j + t] = s_xl[p + t];
-            nc4[r] = (float)((double)s_xc[p + t] + symbolcost258);
-          }
-        }
-        // new group at j + 258: cell j+258+t <- nc4 (reached from j+t), everything beyond is untouched
-#pragma unroll
-        for (int s = 0; s < 6; ++s) { c[s] = 1e30f; l[s] = 0; }
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-          const u32 t = 64u * r + lane;
-          if (t < ZMX_MAX_MATCH) { c[r] = nc4[r]; l[r] = j + t + 1; }
-        }
-        base = j + ZMX_MAX_MATCH;
-        noshort = true;   // squeeze.c:273 continues with the match query at the new i
-        // rows between the old and the new position are never read: restart the ring there
-        {
-          const u32 nb_ = base < B ? base : B - 1;
-          const u32 ro = dbase[nb_].x & ~(DP_PIECE - 1);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();
-          if (ro > loaded_end) loaded_end = ro;
-        }
-        break;
-      }
-      q += n;
-    }
-    if (regroup) continue;
-
-    // ---- group done: cells base..base+63 are final
-    if (jj <= B && jj >= 1) la[jj] = (u16)(l[0] ? jj + 1 - l[0] : 0u);
-#pragma unroll
-    for (int s = 0; s < 5; ++s) { c[s] = c[s + 1]; l[s] = l[s + 1]; }
-    c[5] = 1e30f;
-    l[5] = 0;
-    base += 64;
-  }
-  if (lane == 0) la[0] = 0;
-  if (prof && lane == 0) {
-    u64* o = P.prof + (u64)b * ZMX_PROF_N;
-    o[0] = t_stage; o[1] = t_chain; o[2] = n_fast; o[3] = n_slow; o[4] = B; o[5] = t_fast; o[6] = n_two; o[7] = t_two;
-  }
 }

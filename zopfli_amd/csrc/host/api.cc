@@ -17,6 +17,7 @@
 
 // implemented by the device layer: kernel-only seconds / launches of the squeeze kernel
 extern "C" void zmx_internal_kernel_stats(double* seconds3, double* squeeze_launches, int reset);
+extern "C" void zmx_internal_seg_stats(double* out8, int reset);
 // implemented by the device layer: size of the resident input
 extern "C" size_t zmx_internal_input_size(zmx_ctx* ctx);
 // implemented by the device layer: the caller's host copy of the resident input (borrowed)
@@ -90,8 +91,9 @@ void EmitChunks(const std::vector<zamd::Chunk>& chunks, const unsigned char* in,
 
 void ResetTiming() {
   zamd::ThreadTiming() = zamd::Timing();
-  double a[3], b;
+  double a[8], b;
   zmx_internal_kernel_stats(a, &b, 1);
+  zmx_internal_seg_stats(a, 1);
 }
 
 void PushByte(unsigned v, unsigned char** out, size_t* outsize) {
@@ -297,6 +299,11 @@ int zmx_last_timing(double* out8) {
 
 int zmx_last_kernel_timing(double* out4) {
   zmx_internal_kernel_stats(out4, &out4[3], 0);
+  return 0;
+}
+
+int zmx_last_seg_stats(double* out8) {
+  zmx_internal_seg_stats(out8, 0);
   return 0;
 }
 

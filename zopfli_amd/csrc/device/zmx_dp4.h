@@ -330,6 +330,9 @@ struct Dp4Params {
   u32* stats;              // [8] tasks / accepted / re-run: state, level, tie / positions re-run / re-run: values
   float level_scale;       // test hook (ZOPFLI_AMD_SEG_SCALE): the guessed levels are multiplied by this
   const u32* order;        // SPEC: launch order of the tasks (the long head tasks first), indexed from task0
+  const void* dsc;         // k_dp5_spec: one row descriptor per block position (k_mkdesc)
+  const u32* winflag;      // k_dp5_spec: per 32-position window, 1 = can take the fast path (k_mkdesc)
+  const u32* win_off;      // [nb_total] first window of each block in winflag[]
 };
 
 // What one pass of the four waves over a stretch of the chain does.
@@ -588,7 +591,7 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
             if ((u32)s <= smax) {
               const u32 k1 = km1 + 64u * s;
               if (k1 < ke) {
-                const double w = s_ring[DP_FRONT + ((ro + k1) & (DP_RING - 1))];
+                const double w = row_code(s_ring[DP_FRONT + ((ro + k1) & (DP_RING - 1))]);
                 const double mcl = k1 == 0 ? -kInf : mincost;
                 DP_RELAX(c[s], l[s], w, mcl)
               }
@@ -804,8 +807,8 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
           const u32 da = lane - pa - 1, db = lane + 32u - pb - 1;
 #pragma unroll
           for (int u = 0; u < 16; ++u) {
-            t1[(pa + u) * 64 + lane] = da - u < ta[u].y ? va[u] : kInf;
-            t1[(pb + u) * 64 + lane] = db - u < tb[u].y ? vb[u] : kInf;
+            t1[(pa + u) * 64 + lane] = da - u < ta[u].y ? row_code(va[u]) : kInf;
+            t1[(pb + u) * 64 + lane] = db - u < tb[u].y ? row_code(vb[u]) : kInf;
           }
           const u64 tk1c = D3_TICK();
           __syncthreads();
@@ -829,7 +832,7 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
 #pragma unroll
               for (int u = 0; u < 16; ++u) v0[u] = reinterpret_cast<const double*>(ring0 + (int)t[u].x)[wl];   // row[x] = edge k = x - p
 #pragma unroll
-              for (int u = 0; u < 16; ++u) t1[(p0 + u) * 64 + lane] = d0 - u < t[u].y ? v0[u] : kInf;
+              for (int u = 0; u < 16; ++u) t1[(p0 + u) * 64 + lane] = d0 - u < t[u].y ? row_code(v0[u]) : kInf;
             }
             p0 += 8;
             continue;
@@ -844,7 +847,7 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
 #pragma unroll
             for (int u = 0; u < 8; ++u) v0[u] = reinterpret_cast<const double*>(ring0 + (int)t[u].x)[wl];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t1[(p0 + u) * 64 + lane] = d0 - u < t[u].y ? v0[u] : kInf;
+            for (int u = 0; u < 8; ++u) t1[(p0 + u) * 64 + lane] = d0 - u < t[u].y ? row_code(v0[u]) : kInf;
           } else {
             double v0[8], v1[8];
 #pragma unroll
@@ -855,8 +858,8 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-              t1[(p0 + u) * 64 + lane] = d0 - u < t[u].y ? v0[u] : kInf;
-              t2[((p0 + u) & 31) * 64 + lane] = d0 - u + 64 < t[u].y ? v1[u] : kInf;
+              t1[(p0 + u) * 64 + lane] = d0 - u < t[u].y ? row_code(v0[u]) : kInf;
+              t2[((p0 + u) & 31) * 64 + lane] = d0 - u + 64 < t[u].y ? row_code(v1[u]) : kInf;
             }
           }
         }

@@ -12,17 +12,69 @@
 //
 //     lane l of row u  =  rows[roff_u + l - u - 1]   if 0 <= l - u - 1 < kend_u, else +inf
 //
-// with everything per position on the scalar side: {roff, kend} arrive by s_load (uniform address),
-// the row's lane mask is ((1 << kend) - 1) << (u + 1) in an SGPR pair, the row's base address an
-// SGPR pair, and lanes outside the row are pointed at one +inf that k_edges leaves behind the
-// block's rows — 2 VALU instructions and one global_load_dwordx2 per position, then the 8-instruction
-// chain step of k_dp4.  Other windows (long matches, shortcut flags, edges below mincost, ragged
+// with everything per position on the scalar side: a ready-made buffer descriptor whose buffer IS
+// the row (base rows + roff, kend * 8 bytes; k_mkdesc) arrives by s_load (uniform address); lane l
+// asks for offset 8 (l - u - 1), which wraps below the row and overshoots beyond it, so the
+// hardware's range check drops those lanes before they reach the L1 (a plain 64-lane load of 8 bytes
+// per lane costs ~17 L1 accesses whatever the lanes point at: measured, the kernel was L1-bound)
+// and returns zero for them, which the row encoding (ZMX_ROW_KEY) turns into an edge nobody takes —
+// 2 VALU instructions and one buffer_load_dwordx2 per position, then the 8-instruction chain step
+// of k_dp4.  Other windows (long matches, shortcut flags, edges below mincost, ragged
 // tails) take the generic path, position by position, with the reference's tests literally.
 #pragma once
 
-struct D5Cls {          // one window: lane l < 32 = position wbase + l
+// A pointer every lane holds the same value of, as the compiler can see it (an SGPR pair).
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+  const u64 a = reinterpret_cast<u64>(p);
+  const u32 lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)a), hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(a >> 32));
+  return reinterpret_cast<T*>(((u64)hi << 32) | lo);
+}
+// dph[] through the scalar cache: it is written by k_rowscan long before this kernel, and the
+// constant address space is what makes the compiler use s_load for it although the kernel stores
+// to other global arrays in between
+typedef u32 d5_u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) d5_u32x4* d5_cdscp;
+
+// One buffer descriptor per block position whose buffer IS the position's edge row: base = its first
+// slot in rows[], kend * 8 bytes long (k_mkdesc, whenever the table set meets a new rows[] array).
+struct MkDescParams {
+  const BlockDesc* blocks;
+  const uint2* dph;
+  const u64* row_base;
+  const double* rows;
+  d5_u32x4* dsc;
+  const u32* win_off;   // [nb] first entry of each block in winflag[]
+  u32* winflag;         // per 32-position window of a block (aligned to the block start): 1 = 32 positions, none flagged
+                        // for the long-run shortcut, none with an edge beyond cell register 0 of a window at that place
+};
+
+__global__ __launch_bounds__(256) void k_mkdesc(MkDescParams P) {
+  const BlockDesc bd = P.blocks[blockIdx.y];
+  const u32 B = (u32)(bd.inend - bd.instart);
+  const u32 p = blockIdx.x * 256u + threadIdx.x;
+  const u32 lane = threadIdx.x & 63;
+  uint2 dhw = make_uint2(0, 0);
+  if (p < B) dhw = P.dph[bd.pos_off + p];
+  // (whole waves take part in the ballot; a wave covers two windows)
+  const u64 notfast = __ballot(p >= B || (dhw.y >> 16) != 0 || (dhw.y & 0xffffu) + (lane & 31u) >= 64u);
+  if ((lane & 31u) == 0 && p < B) {
+    P.winflag[P.win_off[blockIdx.y] + (p >> 5)] = ((u32)(notfast >> (lane & 32u)) == 0) ? 1u : 0u;
+  }
+  if (p >= B) return;
+  const uint2 dh = dhw;
+  const u64 a = reinterpret_cast<u64>(P.rows + P.row_base[blockIdx.y] + dh.x);
+  d5_u32x4 d;
+  d.x = (u32)a;
+  d.y = (u32)(a >> 32) & 0xffffu;     // stride 0
+  d.z = (dh.y & 0xffffu) * 8u;        // bytes in the row
+  d.w = 0x00020000u;                  // raw 32-bit data format
+  P.dsc[bd.pos_off + p] = d;
+}
+
+struct D5Cls {          // one window on the generic path: lane l < 32 = position wbase + l
   u32 kend, roff;
-  u64 ms, m_r1, m_bad;  // flagged for the long-run shortcut / reach beyond cell register 0 / edge below mincost
+  u64 ms;               // flagged for the long-run shortcut
   u32 nav;
 };
 
@@ -32,13 +84,15 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
   const u32 lane = threadIdx.x & 63;
   const u32 lane8 = lane * 8u;
   const u32 B = (u32)(bd.inend - bd.instart);
-  const uint2* __restrict__ dbase = P.dph + bd.pos_off;
-  const u32* __restrict__ badpos = P.badpos + (bd.pos_off >> 5);
+  const uint2* __restrict__ dbase = uniform_ptr(P.dph + bd.pos_off);
+  const u32* __restrict__ badpos = uniform_ptr(P.badpos + (bd.pos_off >> 5));
   const u32 bit_off = (u32)(bd.pos_off & 31);
   u16* la = P.la + bd.la_off;
-  const double* __restrict__ rows = P.rows + P.row_base[b];
-  // k_edges leaves one +inf at the first padded slot behind the block's rows
-  const u32 tail_bytes = (u32)(((P.block_edges[b] + DP_PIECE - 1) & ~(u64)(DP_PIECE - 1)) * 8u);
+  const double* __restrict__ rows = uniform_ptr(P.rows + P.row_base[b]);
+  const d5_u32x4* __restrict__ dsc = uniform_ptr(static_cast<const d5_u32x4*>(P.dsc) + bd.pos_off);
+  typedef const __attribute__((address_space(4))) u32* cu32p;
+  const cu32p winflag = (cu32p)uniform_ptr(P.winflag + P.win_off[b]);
+  const cu32p badw = (cu32p)badpos;
   const double mincost = P.mincost[b];
   const double symbolcost258 = (double)(0 + 0) + P.cost[(u64)b * 320 + 285] + P.cost[(u64)b * 320 + 288];
   const double kInf = __longlong_as_double(0x7ff0000000000000ll);
@@ -67,7 +121,40 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
   u64 n_fast = 0, n_slow = 0;
   const u64 t_begin = PROF ? (u64)__builtin_readcyclecounter() : 0ull;
 
+  // rows of positions WB + U0 .. WB + U0 + 15 into WV: the row is the buffer; lanes below u + 1 (the
+  // offset wraps) and beyond u + kend are out of range, never reach the cache and come back as
+  // zero = 2^1023 decoded
+#define D5_ISSUE(WV, WB, U0)                                                                      \
+  {                                                                                               \
+    const d5_cdscp dw_ = (d5_cdscp)(dsc + (WB) + (U0));     /* uniform: s_load */                  \
+    _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                              \
+      const d5_u32x4 d_ = dw_[u];                                                                 \
+      const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                       \
+          reinterpret_cast<void*>(((u64)d_.y << 32) | d_.x), (short)0, (int)d_.z, (int)d_.w);     \
+      const auto x_ = __builtin_amdgcn_raw_buffer_load_b64(rs_, (int)(lane8 - 8u * (u32)((U0) + u + 1)), 0, 0); \
+      WV[u] = __longlong_as_double((long long)(((u64)(x_[1] ^ (u32)(ZMX_ROW_KEY >> 32)) << 32) | x_[0])); \
+    }                                                                                             \
+  }
+  // the chain over positions U0 .. U0 + 15 of the window at wbase
+#define D5_CHAIN(WV, U0)                                                                          \
+  {                                                                                               \
+    _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                              \
+      const double cj = (double)rdlane_f32(c[0], (u32)((U0) + u));                                \
+      D3_RELAX_K(c[0], lt_, WV[u], (u32)((U0) + u + 1))                                           \
+    }                                                                                             \
+  }
+  // a window that can take the fast path: at a multiple of 32 from the block start, statically
+  // clean (k_mkdesc) and without an edge below mincost in this run (k_edges' bitmap)
+  auto is_clean = [&](u32 wb) -> bool {
+    if ((wb & 31u) != 0 || wb + 32u > B) return false;
+    if (winflag[wb >> 5] == 0) return false;
+    const u32 g = bit_off + wb;
+    const u64 two = ((u64)badw[(g >> 5) + 1] << 32) | badw[g >> 5];
+    return (u32)(two >> (g & 31u)) == 0;
+  };
+  u32 touched = 0, sink = 0;
   while (wbase < J.pend) {          // (J.pend = B + 1 on the last task: the window at B retires cell B)
+    wbase = (u32)__builtin_amdgcn_readfirstlane((int)wbase);
     if (J.spec && la_lo == SEG_NONE && wbase >= J.pout) {
       // the first window at or after pout: from here on the task owns the length_array; what the
       // registers hold now is compared with the predecessor's exit state
@@ -77,50 +164,48 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
       la_lo = wbase;
       vmax = 0.0f;
     }
-    // ---- the window's positions
-    D5Cls W;
-    W.nav = B - wbase < 32u ? B - wbase : 32u;
-    {
-      const u32 jj = wbase + lane;
-      const bool act = lane < W.nav;
-      const u32 cur = jj < B ? jj : B - 1;
-      const uint2 dh = dbase[cur];
-      const u32 bw = badpos[(bit_off + cur) >> 5];
-      W.kend = act ? (dh.y & 0xffffu) : 0u;
-      W.roff = dh.x;
-      W.ms = __ballot(act && (dh.y >> 16) != 0);
-      W.m_r1 = __ballot(W.kend + lane >= 64u);
-      W.m_bad = __ballot(act && ((bw >> ((bit_off + cur) & 31u)) & 1u) != 0);
-    }
-    if (noshort) W.ms &= ~1ull;      // squeeze.c:273: the position right after a shortcut is not tested again
     bool jumped = false;
-    if (W.nav == 32u && (W.ms | W.m_r1 | W.m_bad) == 0) {
-      // ---- 32 positions, one cell register, no flags: rows straight into registers, then the chain
-      const uint2* __restrict__ dw = dbase + wbase;    // uniform: s_load
-      double wv[32];
-#pragma unroll
-      for (int u = 0; u < 32; ++u) {
-        const uint2 dh = dw[u];
-        const u32 ke = dh.y & 0xffffu;
-        const u64 mask = ((1ull << ke) - 1ull) << (u + 1);           // lanes u + 1 .. u + kend (kend + u < 64 here)
-        const bool valid = __builtin_amdgcn_inverse_ballot_w64(mask);
-        const int soff = (int)(dh.x - (u32)(u + 1)) * 8;              // byte offset of lane 0's slot, may be < 0
-        const char* sa = reinterpret_cast<const char*>(rows) + (long long)soff;
-        const u32 vo = valid ? lane8 : tail_bytes - (u32)soff;        // outside the row: the +inf behind the rows
-        wv[u] = *reinterpret_cast<const double*>(sa + vo);
+    const bool fastwin = is_clean(wbase);
+    if (fastwin) {
+      // ---- 32 positions, one cell register, no flags: the rows come straight into registers, then
+      //      the chain (the other waves of the SIMD run while this one waits for its rows: requesting the
+      //      next window's rows before this window's chain was measured slower — 188 registers, two
+      //      waves per SIMD instead of four)
+      double wv0[16], wv1[16];
+      D5_ISSUE(wv0, wbase, 0)
+      D5_ISSUE(wv1, wbase, 16)
+      // Touch the rows of the next window (one word per 128-byte line over 8 KB from its first row) so
+      // that they are on their way from HBM to the L2 while this window's chain runs; the word read is
+      // folded into `sink` an iteration later, when it has long arrived.
+      sink ^= touched;
+      touched = 0;
+      if (wbase + 32u < B) {
+        const d5_u32x4 dn = ((d5_cdscp)(dsc + wbase + 32u))[0];
+        const char* tp = reinterpret_cast<const char*>(((u64)dn.y << 32) | dn.x);
+        touched = *reinterpret_cast<const u32*>(tp + lane * 128u);
       }
-      u32 lt = 0;                              // 1 + index of the last position that updated the cell
-#pragma unroll
-      for (int u = 0; u < 32; ++u) {
-        const double cj = (double)rdlane_f32(c[0], (u32)u);
-        D3_RELAX_K(c[0], lt, wv[u], (u32)(u + 1))
-      }
-      l[0] = lt ? wbase + lt : l[0];
+      u32 lt_ = 0;                             // 1 + index of the last position that updated the cell
+      D5_CHAIN(wv0, 0)
+      D5_CHAIN(wv1, 16)
+      l[0] = lt_ ? wbase + lt_ : l[0];
       reach = reach > 63 ? reach : 63;
       noshort = false;
       n_fast += 32;
     } else {
       // ---- position by position
+      D5Cls W;
+      W.nav = B - wbase < 32u ? B - wbase : 32u;
+      {
+        const u32 jj = wbase + lane;
+        const bool act = lane < W.nav;
+        const u32 cur = jj < B ? jj : B - 1;
+        const uint2 dh = dbase[cur];
+        const u32 bw = badpos[(bit_off + cur) >> 5];
+        W.kend = act ? (dh.y & 0xffffu) : 0u;
+        W.roff = dh.x;
+        W.ms = __ballot(act && (dh.y >> 16) != 0);
+      }
+      if (noshort) W.ms &= ~1ull;      // squeeze.c:273: the position right after a shortcut is not tested again
       for (u32 p = 0; p < W.nav; ++p) {
         const u32 j = wbase + p;
         if ((W.ms >> p) & 1) {
@@ -173,7 +258,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
           if ((u32)s <= smax) {
             const u32 k1 = km1 + 64u * s;
             if (k1 < ke) {
-              const double w = rows[ro + k1];
+              const double w = row_code(rows[ro + k1]);
               const double mcl = k1 == 0 ? -kInf : mincost;
               DP_RELAX(c[s], l[s], w, mcl)
             }
@@ -193,7 +278,10 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
       wbase += 32;
     }
   }
+#undef D5_ISSUE
+#undef D5_CHAIN
   if (J.la_lo == 1 && lane == 0) la[0] = 0;   // the head of the block
+  if ((sink ^ touched) == 0x9e3779b9u && lane == 77u) la[0] = 1;   // (never: lane < 64; keeps the touches alive)
   if (J.exit) {
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
@@ -210,11 +298,14 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
     atomicAdd(&o[2], n_fast); atomicAdd(&o[3], n_slow); atomicAdd(&o[4], n_fast + n_slow);
     atomicAdd(&o[5], (u64)__builtin_readcyclecounter() - t_begin); atomicAdd(&o[6], n_fast);
     atomicAdd(&o[14], n_slow);
+    const u64 dt = (u64)__builtin_readcyclecounter() - t_begin;
+    atomicMax(&o[7], dt);                               // the longest task of the block
+    if (J.la_lo == 1) atomicAdd(&o[8], dt);             // the head task
   }
 }
 
-template <bool PROF>
-__global__ __launch_bounds__(64) void k_dp5_spec(Dp4Params P) {
+template <bool PROF, int WAVES>
+__global__ __launch_bounds__(64, WAVES) void k_dp5_spec(Dp4Params P) {
   __shared__ float s_xc[DP_XN];
   __shared__ u16 s_xl[DP_XN];
   const u32 t = P.order[P.task0 + blockIdx.x];

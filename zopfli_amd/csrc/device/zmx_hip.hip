@@ -61,6 +61,8 @@ hipError_t DevAlloc(T** p, size_t n) {
 struct zmx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // the heads of the chain run beside the other tasks (zmx_squeeze_run)
+  hipEvent_t ev2[2] = {nullptr, nullptr};
   u8* d_in = nullptr;
   size_t insize = 0, in_cap = 0;
   const unsigned char* h_in = nullptr;  // caller's buffer (borrowed until the next zmx_set_input)
@@ -119,6 +121,11 @@ struct zmx_tables {
   SegTask* d_tasks = nullptr;
   u32* d_task_off = nullptr;
   u32* d_task_order = nullptr;
+  d5_u32x4* d_dsc = nullptr;       // per position: the buffer descriptor of its edge row (k_mkdesc)
+  const double* dsc_rows = nullptr; // the rows[] array the descriptors point into
+  u32* d_winflag = nullptr;        // per 32-position window: fast path possible (k_mkdesc)
+  u32* d_win_off = nullptr;        // [nb]
+  std::vector<u32> win_off;
   float* d_lvl = nullptr;
   SegSnap* d_entry = nullptr;
   SegSnap* d_exit = nullptr;
@@ -231,7 +238,9 @@ int zmx_ctx_create(int device, zmx_ctx** out) {
   zmx_ctx* c = new zmx_ctx();
   c->device = device;
   HIPCHK(hipStreamCreate(&c->stream));
+  HIPCHK(hipStreamCreate(&c->stream2));
   for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
+  for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev2[i], hipEventDisableTiming));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
                              CH_LDS_BYTES));
   *out = c;
@@ -248,6 +257,8 @@ void zmx_ctx_destroy(zmx_ctx* c) {
   for (auto& f : c->pool_free) (void)hipFree(f.first);
   for (auto& f : c->pool_live) (void)hipFree(f.first);
   for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  for (int i = 0; i < 2; ++i) if (c->ev2[i]) (void)hipEventDestroy(c->ev2[i]);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -298,6 +309,9 @@ void zmx_tables_free(zmx_ctx* c, zmx_tables* t) {
   PoolFree(c, t->d_tasks);
   PoolFree(c, t->d_task_off);
   PoolFree(c, t->d_task_order);
+  PoolFree(c, t->d_dsc);
+  PoolFree(c, t->d_winflag);
+  PoolFree(c, t->d_win_off);
   PoolFree(c, t->d_lvl);
   PoolFree(c, t->d_entry);
   PoolFree(c, t->d_exit);
@@ -729,15 +743,39 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     if (c->d_rows) HIPCHK(hipFree(c->d_rows));
     c->d_rows = nullptr;
     c->rows_cap = 0;
-    hipError_t e = DevAlloc(&c->d_rows, t->max_range_rows);
+    // (+ 2048 doubles: k_dp5_spec touches up to 8 KB beyond the first row of a window)
+    hipError_t e = DevAlloc(&c->d_rows, t->max_range_rows + 2048);
     if (e != hipSuccess && !c->pool_free.empty()) {   // out of memory: drop the table cache and retry
       for (auto& f : c->pool_free) (void)hipFree(f.first);
       c->pool_free.clear();
       c->pool_free_bytes = 0;
-      e = DevAlloc(&c->d_rows, t->max_range_rows);
+      e = DevAlloc(&c->d_rows, t->max_range_rows + 2048);
     }
     HIPCHK(e);
     c->rows_cap = t->max_range_rows;
+  }
+  if (t->dsc_rows != c->d_rows || !t->d_dsc) {   // first run, or rows[] has moved
+    if (!t->d_dsc) {
+      HIPCHK(PoolAlloc(c, &t->d_dsc, t->total_b));
+      t->win_off.assign(nb + 1, 0);
+      for (size_t b = 0; b < nb; ++b) t->win_off[b + 1] = t->win_off[b] + (t->bsize[b] + 31) / 32;
+      HIPCHK(PoolAlloc(c, &t->d_winflag, t->win_off[nb]));
+      HIPCHK(PoolAlloc(c, &t->d_win_off, nb + 1));
+      HIPCHK(hipMemcpyAsync(t->d_win_off, t->win_off.data(), (nb + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+    }
+    MkDescParams mp;
+    mp.win_off = t->d_win_off;
+    mp.winflag = t->d_winflag;
+    mp.blocks = t->d_blocks;
+    mp.dph = t->d_dph;
+    mp.row_base = t->d_row_base;
+    mp.rows = c->d_rows;
+    mp.dsc = t->d_dsc;
+    u32 max_b = 1;
+    for (size_t b = 0; b < nb; ++b) max_b = std::max(max_b, t->bsize[b]);
+    hipLaunchKernelGGL(k_mkdesc, dim3((max_b + 255) / 256, static_cast<unsigned>(nb)), dim3(256), 0, c->stream, mp);
+    HIPCHK(hipGetLastError());
+    t->dsc_rows = c->d_rows;
   }
   static const bool want_prof = std::getenv("ZOPFLI_AMD_PROF") != nullptr;
   if (want_prof && !t->d_prof) HIPCHK(PoolAlloc(c, &t->d_prof, nb * ZMX_PROF_N));
@@ -754,7 +792,6 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   ep.row_base = t->d_row_base;
   ep.mincost = t->d_mincost;
   ep.badpos = t->d_badpos;
-  ep.block_edges = t->d_block_edges;
   Dp4Params cp;
   cp.blocks = t->d_blocks;
   cp.dph = t->d_dph;
@@ -779,6 +816,9 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   static const float level_scale = [] { const char* e = std::getenv("ZOPFLI_AMD_SEG_SCALE"); return e ? static_cast<float>(std::atof(e)) : 1.0f; }();
   cp.level_scale = level_scale;
   cp.order = t->d_task_order;
+  cp.dsc = t->d_dsc;
+  cp.winflag = t->d_winflag;
+  cp.win_off = t->d_win_off;
   // ZOPFLI_AMD_SPEC=4: the speculative pass on k_dp4's four-wave pipeline (one task per CU) instead of
   // k_dp5's one wave per task
   static const bool spec4 = [] { const char* e = std::getenv("ZOPFLI_AMD_SPEC"); return e && std::atoi(e) == 4; }();
@@ -817,8 +857,33 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
       if (cp.prof) hipLaunchKernelGGL(k_dp4_spec<true>, dim3(ntask), dpdim, 0, c->stream, cp);
       else hipLaunchKernelGGL(k_dp4_spec<false>, dim3(ntask), dpdim, 0, c->stream, cp);
     } else {
-      if (cp.prof) hipLaunchKernelGGL(k_dp5_spec<true>, dim3(ntask), dim3(64), 0, c->stream, cp);
-      else hipLaunchKernelGGL(k_dp5_spec<false>, dim3(ntask), dim3(64), 0, c->stream, cp);
+      // Every task one wave, the heads (exact, several times as long as the others, and all there is of
+      // a small block) first in the launch order.  ZOPFLI_AMD_HEADS (experiments): 1 = the heads on the
+      // four-wave pipeline, one per CU, on a second stream beside the others (measured slower: the
+      // 142 KB workgroups wait for CUs the lean waves have filled); 2 = the same on one stream.
+      static const int heads_mode = [] { const char* e = std::getenv("ZOPFLI_AMD_HEADS"); return e ? std::atoi(e) : 0; }();
+      Dp4Params cl = cp;
+      unsigned nlean = ntask;
+      if (heads_mode != 0) {
+        hipStream_t hs = heads_mode == 1 ? c->stream2 : c->stream;
+        if (heads_mode == 1) {
+          HIPCHK(hipEventRecord(c->ev2[0], c->stream));
+          HIPCHK(hipStreamWaitEvent(c->stream2, c->ev2[0], 0));
+        }
+        if (cp.prof) hipLaunchKernelGGL(k_dp4_spec<true>, dim3(nblk), dpdim, 0, hs, cp);
+        else hipLaunchKernelGGL(k_dp4_spec<false>, dim3(nblk), dpdim, 0, hs, cp);
+        if (heads_mode == 1) HIPCHK(hipEventRecord(c->ev2[1], c->stream2));
+        cl.task0 = cp.task0 + nblk;
+        nlean = ntask - nblk;
+      }
+      if (nlean) {
+        // (registers for 4 or 6 waves per SIMD: ZOPFLI_AMD_D5W)
+        static const int d5w = [] { const char* e = std::getenv("ZOPFLI_AMD_D5W"); return e ? std::atoi(e) : 4; }();
+        if (cp.prof) hipLaunchKernelGGL((k_dp5_spec<true, 4>), dim3(nlean), dim3(64), 0, c->stream, cl);
+        else if (d5w == 6) hipLaunchKernelGGL((k_dp5_spec<false, 6>), dim3(nlean), dim3(64), 0, c->stream, cl);
+        else hipLaunchKernelGGL((k_dp5_spec<false, 4>), dim3(nlean), dim3(64), 0, c->stream, cl);
+      }
+      if (heads_mode == 1) HIPCHK(hipStreamWaitEvent(c->stream, c->ev2[1], 0));
     }
     if (ntask > nblk) {
       hipLaunchKernelGGL(k_dpcheck, dim3(ntask), dim3(64), 0, c->stream, cp);
@@ -871,6 +936,11 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
                  ksec[0] * 1e3, ksec[1] * 1e3, ksec[2] * 1e3, a[1] / a[4], a[0],
                  100.0 * a[2] / (a[2] + a[3] + 1e-9), a[4], t->total_b, segstats[0], segstats[1], segstats[2],
                  segstats[6], segstats[3], segstats[4], segstats[5]);
+    {
+      double mx = 0, hd = 0;
+      for (size_t b = 0; b < nb; ++b) { mx = std::max(mx, static_cast<double>(pr[b * ZMX_PROF_N + 7])); hd = std::max(hd, static_cast<double>(pr[b * ZMX_PROF_N + 8])); }
+      std::fprintf(stderr, "  k_dp5_spec: longest task %.0f cycles, longest head task %.0f cycles\n", mx, hd);
+    }
     const char* nm[5] = {"32", "16", "8", "8 (two registers)", "generic"};
     for (int i = 0; i < 5; ++i)
       std::fprintf(stderr, "  path %-18s %5.1f%% of positions, %6.1f cycles/position\n", nm[i], 100.0 * a[6 + 2 * i] / a[4],

@@ -89,6 +89,13 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// rows[] holds every DP edge cost with the bits 0x7fe0 of its top half flipped: the all-zero word
+// that a buffer load returns for a lane outside its row (k_dp5_spec fetches a row with the row as
+// the buffer) then decodes to 2^1023, an edge nobody takes, and a real cost (>= 0, < 2^1023) never
+// encodes to zero.
+#define ZMX_ROW_KEY 0x7fe0000000000000ll
+__device__ __forceinline__ double row_code(double w) { return __longlong_as_double(__double_as_longlong(w) ^ ZMX_ROW_KEY); }
+
 // ----------------------------------------------------------------------------
 // K1a  same[]: run length ahead, bounded by the block end, capped at 65535
 // ----------------------------------------------------------------------------
@@ -412,7 +419,6 @@ struct EdgeParams {
   const u64* row_base;     // [nb_total] first row slot of each block (in doubles)
   const double* mincost;   // [nb_total]
   u32* badpos;             // bit per position (pos_off + p): a match edge of it costs less than mincost (zeroed per run)
-  const u64* block_edges;  // [nb_total] rows of each block
 };
 
 __global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
@@ -455,8 +461,6 @@ __global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
   __syncthreads();
   const double kInf = __longlong_as_double(0x7ff0000000000000ll);
   u8* mark = s_mark[wid];
-  // one +inf behind the block's rows: where k_dp5_spec points the lanes that lie outside a row
-  if (tp0 == 0 && tid == 0) rows[(P.block_edges[b] + 127u) & ~(u64)127u] = kInf;   // (DP_PIECE = 128)
 
   for (u32 g = wid; g < MT / 64; g += 4) {
     const u32 base = tp0 + g * 64;
@@ -549,7 +553,7 @@ __global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
               atomicOr(&P.badpos[gp >> 5], 1u << (gp & 31));
             }
           }
-          rows[(u64)off_q + e] = w;
+          rows[(u64)off_q + e] = row_code(w);
         }
       }
       // rows of records with more than 8 change points (pool): whole wave per position
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
           }
           const u32 dist = plo < pn ? P.pool[poff + plo] >> 16 : 1u;
           const double w = ((double)((int)s_klb[k] + dev_dist_extra_bits(dist)) + s_kll[k]) + s_d[dev_dist_symbol(dist)];
-          rows[(u64)roff_p + k - 1] = w;
+          rows[(u64)roff_p + k - 1] = row_code(w);
           if (w < mincost) {
             const u64 gp = bd.pos_off + base + p;
             atomicOr(&P.badpos[gp >> 5], 1u << (gp & 31));

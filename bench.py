@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 MB = 1000000
 WINDOW = 32768
-PMC_PROFILE = "r01_v8_bench100MB_pmc.json"
+PMC_PROFILE = "r02_bench100MB_pmc.json"
 SHADER_CLOCK_HZ = 2.4e9   # MI355X peak engine clock; s_memtime counts at this rate (measured)
 
 
@@ -47,6 +47,65 @@ def cpu_baseline(sample, options):
                       f"oracle/_ref/libzopfli_ref.so (gcc -O3 -DNDEBUG), {dt:.1f} s, {len(out)} bytes out"}, out
 
 
+def _ref_piece(task):
+    """One master block through the reference's ZopfliDeflatePart, in a worker process."""
+    data, start, end, n, split, smax = task
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    t0 = time.perf_counter()
+    out, _bp = ol.ref_deflate_part(data, start, end, 2, 0, n, split)
+    return len(out), time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(shard, options):
+    """SURVEY 8(d) secondary baseline: the real reference on EVERY host core — ZopfliDeflatePart per
+    master block (deflate.c:916-923: the blocks are independent), one worker process per core, two
+    master blocks each, so the whole box works for a few seconds."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import multiprocessing as mp
+
+    import oracle_lib as ol
+    if not ol.have_ref():
+        return None
+    cores = os.cpu_count() or 1
+    nblocks = min(len(shard) // MB, 2 * cores)
+    if nblocks < 1:
+        return None
+    tasks = []
+    for b in range(nblocks):
+        lo = max(0, b * MB - WINDOW)
+        tasks.append((shard[lo:(b + 1) * MB], b * MB - lo, (b + 1) * MB - lo, options.numiterations,
+                      options.blocksplitting, options.blocksplittingmax))
+    workers = min(cores, nblocks)
+    with mp.get_context("fork").Pool(workers) as pool:
+        t0 = time.perf_counter()
+        res = pool.map(_ref_piece, tasks, chunksize=1)
+        dt = time.perf_counter() - t0
+    return {"value": round(nblocks / dt, 3), "unit": "MB/s", "cores": workers, "kind": "reference",
+            "sample": f"first {nblocks} master blocks of the workload, ZopfliDeflatePart per master block in "
+                      f"{workers} worker processes (one per core), {dt:.1f} s wall, "
+                      f"{sum(r[1] for r in res):.0f} s of core time, {sum(r[0] for r in res)} bytes out"}
+
+
+def measured_copy_gbs(torch, device):
+    """What a plain device copy reaches on this GPU (read + write bytes per second), beside the 8 TB/s on paper."""
+    try:
+        n = 1 << 30
+        a = torch.empty(n, dtype=torch.uint8, device=device)
+        b = torch.empty(n, dtype=torch.uint8, device=device)
+        b.copy_(a)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        return round(5 * 2 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,6 +121,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo "
                     "exercises the same sharding/gather/merge code where only one GPU is visible)")
+    ap.add_argument("--gather", default="rccl-c", choices=["rccl-c", "torch"],
+                    help="who gathers the ranks' blobs at N>1: the library's own RCCL gather (zmx_dist_*, dist.cc; "
+                         "falls back to torch.distributed if it cannot start) or torch.distributed's gather")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = --size bytes per GPU (default), strong = --size bytes in total "
+                         "(BASELINE configs[2]: one 100 MB stream sharded by master block)")
     ap.add_argument("--device-index", type=int, default=None, help="HIP device of this rank (default LOCAL_RANK)")
     args = ap.parse_args()
 
@@ -95,28 +160,80 @@ def main():
     lib = api.library()
     options = ZopfliOptions(args.numiterations, args.blocksplitting, 15)
     size = args.size
-    assert size % MB == 0 or world == 1, "shards must be whole master blocks"
+    strong = args.scaling == "strong" and world > 1
 
-    # ---- synthetic input: shard r = class `cls`, seed = the class's default seed + r
+    # ---- synthetic input.  weak: shard r = class `cls`, seed = the class's default seed + r, the shards
+    #      being consecutive ranges of master blocks of ONE stream.  strong: one stream of `size` bytes
+    #      (seed = the default), rank r taking the master blocks sharding.shard_ranges gives it.
     from zopfli_amd.datagen import DEFAULT_SEED
     seed0 = DEFAULT_SEED[args.cls]
-    shard = generate(args.cls, size, seed=seed0 + rank)
-    prefix = b""
-    if rank > 0:
-        prefix = generate(args.cls, size, seed=seed0 + rank - 1)[-WINDOW:]  # tail of the previous shard = dictionary
+    if strong:
+        whole = generate(args.cls, size, seed=seed0)
+        s0, s1 = sharding.shard_ranges(size, world)[rank]
+        shard = whole[s0:s1]
+        prefix = whole[max(0, s0 - WINDOW):s0]
+        total_bytes = size
+        nonempty = [r for r in range(world) if sharding.shard_ranges(size, world)[r][1] > sharding.shard_ranges(size, world)[r][0]]
+        last_rank = nonempty[-1] if nonempty else 0
+        del whole
+    else:
+        assert size % MB == 0 or world == 1, "shards must be whole master blocks"
+        shard = generate(args.cls, size, seed=seed0 + rank)
+        prefix = b""
+        if rank > 0:
+            prefix = generate(args.cls, size, seed=seed0 + rank - 1)[-WINDOW:]  # tail of the previous shard = dictionary
+        total_bytes = size * world
+        last_rank = world - 1
     resident = prefix + shard
     ctx = Context(dev_index, lib)
     ctx.set_input(resident)  # H2D, outside the timed region
     instart, inend = len(prefix), len(resident)
-    final = 1 if rank == world - 1 else 0
+    final = 1 if rank == last_rank else 0
+    # ---- the gather: the library's own RCCL gather unless it cannot start
+    cdist = None
+    gather_kind = "none (one rank)"
+    if world > 1:
+        gather_kind = "torch.distributed " + args.backend
+        if args.gather == "rccl-c" and args.backend == "nccl":
+            from zopfli_amd import Dist
+            err = ""
+            uid = [None]
+            try:
+                if rank == 0:
+                    uid[0] = Dist.unique_id(lib)
+            except RuntimeError as e:   # e.g. librccl missing
+                err = str(e)
+            dist.broadcast_object_list(uid, src=0)
+            ok = 0
+            if uid[0] is not None:
+                try:
+                    cdist = Dist(ctx, rank, world, uid[0])
+                    ok = 1
+                except RuntimeError as e:
+                    err = str(e)
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                gather_kind = "library RCCL (zmx_dist_gather: ncclAllGather sizes + grouped ncclSend/ncclRecv)"
+            else:
+                if cdist is not None:
+                    cdist.close()
+                cdist = None
+                gather_kind += " (library RCCL gather unavailable: %s)" % err
     header = bytes([31, 139, 8, 0, 0, 0, 0, 0, 2, 3])
 
     def gather_blobs(blob):
-        return sharding.gather_bytes(blob, rank, world, device, dist)   # one RCCL gather over xGMI
+        if cdist is not None:
+            return cdist.gather(blob)                                     # the library's RCCL gather over xGMI
+        return sharding.gather_bytes(blob, rank, world, device, dist)   # torch.distributed's gather (RCCL)
 
     def gather_crc(crc):
-        parts = sharding.gather_bytes(crc.to_bytes(4, "little"), rank, world, device, dist)
-        return None if parts is None else [int.from_bytes(bytes(p), "little") for p in parts]
+        """(crc32, length) of every rank's shard, on rank 0"""
+        rec = crc.to_bytes(4, "little") + len(shard).to_bytes(8, "little")
+        parts = cdist.gather(rec) if cdist is not None else sharding.gather_bytes(rec, rank, world, device, dist)
+        if parts is None:
+            return None
+        return [(int.from_bytes(bytes(p[:4]), "little"), int.from_bytes(bytes(p[4:12]), "little")) for p in parts]
 
     timing_acc = {}
     seg_acc = {}
@@ -126,7 +243,10 @@ def main():
         th = threading.Thread(target=lambda: crc_box.__setitem__(0, zlib.crc32(shard)))
         th.start()  # the checksum does not depend on the device work
         ta = time.perf_counter()
-        blob = ctx.deflate_range(options, instart, inend, final, as_array=True)   # the library's buffer, no copy
+        if inend > instart or total_bytes == 0:
+            blob = ctx.deflate_range(options, instart, inend, final, as_array=True)   # the library's buffer, no copy
+        else:
+            blob = b""      # (strong scaling with more ranks than master blocks: nothing to do here)
         tb = time.perf_counter()
         for k, v in api.last_timing(lib).items():
             timing_acc[k] = timing_acc.get(k, 0.0) + v
@@ -140,13 +260,12 @@ def main():
         timing_acc["gather"] = timing_acc.get("gather", 0.0) + (tc - tb)
         if rank != 0:
             return None
-        crc = crcs[0]
-        for c in crcs[1:]:
-            crc = crc32_combine(crc, c, size)
-        total = size * world
-        trailer = crc.to_bytes(4, "little") + (total & 0xffffffff).to_bytes(4, "little")
+        crc = crcs[0][0]
+        for c, n in crcs[1:]:
+            crc = crc32_combine(crc, c, n)
+        trailer = crc.to_bytes(4, "little") + (total_bytes & 0xffffffff).to_bytes(4, "little")
         # the gzip stream in one malloc'ed buffer, as a C caller of zmx_chunks_merge gets it
-        out = ctx.merge(blobs, header, trailer, as_array=True)
+        out = ctx.merge([b for b in blobs if len(b)], header, trailer, as_array=True)
         timing_acc["merge"] = timing_acc.get("merge", 0.0) + (time.perf_counter() - tc)
         return out
 
@@ -173,14 +292,18 @@ def main():
 
     if rank == 0:
         out = out.tobytes()   # outside the timed region
-        total = size * world
+        total = total_bytes
         ms = dt / args.steps * 1e3
         value = total / MB / (dt / args.steps)
         # ---- correctness of the measured output (outside the timed region)
         bitexact = None
         roundtrip = None
-        if world == 1:
-            roundtrip = gzip.decompress(out) == shard
+        if world == 1 or strong:
+            if world == 1:
+                roundtrip = gzip.decompress(out) == shard
+            else:
+                dd = zlib.decompressobj(31)
+                roundtrip = (len(dd.decompress(out)) + len(dd.flush())) == total
             sha = hashlib.sha256(out).hexdigest()
             for name in ("vectors_big.json", "vectors_big2.json", "vectors.json"):
                 p = os.path.join(ROOT, "tests", "golden", name)
@@ -195,57 +318,82 @@ def main():
             d = zlib.decompressobj(31)
             n = len(d.decompress(out)) + len(d.flush())
             roundtrip = (n == total)
-        # ---- roofline of the dominant kernel (k_dp3, the serial DP chain): algorithmic bytes = 31 B per
-        #      position per launch (28 B match record + 1 B literal + 2 B length_array)
+        # ---- roofline of the dominant kernels: the chain (GetBestLengths: k_dp5_spec + k_dpcheck + k_dp4_fix of
+        #      one squeeze run; algorithmic bytes = 31 B per position per run: 28 B match record + 1 B literal +
+        #      2 B length_array) and, beside it, the match-table kernel (29 B per position)
         launches = timing_acc.get("squeeze_launches", 0.0)
         ksec = timing_acc.get("dp_kernel", 0.0)
+        copy_gbs = measured_copy_gbs(torch, device) if world == 1 else None
         roofline = None
         if launches > 0 and ksec > 0:
             per_launch_bytes = 31.0 * size
             achieved = per_launch_bytes / (ksec / launches) / 1e9
-            # HBM bytes per k_dp launch from the rocprofv3 PMC passes of this exact workload
-            # (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md; tools/collect_profiles.sh): only
-            # reported when the committed profile was taken on the same configuration
+            # HBM bytes per launch from the rocprofv3 PMC passes of this exact workload (FETCH_SIZE x 2 +
+            # WRITE_SIZE, MI355X_MICROARCH.md): only reported when the committed profile was taken on the
+            # same configuration
             traffic = None
             pmc = os.path.join(ROOT, "profiles", PMC_PROFILE)
-            if (os.path.exists(pmc) and size == 100 * MB and args.numiterations == 15
+            if (os.path.exists(pmc) and size == 100 * MB and args.numiterations == 15 and args.cls == "T"
                     and args.blocksplitting == 0 and world == 1):
                 with open(pmc) as f:
-                    traffic = round(json.load(f).get("k_dp3", {}).get("hbm_bytes", 0) / 1e9, 3) or None
-            roofline = {"bound": "hbm", "kernel": "k_dp3", "achieved": round(achieved, 3), "peak": 8000.0,
+                    traffic = round(json.load(f).get("chain", {}).get("hbm_bytes", 0) / 1e9, 3) or None
+            roofline = {"bound": "hbm", "kernel": "the chain of one squeeze run: k_dp5_spec + k_dpcheck + k_dp4_fix",
+                        "achieved": round(achieved, 3), "peak": 8000.0,
                         "unit": "GB/s", "frac": round(achieved / 8000.0, 6), "traffic": traffic,
                         "traffic_unit": "GB per launch (rocprofv3 PMC, profiles/" + PMC_PROFILE + ")",
                         "algorithmic_gb_per_launch": round(per_launch_bytes / 1e9, 3),
-                        "avg_launch_ms": round(ksec / launches * 1e3, 3), "launches_per_step": launches / args.steps}
-            # what really bounds k_dp3: one wave per master block walks a chain of dependent updates,
-            # 8 VALU instructions per position at the 5.8 cycles a lone wave needs per instruction
-            # (tools/ubench_chain.hip)
-            block = min(size, MB)
-            cyc = (ksec / launches) * SHADER_CLOCK_HZ / block
-            roofline["chain"] = {"cycles_per_position": round(cyc, 1), "issue_floor_cycles_per_position": 46.4,
-                                 "frac_of_issue_floor": round(46.4 / cyc, 3), "clock_ghz": SHADER_CLOCK_HZ / 1e9}
+                        "avg_launch_ms": round(ksec / launches * 1e3, 3), "launches_per_step": launches / args.steps,
+                        "measured_copy_peak_gbs": copy_gbs}
+            tasks = seg_acc.get("tasks", 0.0)
+            if tasks:
+                # how the chain's tasks fared: what was accepted as computed, what was run again serially and why
+                roofline["chain"] = {
+                    "tasks_per_launch": round(tasks / launches, 1),
+                    "accepted_frac": round(seg_acc.get("accepted", 0.0) / tasks, 5),
+                    "rerun_state_frac": round((seg_acc.get("rerun_state", 0.0) + seg_acc.get("rerun_values", 0.0)) / tasks, 5),
+                    "rerun_level_frac": round(seg_acc.get("rerun_level", 0.0) / tasks, 5),
+                    "rerun_tie_frac": round(seg_acc.get("rerun_tie", 0.0) / tasks, 5),
+                    "positions_rerun_frac": round(seg_acc.get("positions_rerun", 0.0) / max(seg_acc.get("positions", 1.0), 1.0), 5)}
+        msec, mpos = timing_acc.get("match_kernel", 0.0), timing_acc.get("positions_matched", 0.0)
+        roofline_match = None
+        if msec > 0 and mpos > 0:
+            ach = 29.0 * mpos / msec / 1e9
+            roofline_match = {"bound": "hbm", "kernel": "k_match2", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
+                              "frac": round(ach / 8000.0, 6), "seconds_per_step": round(msec / args.steps, 5),
+                              "positions_per_step": mpos / args.steps,
+                              "ns_per_position": round(msec / mpos * 1e9, 4),
+                              "hash_kernels_seconds_per_step": round(timing_acc.get("hash_kernels", 0.0) / args.steps, 5)}
         line = {
             "metric": "input MB/s at numiterations=15 (gzip, bit-exact vs reference)",
             "value": round(value, 4), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None,
             "dtype": "u8 (f32/f64 cost DP)", "data": "synthetic",
-            "config": {"workload": f"class-{args.cls} synthetic {size} B per GPU (T = text-like enwik8 stand-in), numiterations="
+            "config": {"workload": f"class-{args.cls} synthetic {size} B {'in total' if strong else 'per GPU'} "
+                                   f"(T = text-like enwik8 stand-in), numiterations="
                                    f"{args.numiterations}, blocksplitting={args.blocksplitting}, gzip, "
                                    f"{'configs[1]' if args.blocksplitting == 0 else 'configs[2]'}",
                        "total_bytes": total, "master_blocks": (total + MB - 1) // MB,
-                       "sharding": "master blocks, contiguous per rank, RCCL gather of bit chunks"},
+                       "sharding": "master blocks, contiguous per rank, gather of bit chunks to rank 0",
+                       "gather": gather_kind},
             "output_bytes": len(out), "roundtrip_ok": roundtrip, "bitexact_vs_reference": bitexact,
             "roofline": roofline,
+            "roofline_match": roofline_match,
             "chain_tasks_per_step": {k: round(v / args.steps, 1) for k, v in seg_acc.items()},
             "breakdown_s_per_step": {k: round(v / args.steps, 4) for k, v in timing_acc.items()
-                                     if k != "squeeze_launches"},
+                                     if k not in ("squeeze_launches", "table_builds", "positions_matched")},
         }
         if world == 1 and not args.no_cpu_baseline:
             sample = shard[:min(args.cpu_sample, size)]
             res = cpu_baseline(sample, options)
             if res:
                 line["cpu_baseline"] = res[0]
+            allc = cpu_baseline_all_cores(shard, options)
+            if allc:
+                line["cpu_baseline_all_cores"] = allc
         print(json.dumps(line), flush=True)
+    if cdist is not None:
+        cdist.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

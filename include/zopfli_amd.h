@@ -23,6 +23,21 @@
 extern "C" {
 #endif
 
+/* libzopfli_amd.so is built with -fvisibility=hidden: exactly the functions declared here are
+ * exported (plus one test hook). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
+/* Errors.  The reference's entry points return void; like the reference (which exit()s when malloc
+ * fails, util.h:135-155) the Zopfli* functions below print a message to stderr and exit(EXIT_FAILURE)
+ * when the device side fails: no usable gfx950 device, a HIP error such as an allocation that does
+ * not fit in HBM, or a single deflate block whose DP edges do not fit 32-bit row offsets (more than
+ * 2^32 - 1 match-length candidates in one block: beyond ~16 MB of highly repetitive data; the limit
+ * applies to one block [instart, inend) of ZopfliDeflatePart with blocksplitting = 0 only — ZopfliDeflate
+ * and ZopfliCompress cut their input into 1 000 000-byte master blocks first).  The zmx_* functions of
+ * part 2 return non-zero instead and leave a message for zmx_last_error(). */
+
 /* ------------------------------------------------------------------ Part 1 */
 
 /* reference: src/zopfli/zopfli.h:33-64 (six ints, this order) */
@@ -92,12 +107,16 @@ typedef struct zmx_block {
 #define ZMX_HIST (ZMX_NUM_LL + ZMX_NUM_D) /* litlen bins then dist bins */
 
 int zmx_device_count(void);
+/* The message of the last failed zmx_* call on the calling thread. */
 const char* zmx_last_error(void);
 
 int zmx_ctx_create(int device, zmx_ctx** ctx);
 void zmx_ctx_destroy(zmx_ctx* ctx);
 
-/* Copies the whole input to HBM once; every later call works on that copy. */
+/* Copies the whole input to HBM once; the kernels work on that copy.  The host side keeps reading a
+ * few bytes of `in` itself (the ends of blocks when match tables are reused, the bytes of stored
+ * blocks): `in` must stay valid and unchanged until the next zmx_set_input or zmx_ctx_destroy on
+ * this context.  The calling thread's current HIP device is left as it was. */
 int zmx_set_input(zmx_ctx* ctx, const unsigned char* in, size_t insize);
 
 /* Kernel A.  For every block: the static hash arrays (hash.c:100-137 val/same/
@@ -167,6 +186,27 @@ int zmx_deflate_range(zmx_ctx* ctx, const ZopfliOptions* options, size_t instart
 int zmx_chunks_merge(const unsigned char* const* blobs, const size_t* blobsizes, size_t nblobs,
                      unsigned char* bp, unsigned char** out, size_t* outsize);
 
+/* -------- one process per GPU: the gather of the ranks' blobs over RCCL (xGMI inside a node)
+ *
+ * ZopfliDeflate's master blocks are independent (deflate.c:916-923): rank r of `world` runs
+ * zmx_deflate_range on its contiguous range of master blocks, the blobs are gathered to rank 0 and
+ * merged there with zmx_chunks_merge.  librccl is loaded with dlopen on first use.  (Inside ONE
+ * process the Zopfli* entry points of part 1 already deal the master blocks over every visible
+ * device: ZOPFLI_AMD_DEVICES.) */
+typedef struct zmx_dist zmx_dist;
+
+/* Rank 0: a fresh ncclUniqueId (128 bytes) that the launcher hands to every rank (file, environment,
+ * MPI, torch.distributed ...). */
+int zmx_dist_unique_id(unsigned char* id128);
+/* Collective: the communicator of `world` ranks, this process being `rank` on ctx's device. */
+int zmx_dist_init(zmx_ctx* ctx, int rank, int world, const unsigned char* id128, zmx_dist** dist);
+void zmx_dist_destroy(zmx_dist* dist);
+/* Collective: every rank contributes `size` bytes.  On rank 0 *gathered is a malloc'ed buffer holding
+ * the blobs of rank 0, 1, ... back to back and sizes[r] their lengths (sizes has `world` entries);
+ * elsewhere *gathered = NULL and sizes is not written. */
+int zmx_dist_gather(zmx_dist* dist, const unsigned char* blob, size_t size, unsigned char** gathered,
+                    size_t* sizes);
+
 /* Timing breakdown of the last Zopfli* / zmx_deflate_range call on this
  * thread: seconds spent in [0] match tables [1] greedy [2] squeeze runs
  * [3] host cost model [4] block split [5] encode [6] DP-chain kernel (k_dp3) time
@@ -183,12 +223,21 @@ int zmx_last_kernel_timing(double* out4);
  * [1] chunk serialisation (zmx_deflate_range). */
 int zmx_last_host_timing(double* out2);
 
+/* Match-table builds since the last Zopfli* / zmx_deflate_range call started (HIP events):
+ * [0] seconds in k_match2 [1] seconds in k_same + k_chain [2] table builds [3] positions whose record
+ * the match kernel computed (the others were copied from the parent tables). */
+int zmx_last_match_timing(double* out4);
+
 /* The chain's tasks (GetBestLengths cut into verified stretches, zmx_dp4.h) since the last Zopfli* /
  * zmx_deflate_range call started: [0] tasks [1] accepted as computed [2] re-run because the entry
  * state differed [3] because the guessed level left the binade [4] because a weight could tie
  * [5] positions re-run serially [6] re-run because the entry values differed by more than a shift
  * [7] block positions of all squeeze runs. */
 int zmx_last_seg_stats(double* out8);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

@@ -32,11 +32,15 @@ struct zmx_tables {
   std::vector<BlockData> blocks;
 };
 
-static std::string g_err;
+static thread_local std::string g_err;
 
 extern "C" {
 
-int zmx_device_count(void) { return 1; }
+// (ZOPFLI_HOSTTEST_DEVICES pretends to that many devices: the multi-device sharding of api.cc on CPU)
+int zmx_device_count(void) {
+  const char* e = std::getenv("ZOPFLI_HOSTTEST_DEVICES");
+  return e ? std::atoi(e) : 1;
+}
 const char* zmx_last_error(void) { return g_err.c_str(); }
 
 int zmx_ctx_create(int, zmx_ctx** ctx) {
@@ -53,6 +57,12 @@ size_t zmx_internal_input_size(zmx_ctx* ctx) { return ctx->input.size(); }
 const unsigned char* zmx_internal_input_host(zmx_ctx* ctx) { return ctx->input.data(); }
 void zmx_internal_kernel_stats(double* a, double* b, int) { a[0] = a[1] = a[2] = 0; *b = 0; }
 void zmx_internal_seg_stats(double* a, int) { for (int i = 0; i < 8; ++i) a[i] = 0; }
+void zmx_internal_match_stats(double* a, int) { for (int i = 0; i < 4; ++i) a[i] = 0; }
+// (the RCCL gather of dist.cc is not part of the host-logic test library)
+int zmx_dist_unique_id(unsigned char*) { g_err = "no RCCL in the host test library"; return -1; }
+int zmx_dist_init(zmx_ctx*, int, int, const unsigned char*, zmx_dist**) { g_err = "no RCCL in the host test library"; return -1; }
+void zmx_dist_destroy(zmx_dist*) {}
+int zmx_dist_gather(zmx_dist*, const unsigned char*, size_t, unsigned char**, size_t*) { g_err = "no RCCL in the host test library"; return -1; }
 
 int zmx_tables_build(zmx_ctx* ctx, const zmx_block* blocks, size_t nblocks, zmx_tables** tables) {
   zmx_tables* t = new zmx_tables();

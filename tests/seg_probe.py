@@ -25,6 +25,9 @@ CASES = [
 
 
 def main():
+    global CASES
+    if os.environ.get("SEG_PROBE_CASES"):
+        CASES = [c for c in CASES if c[0] in os.environ["SEG_PROBE_CASES"]]
     lib = api.library()
     ctx = Context(0, lib)
     for cls, n, blocks in CASES:

@@ -25,3 +25,72 @@ def test_options_layout():
     assert (o.verbose, o.verbose_more, o.numiterations, o.blocksplitting, o.blocksplittinglast,
             o.blocksplittingmax) == (0, 0, 15, 1, 0, 15)
     assert ctypes.sizeof(ZopfliOptions) == 24
+
+
+def _ref_run_info(cost):
+    """The tie mask and the weight bound of a cost model in exact rational arithmetic: a float c of
+    binade e plus an edge weight w is computed as dbl(w + c) = c + RNE(w / g) g with g = 2^(e-52),
+    and the float rounding of that sum ties iff the remainder modulo 2^(e-23) is half of it."""
+    from fractions import Fraction
+    ll, d = cost[:288], cost[288:]
+
+    def lbits(s):
+        return 0 if s < 265 or s == 285 else (s - 261) // 4
+
+    def dbits(s):
+        return 0 if s < 4 else s // 2 - 1
+
+    ws = [float(x) for x in ll[:256]]
+    for ls in range(257, 286):
+        for ds in range(30):
+            ws.append((float(lbits(ls) + dbits(ds)) + float(ll[ls])) + float(d[ds]))
+    mask = 0
+    for w in ws:
+        if w <= 0:
+            continue
+        fw = Fraction(w)
+        for e in range(4, 32):
+            q = fw / Fraction(2) ** (e - 52)
+            fl = q.numerator // q.denominator
+            rem = q - fl
+            r = fl + (1 if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and fl % 2 == 1) else 0)
+            if r % (1 << 29) == (1 << 28):
+                mask |= 1 << e
+    return max(ws), mask
+
+
+def test_chain_acceptance_facts():
+    """zmx_hip.hip RunInfo (what k_dp4_fix's acceptance test knows about a cost model) against exact
+    arithmetic: random entropy-like tables never tie; weights built to tie in a chosen binade do."""
+    import numpy as np
+    from zopfli_amd import api
+    lib = api.library()
+    lib.zmx_internal_run_info.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_float),
+                                          ctypes.POINTER(ctypes.c_uint32)]
+    lib.zmx_internal_run_info.restype = None
+    rng = np.random.default_rng(5)
+
+    def run(cost):
+        cost = np.ascontiguousarray(cost, dtype=np.float64)
+        wmax, mask = ctypes.c_float(0), ctypes.c_uint32(0)
+        lib.zmx_internal_run_info(cost.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.byref(wmax),
+                                  ctypes.byref(mask))
+        return wmax.value, mask.value
+
+    for _ in range(3):
+        cost = np.log2(1.0 / rng.dirichlet(np.ones(320) * 0.3)).clip(0, 40)
+        wmax, mask = run(cost)
+        rmax, rmask = _ref_run_info(cost)
+        assert mask == rmask
+        assert wmax >= rmax
+    # a literal cost of 5.0625 = 40.5 float ulps of binade 20 (ulp 1/8): ties there, and in the
+    # binades whose ulp it is also an odd multiple of a half of
+    cost = np.full(320, 3.0)
+    cost[65] = 5.0625
+    wmax, mask = run(cost)
+    rmax, rmask = _ref_run_info(cost)
+    assert mask == rmask and (mask >> 20) & 1
+    # a match cost that only ties after the double rounding of the sum: 2^-30 above a half ulp of binade 24
+    cost = np.full(320, 2.0)
+    cost[288] = 1.0 + 2.0 ** -29
+    assert run(cost)[1] == _ref_run_info(cost)[1]

@@ -205,3 +205,32 @@ def test_chunks_merge_bit_offsets(host, seed):
         assert bp.value == want_bp
         assert got == want
     ctypes.CDLL(None).mallopt(-6, 0)
+
+
+def test_multi_device_sharding_through_the_c_entry_point():
+    """ZopfliCompress with the master blocks dealt over several devices inside the library (api.cc
+    RunPartsSharded; here three pretend devices of the oracle-backed layer): the stream equals the
+    one-device stream and the reference's, for a size that leaves the devices unequal shares, a
+    stored-block region (random bytes) and a part smaller than a master block."""
+    import subprocess
+    import sys
+    code = (
+        "import hashlib, sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import oracle_lib as ol\n"
+        "from zopfli_amd import ZopfliOptions, api, generate\n"
+        "host = ol.hosttest_library()\n"
+        "data = generate('M', 2300000) + generate('R', 400000)\n"
+        "print(hashlib.sha256(api.compress(data, 0, ZopfliOptions(1), lib=host)).hexdigest())\n"
+        "print(hashlib.sha256(api.deflate_part(data, 1500000, 2600000, 2, 1, ZopfliOptions(1), lib=host)[0]).hexdigest())\n"
+        % (os.path.dirname(os.path.dirname(__file__)), os.path.dirname(__file__)))
+    res = {}
+    for ndev in ("1", "3"):
+        env = dict(os.environ, ZOPFLI_HOSTTEST_DEVICES=ndev, ZOPFLI_AMD_DEVICES="all")
+        env.pop("LOCAL_RANK", None)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[ndev] = r.stdout.split()
+    assert res["1"] == res["3"]
+    data = generate("M", 2300000) + generate("R", 400000)
+    assert res["3"][0] == hashlib.sha256(ol.ref_compress(data, 0, 1)).hexdigest()

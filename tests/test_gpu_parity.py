@@ -166,7 +166,7 @@ def test_squeeze_runs(gpu_ctx, case):
 # (environment, what the task statistics must show)
 CHAIN_ENVS = [
     ({}, lambda st: st["tasks"] > 100 and st["accepted"] > 0),
-    ({"ZOPFLI_AMD_SPEC": "4"}, lambda st: st["tasks"] > 100 and st["accepted"] > 0),        # speculative pass on the 4-wave pipeline
+    ({"ZOPFLI_AMD_D5W": "6"}, lambda st: st["tasks"] > 100 and st["accepted"] > 0),         # the 6-waves-per-SIMD build of k_dp5_spec
     ({"ZOPFLI_AMD_SEG_L": "0"}, lambda st: st["tasks"] == 0),                                   # the serial chain
     ({"ZOPFLI_AMD_SEG_WARM": "64", "ZOPFLI_AMD_SEG_HEAD": "0"}, lambda st: st["rerun_state"] > 0),                           # warm-up too short: states differ
     ({"ZOPFLI_AMD_SEG_SCALE": "1.9"}, lambda st: st["rerun_level"] + st["rerun_values"] > 0),                         # wrong binade guessed
@@ -298,6 +298,30 @@ def test_reference_cli_linked_against_libzopfli_amd(tmp_path):
             assert out == ol.ref_compress(data, fmt, 5)
 
 
+def test_dynamic_user_of_libzopfli_so_1_switches_by_library_path(tmp_path):
+    """an existing user of libzopfli.so.1 — the reference's CLI linked against the reference's
+    own shared library, no rpath — gets this library by LD_LIBRARY_PATH alone (same soname) and writes
+    the same file."""
+    import subprocess
+    from zopfli_amd._build import LIB_SONAME, REF_CLI_DYN, REF_SO_DIR
+    if not (os.path.exists(REF_CLI_DYN) and os.path.exists(LIB_SONAME)):
+        pytest.skip("tests/_build/zopfli_ref_cli_dyn not built (needs /root/reference at build time)")
+    data = generate("M", 250000, 3)
+    outs = {}
+    for name, libdir in (("ref", REF_SO_DIR), ("amd", os.path.dirname(LIB_SONAME))):
+        src = tmp_path / (name + ".bin")
+        src.write_bytes(data)
+        env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+        r = subprocess.run([REF_CLI_DYN, "--i5", str(src)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        outs[name] = (tmp_path / (name + ".bin.gz")).read_bytes()
+        # which library did the loader pick?
+        ldd = subprocess.run(["ldd", REF_CLI_DYN], env=env, capture_output=True, text=True).stdout
+        assert libdir in ldd, ldd
+    assert outs["amd"] == outs["ref"]
+    assert gzip.decompress(outs["amd"]) == data
+
+
 def test_small_batches_and_threads():
     """Device batches smaller than the request (ZOPFLI_AMD_PARTS_PER_BATCH=2 on 5 master blocks) and
     two caller threads at once (the shared context serialises them) give the bytes of the default run."""
@@ -322,6 +346,49 @@ def test_small_batches_and_threads():
     assert res["2"] == res["256"]
     if ol.have_ref():
         assert res["2"][0] == hashlib.sha256(ol.ref_compress(generate("M", 4300000), 0, 2)).hexdigest()
+
+
+def test_master_blocks_dealt_over_device_contexts():
+    """The multi-device path of the C entry points (api.cc RunPartsSharded) on a one-GPU box: three
+    contexts on device 0 share the master blocks of one ZopfliCompress call; the stream equals the
+    one-context stream (and the reference's)."""
+    import subprocess
+    import sys
+    code = (
+        "import hashlib, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from zopfli_amd import ZopfliOptions, api, generate\n"
+        "data = generate('M', 4300000) + generate('R', 700000)\n"
+        "print(hashlib.sha256(api.compress(data, 0, ZopfliOptions(3))).hexdigest())\n"
+        "print(hashlib.sha256(api.deflate_part(data, 1500000, 2600000, 2, 1, ZopfliOptions(3))[0]).hexdigest())\n"
+        % os.path.dirname(os.path.dirname(__file__)))
+    res = {}
+    for devs in ("0", "0,0,0"):
+        env = dict(os.environ, ZOPFLI_AMD_DEVICES=devs)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[devs] = r.stdout.split()
+    assert res["0"] == res["0,0,0"]
+    if ol.have_ref():
+        data = generate("M", 4300000) + generate("R", 700000)
+        assert res["0"][0] == hashlib.sha256(ol.ref_compress(data, 0, 3)).hexdigest()
+
+
+def test_rccl_gather_world_of_one(gpu_ctx):
+    """zmx_dist_* (dist.cc): librccl loads, a communicator of one rank forms on the device and the
+    gather returns rank 0's own blob — all of the RCCL path a one-GPU box can run; with more ranks the
+    same calls move the other ranks' blobs (tests/test_cpu_sharding.py covers the sharding and the merge)."""
+    from zopfli_amd import Dist
+    uid = Dist.unique_id(gpu_ctx.lib)
+    assert len(uid) == 128
+    d = Dist(gpu_ctx, 0, 1, uid)
+    try:
+        blob = bytes(range(256)) * 1000
+        parts = d.gather(blob)
+        assert len(parts) == 1 and parts[0].tobytes() == blob
+        assert d.gather(b"")[0].size == 0
+    finally:
+        d.close()
 
 
 def _write_png(path, width, height, seed):

@@ -10,9 +10,9 @@ reference's interface used by the tests and by ``bench.py``:
 There is no CPU fallback: importing works anywhere, but every call needs the
 HIP library and a gfx950 device and raises otherwise.
 """
-from .api import (FORMAT_DEFLATE, FORMAT_GZIP, FORMAT_ZLIB, Context, ZopfliOptions, compress, deflate,
+from .api import (FORMAT_DEFLATE, FORMAT_GZIP, FORMAT_ZLIB, Context, Dist, ZopfliOptions, compress, deflate,
                   deflate_part, library, last_timing)
 from .datagen import generate
 
 __all__ = ["ZopfliOptions", "FORMAT_GZIP", "FORMAT_ZLIB", "FORMAT_DEFLATE", "compress", "deflate",
-           "deflate_part", "Context", "library", "generate", "last_timing"]
+           "deflate_part", "Context", "Dist", "library", "generate", "last_timing"]

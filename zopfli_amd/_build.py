@@ -6,6 +6,9 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "zopfli_amd", "csrc")
 LIB = os.path.join(ROOT, "zopfli_amd", "libzopfli_amd.so")
+# the reference's shared library is libzopfli.so.1 (Makefile:45): the same file under that name, so that
+# a program linked against the reference's library picks this one up from LD_LIBRARY_PATH
+LIB_SONAME = os.path.join(ROOT, "zopfli_amd", "libzopfli.so.1")
 DATAGEN = os.path.join(CSRC, "tools", "libzopfli_datagen.so")
 
 
@@ -28,13 +31,15 @@ def _sources():
 def build_product(force=False):
     """hipcc --offload-arch=gfx950: HIP device layer + C++ host code -> libzopfli_amd.so."""
     hip, cc, hdr = _sources()
-    if not force and not _newer(LIB, [hip] + cc + hdr):
+    if not force and not _newer(LIB, [hip] + cc + hdr) and os.path.exists(LIB_SONAME):
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-fvisibility=hidden", "-Wl,-soname,libzopfli.so.1",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(CSRC, "host"),
-           "-I" + os.path.join(CSRC, "device"), hip] + cc + ["-o", LIB, "-lpthread"]
+           "-I" + os.path.join(CSRC, "device"), hip] + cc + ["-o", LIB, "-lpthread", "-ldl"]
     subprocess.check_call(cmd)
+    shutil.copyfile(LIB, LIB_SONAME)   # (a copy, not a symlink: it has to survive the snapshot to the GPU box)
     return LIB
 
 
@@ -72,6 +77,34 @@ def build_ref_cli():
                                "-L" + os.path.dirname(LIB), "-lzopfli_amd",
                                "-Wl,-rpath," + os.path.dirname(LIB), "-o", REF_CLI])
     return REF_CLI
+
+
+REF_SO_DIR = os.path.join(ROOT, "tests", "_build", "reflib")
+REF_CLI_DYN = os.path.join(ROOT, "tests", "_build", "zopfli_ref_cli_dyn")
+
+
+def build_ref_dynamic():
+    """Test infrastructure: the reference as ITS OWN shared library (tests/_build/reflib/libzopfli.so.1,
+    soname libzopfli.so.1 as in the reference's Makefile:45) and the reference's CLI linked against it
+    with no rpath.  LD_LIBRARY_PATH decides at run time whose libzopfli.so.1 it gets — the drop-in
+    switch of an existing dynamically linked user."""
+    zsrc = "/root/reference/src/zopfli"
+    if not os.path.isdir(zsrc):
+        return None
+    os.makedirs(REF_SO_DIR, exist_ok=True)
+    so = os.path.join(REF_SO_DIR, "libzopfli.so.1")
+    lib_c = [os.path.join(zsrc, f) for f in sorted(os.listdir(zsrc)) if f.endswith(".c") and f != "zopfli_bin.c"]
+    if _newer(so, lib_c):
+        subprocess.check_call(["gcc", "-O2", "-w", "-fPIC", "-shared", "-Wl,-soname,libzopfli.so.1"] + lib_c +
+                              ["-lm", "-o", so])
+        link = os.path.join(REF_SO_DIR, "libzopfli.so")
+        if os.path.lexists(link):
+            os.remove(link)
+        shutil.copyfile(so, link)
+    if _newer(REF_CLI_DYN, [os.path.join(zsrc, "zopfli_bin.c"), so]):
+        subprocess.check_call(["gcc", "-O2", "-w", os.path.join(zsrc, "zopfli_bin.c"), "-I" + zsrc,
+                               "-L" + REF_SO_DIR, "-lzopfli", "-o", REF_CLI_DYN])
+    return REF_CLI_DYN
 
 
 PNG_AMD = os.path.join(ROOT, "tests", "_build", "zopflipng_amd")

@@ -93,6 +93,12 @@ def bind(lib):
     lib.zmx_last_kernel_timing.argtypes = [P(ctypes.c_double)]
     lib.zmx_last_host_timing.argtypes = [P(ctypes.c_double)]
     lib.zmx_last_seg_stats.argtypes = [P(ctypes.c_double)]
+    lib.zmx_last_match_timing.argtypes = [P(ctypes.c_double)]
+    lib.zmx_dist_unique_id.argtypes = [ctypes.c_char_p]
+    lib.zmx_dist_init.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, P(vp)]
+    lib.zmx_dist_destroy.argtypes = [vp]
+    lib.zmx_dist_destroy.restype = None
+    lib.zmx_dist_gather.argtypes = [vp, vp, sz, P(vp), P(sz)]
     return lib
 
 
@@ -156,6 +162,9 @@ def last_timing(lib=None):
     h = (ctypes.c_double * 2)()
     lib.zmx_last_host_timing(h)
     d["download"], d["serialize"] = h[0], h[1]
+    m = (ctypes.c_double * 4)()
+    lib.zmx_last_match_timing(m)
+    d["match_kernel"], d["hash_kernels"], d["table_builds"], d["positions_matched"] = m[0], m[1], m[2], m[3]
     return d
 
 
@@ -244,6 +253,49 @@ class Context:
         data = ctypes.string_at(addr, total) if total else b""
         _libc.free(addr)
         return data
+
+
+class Dist:
+    """zmx_dist_*: the ranks' blobs gathered to rank 0 over RCCL by the library itself (one process
+    per GPU).  `unique_id()` on rank 0, handed to the others by the launcher, then `Dist(ctx, rank,
+    world, id)` on every rank."""
+
+    @staticmethod
+    def unique_id(lib=None):
+        lib = lib or library()
+        buf = ctypes.create_string_buffer(128)
+        if lib.zmx_dist_unique_id(buf) != 0:
+            raise RuntimeError("zmx_dist_unique_id: " + (lib.zmx_last_error() or b"").decode())
+        return buf.raw
+
+    def __init__(self, ctx, rank, world, uid):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self.handle = ctypes.c_void_p()
+        ctx._check(ctx.lib.zmx_dist_init(ctx.handle, rank, world, uid, ctypes.byref(self.handle)), "zmx_dist_init")
+
+    def gather(self, blob):
+        """Returns the list of the ranks' blobs (uint8 arrays, views of one malloc'ed buffer) on rank 0,
+        None elsewhere."""
+        import numpy as np
+        src = blob if isinstance(blob, np.ndarray) else np.frombuffer(blob, dtype=np.uint8)
+        out = ctypes.c_void_p()
+        sizes = (ctypes.c_size_t * self.world)()
+        self.ctx._check(self.ctx.lib.zmx_dist_gather(self.handle, src.ctypes.data if src.size else None, src.size,
+                                                     ctypes.byref(out), sizes), "zmx_dist_gather")
+        if self.rank != 0:
+            return None
+        total = sum(sizes)
+        whole = _owned_array(out.value, total)
+        parts, off = [], 0
+        for r in range(self.world):
+            parts.append(whole[off:off + sizes[r]])
+            off += sizes[r]
+        return parts
+
+    def close(self):
+        if self.handle:
+            self.ctx.lib.zmx_dist_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
 
 
 class Tables:

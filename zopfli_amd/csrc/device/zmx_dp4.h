@@ -28,7 +28,9 @@
 // written.  Any task that fails a test is run again from the true exit state of its predecessor
 // (no guess, no warm-up), which is the serial chain itself.  Nothing unverified is ever used.
 //
-// One task is the round-1 k_dp3 pipeline, one workgroup of four waves (one per SIMD), with one
+// The speculative pass over all tasks is k_dp5_spec (zmx_dp5.h: one wave per task, built for
+// throughput).  The serial re-runs of k_dp4_fix below use the round-1 k_dp3 pipeline, built for the
+// latency of ONE chain: one workgroup of four waves (one per SIMD), with one
 // s_barrier per STEP (a run of positions of one 64-position group whose edge rows span at most
 // D3_SPAN ring slots; where a step ends depends only on dph[], never on DP values):
 //
@@ -90,7 +92,6 @@
     if (lane < 32 && jj_ >= la_lo && jj_ <= B) la[jj_] = (u16)(l[0] ? jj_ + 1 - l[0] : 0u); \
     /* wave 1 stores the lengths of a clean-flagged step from s_lout whichever path ran it */ \
     if ((WB) - base <= 32u) s_lout[it & 1][((WB) - base) * 2 + lane] = l[0]; \
-    D4_TRACK_MAX()                                                           \
     D3_ROT32()                                                               \
   }
 
@@ -104,6 +105,7 @@
 #define D3_EV_PRIME 4u   // wave 1 primes the ring at the start of the segment that follows
 
 #define SEG_CELLS 384u   // the six cell registers of the chain wave
+#define SEG_OVER 384u    // a task stops at the first window base >= pend: less than 64 + 258 cells beyond pend
 #define SEG_NONE 0xffffffffu
 
 // The state of the chain between two groups: the window of cell registers sits at `base`.
@@ -333,15 +335,21 @@ struct Dp4Params {
   const void* dsc;         // k_dp5_spec: one row descriptor per block position (k_mkdesc)
   const u32* winflag;      // k_dp5_spec: per 32-position window, 1 = can take the fast path (k_mkdesc)
   const u32* win_off;      // [nb_total] first window of each block in winflag[]
+  int debug;               // ZOPFLI_AMD_SEG_DEBUG: k_dp4_fix prints its decisions
+  u16* over;               // [tasks][SEG_OVER] lengths of the cells a speculative task computed beyond its pend
 };
 
-// What one pass of the four waves over a stretch of the chain does.
+// What one pass over a stretch of the chain does.  k_dp5_spec's jobs: the head of a block (exact: the
+// block's true initial state) and the speculative tasks (one cell holding a guessed level, entry
+// state recorded at the first window at or after pout).  k_dp4_fix's jobs: a task again, from the
+// true exit state of its predecessor.
 struct D4Job {
-  u32 start;               // first group base
+  u32 start;               // first window / group base
   u32 noshort;             // walk state there
-  u32 pout;                // spec: the entry state is recorded at the first group base >= pout
-  u32 pend;                // the walk stops at the first group base >= pend
+  u32 pout;                // spec: the entry state is recorded at the first window base >= pout
+  u32 pend;                // the walk stops at the first window / group base >= pend
   u32 la_lo;               // length_array is written for cells >= la_lo (SEG_NONE: from the entry on)
+  u32 over_lo;             // ... into `over` instead for cells >= over_lo (SEG_NONE: never)
   bool spec;
   bool load;               // initial state from `init` (+ delta) instead of a single cell holding `level`
   float level;
@@ -349,6 +357,7 @@ struct D4Job {
   const SegSnap* init;
   SegSnap* entry;
   SegSnap* exit;
+  u16* over;               // [SEG_OVER] lengths of the cells from over_lo on
 };
 
 #define D4_LDS_DECL                                                                                   \
@@ -393,7 +402,7 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
     float c[6];
     u32 l[6];
     u32 reach;   // no cell beyond window cell `reach` has been written: registers above reach >> 6 are fresh
-    if (J.load) {
+    {
 #pragma unroll
       for (int s = 0; s < 6; ++s) {
         const float ec = J.init->c[64u * s + lane];
@@ -401,14 +410,8 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
         l[s] = J.init->l[64u * s + lane];
       }
       reach = SEG_CELLS - 1;
-    } else {
-#pragma unroll
-      for (int s = 0; s < 6; ++s) { c[s] = 1e30f; l[s] = 0; }
-      if (lane == 0) c[0] = J.level;
-      reach = 0;
     }
-    u32 la_lo = J.la_lo;
-    float vmax = 0.0f;
+    const u32 la_lo = J.la_lo;
     u32 wo = 0;   // the cell registers cover cells base + wo + 64 s + lane: wo = 32 once the chain is past position 31 of the group
     u64 t_work = 0, n_fast = 0, n_slow = 0, n_steps = 0;
     u64 tp[5] = {0, 0, 0, 0, 0}, np[5] = {0, 0, 0, 0, 0};   // PROF: cycles and positions per path
@@ -446,14 +449,6 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
       const u32 base = S.base;
       u32 p0 = S.q;
       u32 bi = 0;   // block index within the step
-      if (J.spec && la_lo == SEG_NONE && S.q == 0 && base >= J.pout) {
-        // the first group at or after pout: the registers sit at its base.  From here on the task
-        // owns the length_array; what it holds now is compared with the predecessor's exit state.
-#pragma unroll
-        for (int s = 0; s < 6; ++s) { J.entry->c[64u * s + lane] = c[s]; J.entry->l[64u * s + lane] = l[s]; }
-        la_lo = base;
-        vmax = 0.0f;
-      }
       if ((dv[0] & D3_DESC_CLEAN) && reach < 64) {   // (q = 0: a new group, so wo = 0; only register 0 is live)
         // a whole group of single-register positions (the usual step): both windows' rows are
         // requested up front, the second window's arrive while the first one runs
@@ -471,7 +466,6 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
         }
         l[0] = lt ? base + lt : l[0];
         s_lout[it & 1][lane] = l[0];             // cells base .. base + 31 are final (lanes 0..31)
-        D4_TRACK_MAX()
         c[0] = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(c[0]), __float_as_uint(1e30f), false, false)[1]);
         l[0] = __builtin_amdgcn_permlane32_swap(l[0], 0u, false, false)[1];
         lt = 0;
@@ -485,7 +479,6 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
         if (PROF) { tp[0] += D3_TICK() - tk; np[0] += 64; }
         // its event is D3_EV_GROUP_END (64 positions, none flagged): retire the second window
         s_lout[it & 1][64 + lane] = l[0];        // cells base + 32 .. base + 63
-        D4_TRACK_MAX()
         c[0] = __uint_as_float(__builtin_amdgcn_permlane32_swap(__float_as_uint(c[0]), __float_as_uint(1e30f), false, false)[1]);
         l[0] = __builtin_amdgcn_permlane32_swap(l[0], 0u, false, false)[1];
         reach = 31;                              // cells up to window cell 63 were written, the window moved twice
@@ -621,7 +614,6 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
           const u32 x = wbase + 64u * s + lane;
           s_xc[64 * s + lane] = c[s];
           s_xl[64 * s + lane] = (u16)(l[s] ? x + 1 - l[s] : 0u);
-          vmax = fmaxf(vmax, c[s] < 1e29f ? c[s] : 0.0f);
         }
         wave_lds_sync();
         // costs[j+t+258] = costs[j+t] + symbolcost for t = 0..257, unconditionally; cells
@@ -652,17 +644,13 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
       ++it;
       if (last) break;
     }
-    if (J.la_lo == 1 && lane == 0) la[0] = 0;   // the head of the block
     if (J.exit) {
       // the registers sit at the base the walk stopped at (wave 1 writes the header)
 #pragma unroll
       for (int s = 0; s < 6; ++s) {
         J.exit->c[64u * s + lane] = c[s];
         J.exit->l[64u * s + lane] = l[s];
-        vmax = fmaxf(vmax, c[s] < 1e29f ? c[s] : 0.0f);
       }
-      vmax = wave_max_f32(vmax);
-      if (lane == 0) J.exit->vmax = vmax;
     }
     if (PROF && P.prof && lane == 0) {
       u64* o = P.prof + (u64)b * ZMX_PROF_N;
@@ -684,7 +672,7 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
     u32 a_prev = 0;          // a_cur of the step the chain wave works on during this iteration
     u32 it = 0, tail = 0;
     bool more = true;
-    u32 la_lo = J.la_lo;
+    const u32 la_lo = J.la_lo;
     // base and "clean" of the steps walked 1, 2, 3 iterations ago: the chain wave finished the
     // oldest during the previous iteration and left its lengths in s_lout
     u32 hb1 = 0, hb2 = 0, hb3 = 0;
@@ -729,13 +717,8 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
       cur.n = 0; cur.event = D3_EV_BUBBLE;
       hb3 = hb2; hc3 = hc2; hb2 = hb1; hc2 = hc1; hc1 = false;
       if (more) {
-        const u32 ns0 = W.noshort ? 1u : 0u;
         cur = d3_next(W, G, dbase, P.badpos + (bd.pos_off >> 5), (u32)(bd.pos_off & 31), B, lane);
         more = W.bubbles || W.base < J.pend;
-        if (J.spec && la_lo == SEG_NONE && cur.q == 0 && cur.base >= J.pout) {   // the chain wave records the cells
-          la_lo = cur.base;
-          if (lane == 0) { J.entry->base = cur.base; J.entry->noshort = ns0; }
-        }
         if (cur.n) s_tabc[it % 3][lane] = make_uint2(G.roff, G.kend);
         const bool clean = cur.q == 0 && cur.n == 64 && (G.m_r1 | G.m_bad) == 0;
         hb1 = cur.base; hc1 = clean;
@@ -884,50 +867,24 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
-// ---------------------------------------------------------------------------------------------
-// SPEC: one workgroup per task.  The first task of a block starts from the block's true initial
-// state (costs[0] = 0) and is exact; every other task starts SEG_WARM positions early from one
-// cell holding the level guessed for it.
-// ---------------------------------------------------------------------------------------------
-template <bool PROF>
-__global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_spec(Dp4Params P) {
-  D4_LDS_DECL
-  const u32 t = P.order[P.task0 + blockIdx.x];
-  const SegTask T = P.tasks[t];
-  const BlockDesc bd = P.blocks[T.block];
-  const u32 B = (u32)(bd.inend - bd.instart);
-  if (B == 0) return;
-  D4Job J;
-  J.start = T.q;
-  J.noshort = 0;
-  J.pout = T.pout;
-  J.pend = T.pend;
-  J.load = false;
-  J.delta = 0;
-  J.init = nullptr;
-  J.entry = &P.entry[t];
-  J.exit = &P.exit[t];
-  if (T.pout == 0) {       // the head of the block
-    J.spec = false;
-    J.la_lo = 1;
-    J.level = 0.0f;
-  } else {
-    J.spec = true;
-    J.la_lo = SEG_NONE;
-    J.level = P.est_bits ? P.est_bits[T.block] * ((float)T.q / (float)B) : P.lvl[t];
-    J.level *= P.level_scale;
-    if (!(J.level >= 16.0f)) J.level = 16.0f;
-    if (P.est_bits && threadIdx.x == 0) P.lvl[t] = J.level;
-  }
-  d4_run_job<PROF>(P, J, T.block, bd, s_ring, s_t1, s_t2, s_tab, s_desc, s_tabc, s_xc, s_xl, s_lout);
-}
-
 // exit[t - 1] against entry[t] for every task but the heads: one wave per task
 __global__ __launch_bounds__(64) void k_dpcheck(Dp4Params P) {
   const u32 t = P.task0 + blockIdx.x;
   if (P.tasks[t].pout == 0) return;
   const SegCheck r = d4_check(&P.exit[t - 1], &P.entry[t], threadIdx.x);
   if (threadIdx.x == 0) P.chk[t] = r;
+}
+
+// A task of the speculative pass stops at its first window base >= pend and has the lengths of the
+// cells from pend on in its side buffer, not in length_array: its successor may have started writing
+// at a SMALLER base than the one it stopped at (walks out of step after a long-run shortcut), and two
+// workgroups must not write the same cells.  Whoever accepts the task puts them in place.
+__device__ __forceinline__ void d4_copy_over(const Dp4Params& P, u32 t, u32 B, u16* la) {
+  const u32 pend = P.tasks[t].pend;
+  if (pend > B) return;                       // the last task of the block runs to the end
+  const u32 stop = P.exit[t].base;
+  const u16* over = P.over + (u64)t * SEG_OVER;
+  for (u32 i = threadIdx.x; pend + i < stop && pend + i <= B; i += blockDim.x) la[pend + i] = over[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -947,6 +904,8 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
   const bool lead = threadIdx.x == 0;
   const double wmax = (double)P.wmax[b] + 1.0;
   const u32 tiemask = P.tiemask[b];
+  u16* la_block = P.la + bd.la_off;
+  d4_copy_over(P, t0, B, la_block);   // the head is exact
   double delta_prev = 0.0;     // what has to be added to exit[t - 1] to get the true values
   bool rerun_prev = false;     // exit[t - 1] was rewritten by this workgroup: P.chk[t] is stale
   u32 n_ok = 0, n_state = 0, n_level = 0, n_tie = 0, n_pos = 0, n_values = 0;
@@ -969,7 +928,13 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
       if (!pure) { ok = false; why = 1; }
       else if (tie) { ok = false; why = 2; }
     }
+    if (P.debug && lead) {
+      printf("fix b %u t %u pout %u: match %u d %.6f delta %.6f vmin %.4f vmax %.4f why %u ok %d entry base %u exit-1 base %u\n", b,
+             t - t0, P.tasks[t].pout, ck.match, ck.d, delta, (double)ck.vmin, (double)P.exit[t].vmax, why, ok ? 1 : 0,
+             P.entry[t].base, P.exit[t - 1].base);
+    }
     if (ok) {
+      d4_copy_over(P, t, B, la_block);
       delta_prev = delta;
       rerun_prev = false;
       ++n_ok;
@@ -983,6 +948,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
     J.pout = 0;
     J.pend = T.pend;
     J.la_lo = J.start;
+    J.over_lo = SEG_NONE;    // (this workgroup is the only writer of the block's length_array now)
     J.spec = false;
     J.load = true;
     J.level = 0.0f;
@@ -990,6 +956,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
     J.init = &P.exit[t - 1];
     J.entry = nullptr;
     J.exit = &P.exit[t];
+    J.over = nullptr;
     n_pos += (T.pend < B ? T.pend : B) - (J.start < B ? J.start : B);
     __syncthreads();     // every wave has read the old exit[t] / exit[t - 1]
     d4_run_job<PROF>(P, J, b, bd, s_ring, s_t1, s_t2, s_tab, s_desc, s_tabc, s_xc, s_xl, s_lout);

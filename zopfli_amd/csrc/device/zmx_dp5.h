@@ -115,6 +115,14 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
     reach = 0;
   }
   u32 la_lo = J.la_lo;
+  // the length of cell x: into length_array, or — from pend on, where the successor may be writing
+  // already (d4_copy_over) — into the task's side buffer
+  const u32 over_lo = J.over_lo;
+  u16* const over = J.over;
+  auto put_la = [&](u32 x, u16 v) {
+    if (x < over_lo) la[x] = v;
+    else if (x - over_lo < SEG_OVER) over[x - over_lo] = v;
+  };
   float vmax = 0.0f;
   u32 wbase = (u32)__builtin_amdgcn_readfirstlane((int)J.start);
   bool noshort = J.noshort != 0;
@@ -210,7 +218,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
         const u32 j = wbase + p;
         if ((W.ms >> p) & 1) {
           // long-run shortcut at position j (squeeze.c:251-271)
-          if (lane < p && wbase + lane >= la_lo) la[wbase + lane] = (u16)(l[0] ? wbase + lane + 1 - l[0] : 0u);
+          if (lane < p && wbase + lane >= la_lo) put_la(wbase + lane, (u16)(l[0] ? wbase + lane + 1 - l[0] : 0u));
           wave_lds_sync();
 #pragma unroll
           for (int s = 0; s < 6; ++s) {
@@ -228,7 +236,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
             const u32 t = 64u * r + lane;
             nc4[r] = 1e30f;
             if (t < ZMX_MAX_MATCH) {
-              if (j + t >= la_lo) la[j + t] = s_xl[p + t];
+              if (j + t >= la_lo) put_la(j + t, s_xl[p + t]);
               nc4[r] = (float)((double)s_xc[p + t] + symbolcost258);
             }
           }
@@ -272,7 +280,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
     // ---- cells wbase .. wbase + 31 are final
     {
       const u32 jj = wbase + lane;
-      if (lane < 32 && jj >= la_lo && jj <= B) la[jj] = (u16)(l[0] ? jj + 1 - l[0] : 0u);
+      if (lane < 32 && jj >= la_lo && jj <= B) put_la(jj, (u16)(l[0] ? jj + 1 - l[0] : 0u));
       D4_TRACK_MAX()
       D3_ROT32()
       wbase += 32;
@@ -323,6 +331,8 @@ __global__ __launch_bounds__(64, WAVES) void k_dp5_spec(Dp4Params P) {
   J.init = nullptr;
   J.entry = &P.entry[t];
   J.exit = &P.exit[t];
+  J.over_lo = T.pend <= B ? T.pend : SEG_NONE;
+  J.over = P.over + (u64)t * SEG_OVER;
   if (T.pout == 0) {       // the head of the block
     J.spec = false;
     J.la_lo = 1;

@@ -25,10 +25,11 @@
 
 namespace {
 
-std::string g_err;
+thread_local std::string g_err;   // per calling thread (zmx_last_error)
 std::mutex g_stats_mutex;
 double g_kernel_seconds[3] = {0, 0, 0};  // k_edges, chain kernels (k_dp4_spec + k_dpcheck + k_dp4_fix), k_trace (HIP events)
 double g_squeeze_launches = 0;
+double g_match_stats[4] = {0, 0, 0, 0};  // k_match2 seconds, k_same + k_chain seconds, table builds, positions matched
 double g_seg_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // tasks, accepted, re-run: state / level / tie, positions re-run, re-run: values, positions
 
 int Fail(const char* what, hipError_t e, const char* file, int line) {
@@ -48,6 +49,18 @@ int FailMsg(const std::string& m) {
     if (e_ != hipSuccess) return Fail(#expr, e_, __FILE__, __LINE__); \
   } while (0)
 
+// Every zmx_* entry point runs on its context's device and leaves the calling thread's current HIP
+// device as it found it.
+struct DeviceGuard {
+  int old = -1;
+  hipError_t err;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&old) != hipSuccess) old = -1;
+    err = hipSetDevice(device);
+  }
+  ~DeviceGuard() { if (old >= 0) (void)hipSetDevice(old); }
+};
+
 constexpr u32 kMatchGrid = 1024;  // persistent workgroups: 256 CUs x 4 (LDS-limited)
 constexpr size_t kInputPad = 4096;
 
@@ -61,8 +74,6 @@ hipError_t DevAlloc(T** p, size_t n) {
 struct zmx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;   // the heads of the chain run beside the other tasks (zmx_squeeze_run)
-  hipEvent_t ev2[2] = {nullptr, nullptr};
   u8* d_in = nullptr;
   size_t insize = 0, in_cap = 0;
   const unsigned char* h_in = nullptr;  // caller's buffer (borrowed until the next zmx_set_input)
@@ -130,6 +141,7 @@ struct zmx_tables {
   SegSnap* d_entry = nullptr;
   SegSnap* d_exit = nullptr;
   SegCheck* d_chk = nullptr;
+  u16* d_over = nullptr;      // [tasks][SEG_OVER]
   float* d_runinfo = nullptr; // [3][nb]: wmax, tie mask (as bits), estimated block cost
   u32* d_segstats = nullptr;  // 8 words
   std::vector<u32> h_hist;    // the histograms of the last greedy parse / squeeze run (host copy)
@@ -207,12 +219,20 @@ int zmx_device_count(void) {
 const char* zmx_last_error(void) { return g_err.c_str(); }
 
 size_t zmx_internal_input_size(zmx_ctx* ctx) { return ctx->insize; }
+int zmx_internal_device(zmx_ctx* ctx) { return ctx->device; }
+void zmx_internal_set_error(const char* msg) { g_err = msg; }
 const unsigned char* zmx_internal_input_host(zmx_ctx* ctx) { return ctx->h_in; }
 
 void zmx_internal_seg_stats(double* out8, int reset) {
   std::lock_guard<std::mutex> lock(g_stats_mutex);
   for (int i = 0; i < 8; ++i) out8[i] = g_seg_stats[i];
   if (reset) for (int i = 0; i < 8; ++i) g_seg_stats[i] = 0;
+}
+
+void zmx_internal_match_stats(double* out4, int reset) {
+  std::lock_guard<std::mutex> lock(g_stats_mutex);
+  for (int i = 0; i < 4; ++i) out4[i] = g_match_stats[i];
+  if (reset) for (int i = 0; i < 4; ++i) g_match_stats[i] = 0;
 }
 
 void zmx_internal_kernel_stats(double* seconds3, double* squeeze_launches, int reset) {
@@ -229,7 +249,8 @@ int zmx_ctx_create(int device, zmx_ctx** out) {
   int n = 0;
   HIPCHK(hipGetDeviceCount(&n));
   if (device < 0 || device >= n) return FailMsg("zmx_ctx_create: no such HIP device");
-  HIPCHK(hipSetDevice(device));
+  DeviceGuard dev_guard(device);
+  HIPCHK(dev_guard.err);
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device));
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -238,9 +259,8 @@ int zmx_ctx_create(int device, zmx_ctx** out) {
   zmx_ctx* c = new zmx_ctx();
   c->device = device;
   HIPCHK(hipStreamCreate(&c->stream));
-  HIPCHK(hipStreamCreate(&c->stream2));
   for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
-  for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev2[i], hipEventDisableTiming));
+
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
                              CH_LDS_BYTES));
   *out = c;
@@ -249,7 +269,7 @@ int zmx_ctx_create(int device, zmx_ctx** out) {
 
 void zmx_ctx_destroy(zmx_ctx* c) {
   if (!c) return;
-  (void)hipSetDevice(c->device);
+  DeviceGuard dev_guard(c->device);
   (void)hipFree(c->d_in);
   (void)hipFree(c->d_scratch);
   (void)hipFree(c->d_rows);
@@ -257,14 +277,13 @@ void zmx_ctx_destroy(zmx_ctx* c) {
   for (auto& f : c->pool_free) (void)hipFree(f.first);
   for (auto& f : c->pool_live) (void)hipFree(f.first);
   for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-  for (int i = 0; i < 2; ++i) if (c->ev2[i]) (void)hipEventDestroy(c->ev2[i]);
-  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
 int zmx_set_input(zmx_ctx* c, const unsigned char* in, size_t insize) {
-  HIPCHK(hipSetDevice(c->device));
+  DeviceGuard dev_guard(c->device);
+  HIPCHK(dev_guard.err);
   if (insize + kInputPad > c->in_cap) {
     if (c->d_in) HIPCHK(hipFree(c->d_in));
     c->d_in = nullptr;
@@ -281,7 +300,7 @@ int zmx_set_input(zmx_ctx* c, const unsigned char* in, size_t insize) {
 
 void zmx_tables_free(zmx_ctx* c, zmx_tables* t) {
   if (!t) return;
-  if (c) (void)hipSetDevice(c->device);
+  DeviceGuard dev_guard(c ? c->device : 0);
   PoolFree(c, t->d_blocks);
   PoolFree(c, t->d_tile_off);
   PoolFree(c, t->d_same16);
@@ -316,6 +335,7 @@ void zmx_tables_free(zmx_ctx* c, zmx_tables* t) {
   PoolFree(c, t->d_entry);
   PoolFree(c, t->d_exit);
   PoolFree(c, t->d_chk);
+  PoolFree(c, t->d_over);
   PoolFree(c, t->d_runinfo);
   PoolFree(c, t->d_segstats);
   delete t;
@@ -429,6 +449,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   HIPCHK(hipMemcpyAsync(t->d_tile_off, tile_off.data(), (nb + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemsetAsync(t->d_flags, 0, 4 * sizeof(u32), c->stream));
 
+  HIPCHK(hipEventRecord(c->ev[0], c->stream));
   if (max_l > 0) {
     const dim3 g1(static_cast<unsigned>((max_l + 256 * SAME_CH - 1) / (256 * SAME_CH)), static_cast<unsigned>(nb));
     hipLaunchKernelGGL(k_same, g1, dim3(256), 0, c->stream, c->d_in, t->d_blocks, t->d_same16);
@@ -439,6 +460,8 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   }
 
   if (!c->d_scratch) HIPCHK(DevAlloc(&c->d_scratch, static_cast<size_t>(kMatchGrid) * M2_THREADS * SCRATCH_CPS));
+  HIPCHK(hipEventRecord(c->ev[1], c->stream));
+  double match_positions = 0;
 
   if (reuse) {
     // copy every record, adopt the parent's change-point pool (copied records point into it) and
@@ -527,9 +550,22 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     u32 counters[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(counters, t->d_counters, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    match_positions += static_cast<double>(pos_off);
     if ((counters[1] & 1u) == 0) break;
     if (per_pos >= 256) return FailMsg("zmx_tables_build: change-point pool overflow");
     per_pos *= 8;
+  }
+  {
+    HIPCHK(hipEventRecord(c->ev[2], c->stream));
+    HIPCHK(hipEventSynchronize(c->ev[2]));
+    float ms_hash = 0, ms_match = 0;
+    HIPCHK(hipEventElapsedTime(&ms_hash, c->ev[0], c->ev[1]));
+    HIPCHK(hipEventElapsedTime(&ms_match, c->ev[1], c->ev[2]));
+    std::lock_guard<std::mutex> lock(g_stats_mutex);
+    g_match_stats[0] += ms_match * 1e-3;
+    g_match_stats[1] += ms_hash * 1e-3;
+    g_match_stats[2] += 1;
+    g_match_stats[3] += reuse ? static_cast<double>(tile_list.size()) * MT : match_positions;
   }
 
   // DP row layout (k_rowscan) and the launch ranges that fit the row budget
@@ -593,6 +629,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     HIPCHK(PoolAlloc(c, &t->d_entry, nt));
     HIPCHK(PoolAlloc(c, &t->d_exit, nt));
     HIPCHK(PoolAlloc(c, &t->d_chk, nt));
+    HIPCHK(PoolAlloc(c, &t->d_over, nt * SEG_OVER));
     HIPCHK(PoolAlloc(c, &t->d_runinfo, 3 * nb));
     HIPCHK(PoolAlloc(c, &t->d_segstats, 8));
     HIPCHK(hipMemcpyAsync(t->d_tasks, t->tasks.data(), nt * sizeof(SegTask), hipMemcpyHostToDevice, c->stream));
@@ -627,7 +664,8 @@ int zmx_tables_build(zmx_ctx* c, const zmx_block* blocks, size_t nblocks, zmx_ta
 }
 
 int zmx_tables_build_from(zmx_ctx* c, zmx_tables* parent, const zmx_block* blocks, size_t nblocks, zmx_tables** out) {
-  HIPCHK(hipSetDevice(c->device));
+  DeviceGuard dev_guard(c->device);
+  HIPCHK(dev_guard.err);
   zmx_tables* t = new zmx_tables();
   const int rc = BuildTables(c, blocks, nblocks, t, parent);
   if (rc) {
@@ -653,7 +691,8 @@ static int CheckFlags(zmx_ctx* c, zmx_tables* t, const char* where) {
 int zmx_lz77_greedy(zmx_ctx* c, zmx_tables* t, int slot, uint32_t* nsym, uint32_t* hist) {
   if (t->nb == 0) return 0;
   if (slot != 0 && slot != 1) return FailMsg("zmx_lz77_greedy: slot must be 0 or 1");
-  HIPCHK(hipSetDevice(c->device));
+  DeviceGuard dev_guard(c->device);
+  HIPCHK(dev_guard.err);
   GreedySegParams gp;
   gp.blocks = t->d_blocks;
   gp.seg_off = t->d_seg_off;
@@ -694,16 +733,30 @@ static void RunInfo(const double* cost, const u32* hist, u32 B, float* wmax_out,
     for (int ds = 0; ds < 30; ++ds) w[n++] = (static_cast<double>(lbits(ls) + dbits(ds)) + ll[ls]) + d[ds];
   double wmax = 0;
   for (int i = 0; i < n; ++i) wmax = std::max(wmax, w[i]);
+  // dbl(w + c) = c + RNE(w / 2^(e-52)) 2^(e-52) for a float c of binade e; the float rounding of that
+  // sum ties iff the remainder modulo the float ulp 2^(e-23) is exactly half of it, i.e. iff
+  // r = RNE(w 2^(52-e)) has r mod 2^29 = 2^28.  Integer arithmetic on the mantissa: w = m 2^x.
   u32 mask = 0;
-  for (int e = 4; e < 32; ++e) {
-    bool tie = false;
-    for (int i = 0; i < n && !tie; ++i) {
-      // dbl(w + c) = c + RNE(w / 2^(e-52)) 2^(e-52) for a float c of binade e; the float rounding of
-      // that sum ties iff the remainder modulo the float ulp 2^(e-23) is exactly half of it
-      const double r = std::nearbyint(std::ldexp(w[i], 52 - e));
-      tie = std::fmod(r, 536870912.0) == 268435456.0;
+  for (int i = 0; i < n; ++i) {
+    if (!(w[i] > 0)) continue;                       // (0 shifts nothing)
+    int x;
+    const double fr = std::frexp(w[i], &x);          // w = fr 2^x, 0.5 <= fr < 1
+    const uint64_t m = static_cast<uint64_t>(std::ldexp(fr, 53));   // 53-bit integer, exact
+    x -= 53;                                         // w = m 2^x
+    for (int e = 4; e < 32; ++e) {
+      const int sh = -(x + 52 - e);                  // r = RNE(m / 2^sh)
+      uint64_t r;
+      if (sh <= 0) {
+        if (-sh >= 29) continue;                     // r is a multiple of 2^29
+        r = m << -sh;
+      } else if (sh >= 64) {
+        continue;                                    // r = 0
+      } else {
+        const uint64_t q = m >> sh, rem = m & ((1ull << sh) - 1), half = 1ull << (sh - 1);
+        r = q + ((rem > half || (rem == half && (q & 1))) ? 1 : 0);
+      }
+      if ((r & 0x1fffffffull) == 0x10000000ull) mask |= 1u << e;
     }
-    if (tie) mask |= 1u << e;
   }
   *wmax_out = static_cast<float>(wmax) + 1.0f;
   *tiemask_out = mask;
@@ -716,10 +769,17 @@ static void RunInfo(const double* cost, const u32* hist, u32 B, float* wmax_out,
   *est_out = static_cast<float>(est);
 }
 
+// Test hook (tests/test_cpu_abi.py): the acceptance facts of one cost model, no device involved.
+__attribute__((visibility("default"))) void zmx_internal_run_info(const double* cost320, float* wmax, uint32_t* tiemask) {
+  float est;
+  RunInfo(cost320, nullptr, 0, wmax, tiemask, &est);
+}
+
 int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double* mincost, const int32_t* slot,
                     uint32_t* nsym, uint32_t* hist) {
   if (t->nb == 0) return 0;
-  HIPCHK(hipSetDevice(c->device));
+  DeviceGuard dev_guard(c->device);
+  HIPCHK(dev_guard.err);
   for (size_t b = 0; b < t->nb; ++b) {
     if (slot[b] != 0 && slot[b] != 1) return FailMsg("zmx_squeeze_run: slot must be 0 or 1");
   }
@@ -810,18 +870,18 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   cp.entry = t->d_entry;
   cp.exit = t->d_exit;
   cp.chk = t->d_chk;
+  cp.over = t->d_over;
   cp.wmax = t->d_runinfo;
   cp.tiemask = reinterpret_cast<const u32*>(t->d_runinfo + nb);
   cp.stats = t->d_segstats;
   static const float level_scale = [] { const char* e = std::getenv("ZOPFLI_AMD_SEG_SCALE"); return e ? static_cast<float>(std::atof(e)) : 1.0f; }();
   cp.level_scale = level_scale;
   cp.order = t->d_task_order;
+  static const int seg_debug = [] { const char* e = std::getenv("ZOPFLI_AMD_SEG_DEBUG"); return e ? std::atoi(e) : 0; }();
+  cp.debug = seg_debug;
   cp.dsc = t->d_dsc;
   cp.winflag = t->d_winflag;
   cp.win_off = t->d_win_off;
-  // ZOPFLI_AMD_SPEC=4: the speculative pass on k_dp4's four-wave pipeline (one task per CU) instead of
-  // k_dp5's one wave per task
-  static const bool spec4 = [] { const char* e = std::getenv("ZOPFLI_AMD_SPEC"); return e && std::atoi(e) == 4; }();
   HIPCHK(hipMemsetAsync(t->d_badpos, 0, t->badpos_words * sizeof(u32), c->stream));
   TraceSegParams tp;
   tp.blocks = t->d_blocks;
@@ -853,37 +913,13 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
     // the chain: every task speculatively on all CUs, then the per-block walk that accepts or re-runs
-    if (spec4) {
-      if (cp.prof) hipLaunchKernelGGL(k_dp4_spec<true>, dim3(ntask), dpdim, 0, c->stream, cp);
-      else hipLaunchKernelGGL(k_dp4_spec<false>, dim3(ntask), dpdim, 0, c->stream, cp);
-    } else {
-      // Every task one wave, the heads (exact, several times as long as the others, and all there is of
-      // a small block) first in the launch order.  ZOPFLI_AMD_HEADS (experiments): 1 = the heads on the
-      // four-wave pipeline, one per CU, on a second stream beside the others (measured slower: the
-      // 142 KB workgroups wait for CUs the lean waves have filled); 2 = the same on one stream.
-      static const int heads_mode = [] { const char* e = std::getenv("ZOPFLI_AMD_HEADS"); return e ? std::atoi(e) : 0; }();
-      Dp4Params cl = cp;
-      unsigned nlean = ntask;
-      if (heads_mode != 0) {
-        hipStream_t hs = heads_mode == 1 ? c->stream2 : c->stream;
-        if (heads_mode == 1) {
-          HIPCHK(hipEventRecord(c->ev2[0], c->stream));
-          HIPCHK(hipStreamWaitEvent(c->stream2, c->ev2[0], 0));
-        }
-        if (cp.prof) hipLaunchKernelGGL(k_dp4_spec<true>, dim3(nblk), dpdim, 0, hs, cp);
-        else hipLaunchKernelGGL(k_dp4_spec<false>, dim3(nblk), dpdim, 0, hs, cp);
-        if (heads_mode == 1) HIPCHK(hipEventRecord(c->ev2[1], c->stream2));
-        cl.task0 = cp.task0 + nblk;
-        nlean = ntask - nblk;
-      }
-      if (nlean) {
-        // (registers for 4 or 6 waves per SIMD: ZOPFLI_AMD_D5W)
-        static const int d5w = [] { const char* e = std::getenv("ZOPFLI_AMD_D5W"); return e ? std::atoi(e) : 4; }();
-        if (cp.prof) hipLaunchKernelGGL((k_dp5_spec<true, 4>), dim3(nlean), dim3(64), 0, c->stream, cl);
-        else if (d5w == 6) hipLaunchKernelGGL((k_dp5_spec<false, 6>), dim3(nlean), dim3(64), 0, c->stream, cl);
-        else hipLaunchKernelGGL((k_dp5_spec<false, 4>), dim3(nlean), dim3(64), 0, c->stream, cl);
-      }
-      if (heads_mode == 1) HIPCHK(hipStreamWaitEvent(c->stream, c->ev2[1], 0));
+    {
+      // every task one wave, the heads (exact, several times as long as the others, and all there is of
+      // a small block) first in the launch order (registers for 4 or 6 waves per SIMD: ZOPFLI_AMD_D5W)
+      static const int d5w = [] { const char* e = std::getenv("ZOPFLI_AMD_D5W"); return e ? std::atoi(e) : 4; }();
+      if (cp.prof) hipLaunchKernelGGL((k_dp5_spec<true, 4>), dim3(ntask), dim3(64), 0, c->stream, cp);
+      else if (d5w == 6) hipLaunchKernelGGL((k_dp5_spec<false, 6>), dim3(ntask), dim3(64), 0, c->stream, cp);
+      else hipLaunchKernelGGL((k_dp5_spec<false, 4>), dim3(ntask), dim3(64), 0, c->stream, cp);
     }
     if (ntask > nblk) {
       hipLaunchKernelGGL(k_dpcheck, dim3(ntask), dim3(64), 0, c->stream, cp);
@@ -958,7 +994,8 @@ int zmx_store_download(zmx_ctx* c, zmx_tables* t, size_t block, int slot, uint16
   if (nsym == 0) return 0;
   const u32 begin = t->store_begin[slot][block];
   if (begin + nsym > t->bsize[block]) return FailMsg("zmx_store_download: nsym exceeds the store");
-  HIPCHK(hipSetDevice(c->device));
+  DeviceGuard dev_guard(c->device);
+  HIPCHK(dev_guard.err);
   std::vector<u32> tmp(nsym);
   HIPCHK(hipMemcpyAsync(tmp.data(), t->d_store[slot] + t->blocks[block].pos_off + begin, nsym * sizeof(u32),
                         hipMemcpyDeviceToHost, c->stream));
@@ -980,7 +1017,8 @@ int zmx_store_download_batch(zmx_ctx* c, zmx_tables* t, size_t n, const size_t* 
     off[i + 1] = off[i] + nsym[i];
   }
   if (off[n] == 0) return 0;
-  HIPCHK(hipSetDevice(c->device));
+  DeviceGuard dev_guard(c->device);
+  HIPCHK(dev_guard.err);
   if (off[n] > c->stage_cap) {
     if (c->h_stage) HIPCHK(hipHostFree(c->h_stage));
     c->h_stage = nullptr;
@@ -1015,7 +1053,8 @@ int zmx_find_longest_match(zmx_ctx* c, zmx_tables* t, size_t block, size_t pos, 
   if (block >= t->nb) return FailMsg("zmx_find_longest_match: bad block");
   const BlockDesc& d = t->blocks[block];
   if (pos < d.instart || pos >= d.inend) return FailMsg("zmx_find_longest_match: pos outside the block");
-  HIPCHK(hipSetDevice(c->device));
+  DeviceGuard dev_guard(c->device);
+  HIPCHK(dev_guard.err);
   if (t->probe_recs.empty()) t->probe_recs.resize(t->nb);
   std::vector<u32>& recs = t->probe_recs[block];
   if (recs.empty()) {
@@ -1056,7 +1095,8 @@ int zmx_find_longest_match(zmx_ctx* c, zmx_tables* t, size_t block, size_t pos, 
 
 int zmx_length_array_download(zmx_ctx* c, zmx_tables* t, size_t block, uint16_t* out) {
   if (block >= t->nb) return FailMsg("zmx_length_array_download: bad block");
-  HIPCHK(hipSetDevice(c->device));
+  DeviceGuard dev_guard(c->device);
+  HIPCHK(dev_guard.err);
   HIPCHK(hipMemcpy(out, t->d_la + t->blocks[block].la_off, (static_cast<size_t>(t->bsize[block]) + 1) * sizeof(u16),
                    hipMemcpyDeviceToHost));
   return 0;

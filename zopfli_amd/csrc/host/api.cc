@@ -6,7 +6,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -18,6 +20,7 @@
 // implemented by the device layer: kernel-only seconds / launches of the squeeze kernel
 extern "C" void zmx_internal_kernel_stats(double* seconds3, double* squeeze_launches, int reset);
 extern "C" void zmx_internal_seg_stats(double* out8, int reset);
+extern "C" void zmx_internal_match_stats(double* out4, int reset);
 // implemented by the device layer: size of the resident input
 extern "C" size_t zmx_internal_input_size(zmx_ctx* ctx);
 // implemented by the device layer: the caller's host copy of the resident input (borrowed)
@@ -27,22 +30,50 @@ namespace {
 
 using zamd::kMasterBlock;
 
-std::mutex g_mutex;       // one request at a time on the shared context
-zmx_ctx* g_ctx = nullptr;
+std::mutex g_mutex;       // one request at a time on the shared contexts
+std::vector<zmx_ctx*> g_ctx;   // one per device the Zopfli* entry points use
 
 [[noreturn]] void Die(const char* what) {
   std::fprintf(stderr, "zopfli_amd: %s: %s\n", what, zmx_last_error());
   std::exit(EXIT_FAILURE);
 }
 
-// The context the Zopfli* entry points run on: device ZOPFLI_AMD_DEVICE, else
-// LOCAL_RANK (one process per GPU under torchrun), else 0.
-zmx_ctx* SharedContext() {
-  if (g_ctx) return g_ctx;
-  int device = 0;
-  if (const char* e = std::getenv("ZOPFLI_AMD_DEVICE")) device = std::atoi(e);
-  else if (const char* r = std::getenv("LOCAL_RANK")) device = std::atoi(r);
-  if (zmx_ctx_create(device, &g_ctx) != 0) Die("no usable gfx950 device (there is no CPU fallback)");
+// The devices the Zopfli* entry points run on.  ZOPFLI_AMD_DEVICES = "all", a count, or a comma
+// separated list of HIP device indices (an index may repeat: two contexts on one device, which is how
+// the multi-device path is exercised on a one-GPU box); else ZOPFLI_AMD_DEVICE or LOCAL_RANK (one
+// process per GPU under torchrun) name the single device; else every visible device: master blocks
+// are independent (deflate.c:916-923), so a request with several of them is dealt across the devices.
+const std::vector<zmx_ctx*>& SharedContexts() {
+  if (!g_ctx.empty()) return g_ctx;
+  std::vector<int> devices;
+  const int visible = zmx_device_count();
+  if (const char* e = std::getenv("ZOPFLI_AMD_DEVICES")) {
+    if (std::strcmp(e, "all") == 0) {
+      for (int i = 0; i < visible; ++i) devices.push_back(i);
+    } else if (std::strchr(e, ',')) {
+      for (const char* p = e; *p;) {
+        devices.push_back(std::atoi(p));
+        const char* q = std::strchr(p, ',');
+        if (!q) break;
+        p = q + 1;
+      }
+    } else {
+      const int n = std::atoi(e);
+      for (int i = 0; i < n && i < visible; ++i) devices.push_back(i);
+    }
+  } else if (const char* e = std::getenv("ZOPFLI_AMD_DEVICE")) {
+    devices.push_back(std::atoi(e));
+  } else if (const char* r = std::getenv("LOCAL_RANK")) {
+    devices.push_back(std::atoi(r));
+  } else {
+    for (int i = 0; i < visible; ++i) devices.push_back(i);
+  }
+  if (devices.empty()) devices.push_back(0);
+  for (int d : devices) {
+    zmx_ctx* c = nullptr;
+    if (zmx_ctx_create(d, &c) != 0) Die("no usable gfx950 device (there is no CPU fallback)");
+    g_ctx.push_back(c);
+  }
   return g_ctx;
 }
 
@@ -83,6 +114,69 @@ int RunParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const std::v
   return 0;
 }
 
+// The parts of one request (positions relative to `in`) dealt over the shared contexts in contiguous
+// runs, one host thread per device; each device gets its parts' bytes plus the 32 KiB before them
+// (all a part reads: lz77.c:551-552).  Chunks come back in stream order, stored chunks carrying
+// positions relative to `in`.
+int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char* in,
+                    const std::vector<zamd::Part>& parts, std::vector<zamd::Chunk>* chunks) {
+  const std::vector<zmx_ctx*>& ctxs = SharedContexts();
+  const size_t ndev = std::min(ctxs.size(), parts.size());
+  struct Shard {
+    size_t first = 0, last = 0, base = 0;
+    std::vector<zamd::Chunk> chunks;
+    int rc = 0;
+    std::string err;
+    zamd::Timing timing;
+  };
+  std::vector<Shard> shards(ndev);
+  for (size_t d = 0; d < ndev; ++d) {
+    shards[d].first = parts.size() * d / ndev;
+    shards[d].last = parts.size() * (d + 1) / ndev;
+  }
+  auto work = [&](size_t d) {
+    Shard& sh = shards[d];
+    const size_t start = parts[sh.first].instart, end = parts[sh.last - 1].inend;
+    sh.base = start > zamd::kWindow ? start - zamd::kWindow : 0;
+    if (zmx_set_input(ctxs[d], in + sh.base, end - sh.base) != 0) {
+      sh.rc = -1;
+      sh.err = zmx_last_error();
+      return;
+    }
+    std::vector<zamd::Part> mine(parts.begin() + static_cast<long>(sh.first), parts.begin() + static_cast<long>(sh.last));
+    for (auto& p : mine) { p.instart -= sh.base; p.inend -= sh.base; }
+    sh.rc = RunParts(ctxs[d], options, btype, mine, &sh.chunks);
+    if (sh.rc) sh.err = zmx_last_error();
+    for (auto& c : sh.chunks) {
+      if (c.kind == zamd::Chunk::kStored) { c.start += sh.base; c.end += sh.base; }
+    }
+    sh.timing = zamd::ThreadTiming();
+  };
+  if (ndev == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> threads;
+    for (size_t d = 1; d < ndev; ++d) threads.emplace_back(work, d);
+    work(0);
+    for (auto& t : threads) t.join();
+    // the slowest device's breakdown stands for the request (zmx_last_timing)
+    for (size_t d = 1; d < ndev; ++d) {
+      const zamd::Timing& a = shards[d].timing;
+      zamd::Timing& t = zamd::ThreadTiming();
+      if (a.tables + a.greedy + a.squeeze + a.cost_model + a.split + a.encode >
+          t.tables + t.greedy + t.squeeze + t.cost_model + t.split + t.encode) t = a;
+    }
+  }
+  for (auto& sh : shards) {
+    if (sh.rc) {
+      std::fprintf(stderr, "zopfli_amd: device error: %s\n", sh.err.c_str());
+      return sh.rc;
+    }
+    for (auto& c : sh.chunks) chunks->push_back(std::move(c));
+  }
+  return 0;
+}
+
 // Appends merged chunks at (*out, *outsize, *bp), reference conventions.
 void EmitChunks(const std::vector<zamd::Chunk>& chunks, const unsigned char* in, unsigned char* bp,
                 unsigned char** out, size_t* outsize) {
@@ -94,6 +188,7 @@ void ResetTiming() {
   double a[8], b;
   zmx_internal_kernel_stats(a, &b, 1);
   zmx_internal_seg_stats(a, 1);
+  zmx_internal_match_stats(a, 1);
 }
 
 void PushByte(unsigned v, unsigned char** out, size_t* outsize) {
@@ -163,15 +258,12 @@ void ZopfliDeflatePart(const ZopfliOptions* options, int btype, int final, const
                        size_t instart, size_t inend, unsigned char* bp, unsigned char** out,
                        size_t* outsize) {
   std::lock_guard<std::mutex> lock(g_mutex);
-  zmx_ctx* ctx = SharedContext();
   ResetTiming();
-  // only in[windowstart, inend) is read (lz77.c:551-552); make that the resident input
-  const size_t base = instart > zamd::kWindow ? instart - zamd::kWindow : 0;
-  if (zmx_set_input(ctx, in + base, inend - base) != 0) Die("zmx_set_input");
-  std::vector<zamd::Part> parts{{instart - base, inend - base, final != 0}};
+  // only in[windowstart, inend) is read (lz77.c:551-552): that becomes the resident input
+  std::vector<zamd::Part> parts{{instart, inend, final != 0}};
   std::vector<zamd::Chunk> chunks;
-  if (RunParts(ctx, *options, btype, parts, &chunks) != 0) Die("device error");
-  EmitChunks(chunks, in + base, bp, out, outsize);
+  if (RunPartsSharded(*options, btype, in, parts, &chunks) != 0) Die("device error");
+  EmitChunks(chunks, in, bp, out, outsize);
 }
 
 void ZopfliDeflate(const ZopfliOptions* options, int btype, int final, const unsigned char* in,
@@ -179,12 +271,10 @@ void ZopfliDeflate(const ZopfliOptions* options, int btype, int final, const uns
   const size_t offset = *outsize;
   {
     std::lock_guard<std::mutex> lock(g_mutex);
-    zmx_ctx* ctx = SharedContext();
     ResetTiming();
-    if (zmx_set_input(ctx, in, insize) != 0) Die("zmx_set_input");
     const std::vector<zamd::Part> parts = MasterBlocks(insize, final != 0);
     std::vector<zamd::Chunk> chunks;
-    if (RunParts(ctx, *options, btype, parts, &chunks) != 0) Die("device error");
+    if (RunPartsSharded(*options, btype, in, parts, &chunks) != 0) Die("device error");
     EmitChunks(chunks, in, bp, out, outsize);
   }
   if (options->verbose) {
@@ -299,6 +389,11 @@ int zmx_last_timing(double* out8) {
 
 int zmx_last_kernel_timing(double* out4) {
   zmx_internal_kernel_stats(out4, &out4[3], 0);
+  return 0;
+}
+
+int zmx_last_match_timing(double* out4) {
+  zmx_internal_match_stats(out4, 0);
   return 0;
 }
 

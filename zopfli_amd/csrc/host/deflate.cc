@@ -448,20 +448,20 @@ bool DeserializeChunks(const unsigned char* blob, size_t size, std::vector<Chunk
   const uint64_t n = GetU64(blob);
   size_t off = 8;
   for (uint64_t i = 0; i < n; ++i) {
-    if (off + 18 > size) return false;
+    if (size - off < 18) return false;
     Chunk c;
     c.kind = static_cast<Chunk::Kind>(blob[off]);
     c.final_block = blob[off + 1] != 0;
     const uint64_t a = GetU64(blob + off + 2), b = GetU64(blob + off + 10);
     off += 18;
     if (c.kind == Chunk::kBits) {
-      if (off + b > size || (a + 7) / 8 > b) return false;
+      if (b > size - off || (a + 7) / 8 > b) return false;
       c.nbits = a;
       c.view = blob + off;
       c.view_bytes = b;
       off += b;
     } else if (c.kind == Chunk::kStored) {
-      if (off + b > size) return false;
+      if (b > size - off) return false;
       c.start = 0;
       c.end = b;
       c.view = blob + off;
@@ -485,9 +485,15 @@ void ReserveOutput(size_t n, unsigned char** out, size_t* outsize, bool zero) {
     oldcap = 1;
     while (oldcap < *outsize) oldcap <<= 1;
   }
-  if (cap > oldcap || *out == nullptr) {
-    void* p = std::realloc(*out, cap);
+  if (*outsize == 0) {
+    // ZOPFLI_APPEND_DATA mallocs when the size is 0, whatever *out holds (util.h:147): a caller may
+    // leave *out uninitialised
+    void* p = std::malloc(cap);
     if (!p) std::exit(-1);  // the reference also exits on allocation failure
+    *out = static_cast<unsigned char*>(p);
+  } else if (cap > oldcap) {
+    void* p = std::realloc(*out, cap);
+    if (!p) std::exit(-1);
     *out = static_cast<unsigned char*>(p);
   }
   if (zero) std::memset(*out + *outsize, 0, n);
@@ -505,9 +511,13 @@ void AppendToOutput(const uint8_t* data, size_t n, unsigned char** out, size_t* 
     oldcap = 1;
     while (oldcap < *outsize) oldcap <<= 1;
   }
-  if (cap > oldcap || *out == nullptr) {
-    void* p = std::realloc(*out, cap);
+  if (*outsize == 0) {
+    void* p = std::malloc(cap);   // (as above: *out is not looked at while the size is 0)
     if (!p) std::exit(-1);  // the reference also exits on allocation failure
+    *out = static_cast<unsigned char*>(p);
+  } else if (cap > oldcap) {
+    void* p = std::realloc(*out, cap);
+    if (!p) std::exit(-1);
     *out = static_cast<unsigned char*>(p);
   }
   std::memcpy(*out + *outsize, data, n);

@@ -16,6 +16,8 @@
 #include <thread>
 #include <vector>
 
+#include <pthread.h>
+
 namespace zamd {
 
 inline unsigned HostThreads() {
@@ -47,14 +49,12 @@ inline unsigned WideThreads() {
 
 class WorkerPool {
  public:
-  static WorkerPool& Get() {
-    static WorkerPool* pool = new WorkerPool(HostThreads());  // leaked on purpose: no join at exit
-    return *pool;
-  }
+  // The pools are created on first use and leaked on purpose (no join at exit).  A forked child has
+  // none of the worker threads: it forgets the parent's pools and makes its own on first use.
+  static WorkerPool& Get() { return Instance(0, HostThreads()); }
   static WorkerPool& Wide() {
     if (WideThreads() == HostThreads()) return Get();
-    static WorkerPool* pool = new WorkerPool(WideThreads());
-    return *pool;
+    return Instance(1, WideThreads());
   }
 
   // Runs body(i) for i in [0, n) on the workers and the calling thread; returns
@@ -77,6 +77,33 @@ class WorkerPool {
   }
 
  private:
+  static std::atomic<WorkerPool*>* Slots() {
+    static std::atomic<WorkerPool*> slots[2];
+    return slots;
+  }
+  static std::mutex& CreateMutex() {
+    static std::mutex* m = new std::mutex();   // (leaked: usable in a forked child whatever the parent held)
+    return *m;
+  }
+  static void ForgetInChild() {
+    Slots()[0].store(nullptr);
+    Slots()[1].store(nullptr);
+    new (&CreateMutex()) std::mutex();         // the parent may have forked while holding it
+  }
+  static WorkerPool& Instance(int which, unsigned threads) {
+    WorkerPool* p = Slots()[which].load(std::memory_order_acquire);
+    if (p) return *p;
+    std::lock_guard<std::mutex> lock(CreateMutex());
+    p = Slots()[which].load(std::memory_order_acquire);
+    if (!p) {
+      static std::once_flag atfork;
+      std::call_once(atfork, [] { pthread_atfork(nullptr, nullptr, &WorkerPool::ForgetInChild); });
+      p = new WorkerPool(threads);
+      Slots()[which].store(p, std::memory_order_release);
+    }
+    return *p;
+  }
+
   explicit WorkerPool(unsigned threads) {
     const unsigned extra = threads > 1 ? threads - 1 : 0;
     workers_.reserve(extra);

@@ -164,6 +164,12 @@ int zmx_store_download_batch(zmx_ctx* ctx, zmx_tables* tables, size_t n, const s
 int zmx_find_longest_match(zmx_ctx* ctx, zmx_tables* tables, size_t block, size_t pos,
                            uint16_t* sublen, uint16_t* distance, uint16_t* length);
 
+/* Parity probe: the static hash arrays of one block for positions max(0, instart - 32768) .. inend - 1
+ * (inend - windowstart entries each): same[] (hash.c:116-126) and the distances to the previous
+ * position of the same hash / of the same second hash (hash.c:110-114, 129-135; 0 = none). */
+int zmx_hash_links_download(zmx_ctx* ctx, zmx_tables* tables, size_t block, uint16_t* same,
+                            uint16_t* prev1, uint16_t* prev2);
+
 /* Parity probe: length_array[0..blocksize] of the last zmx_squeeze_run. */
 int zmx_length_array_download(zmx_ctx* ctx, zmx_tables* tables, size_t block, uint16_t* out);
 

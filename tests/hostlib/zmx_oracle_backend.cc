@@ -58,6 +58,7 @@ const unsigned char* zmx_internal_input_host(zmx_ctx* ctx) { return ctx->input.d
 void zmx_internal_kernel_stats(double* a, double* b, int) { a[0] = a[1] = a[2] = 0; *b = 0; }
 void zmx_internal_seg_stats(double* a, int) { for (int i = 0; i < 8; ++i) a[i] = 0; }
 void zmx_internal_match_stats(double* a, int) { for (int i = 0; i < 4; ++i) a[i] = 0; }
+int zmx_hash_links_download(zmx_ctx*, zmx_tables*, size_t, uint16_t*, uint16_t*, uint16_t*) { g_err = "not in the host test library"; return -1; }
 // (the RCCL gather of dist.cc is not part of the host-logic test library)
 int zmx_dist_unique_id(unsigned char*) { g_err = "no RCCL in the host test library"; return -1; }
 int zmx_dist_init(zmx_ctx*, int, int, const unsigned char*, zmx_dist**) { g_err = "no RCCL in the host test library"; return -1; }

@@ -69,6 +69,15 @@ class OracleTable:
         self.lib.zo_find_longest_match(self.h, pos, sub.ctypes.data_as(_u16p), ctypes.byref(d), ctypes.byref(l))
         return l.value, d.value, sub
 
+    def hash_links(self):
+        """same[], prev1[], prev2[] for positions windowstart .. inend - 1 (zo_same / zo_prev1 / zo_prev2)."""
+        ws = max(0, self.instart - 32768)
+        out = [np.zeros(self.inend - ws, dtype=np.uint16) for _ in range(3)]
+        for a, f in zip(out, (self.lib.zo_same, self.lib.zo_prev1, self.lib.zo_prev2)):
+            for i, p in enumerate(range(ws, self.inend)):
+                a[i] = f(self.h, p)
+        return out
+
     def greedy(self):
         B = self.inend - self.instart
         ll = np.zeros(B + 1, dtype=np.uint16)
@@ -243,9 +252,9 @@ _libc = ctypes.CDLL(None)
 _libc.free.argtypes = [ctypes.c_void_p]
 
 
-def ref_compress(data, fmt=0, numiterations=15, blocksplitting=1, blocksplittingmax=15):
+def ref_compress(data, fmt=0, numiterations=15, blocksplitting=1, blocksplittingmax=15, verbose=0, verbose_more=0):
     lib = ref()
-    o = RefOptions(0, 0, numiterations, blocksplitting, 0, blocksplittingmax)
+    o = RefOptions(verbose, verbose_more, numiterations, blocksplitting, 0, blocksplittingmax)
     out, size = ctypes.POINTER(ctypes.c_ubyte)(), ctypes.c_size_t(0)
     lib.ZopfliCompress(ctypes.byref(o), fmt, data, len(data), ctypes.byref(out), ctypes.byref(size))
     r = ctypes.string_at(out, size.value)

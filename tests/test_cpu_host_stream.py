@@ -234,3 +234,31 @@ def test_multi_device_sharding_through_the_c_entry_point():
     assert res["1"] == res["3"]
     data = generate("M", 2300000) + generate("R", 400000)
     assert res["3"][0] == hashlib.sha256(ol.ref_compress(data, 0, 1)).hexdigest()
+
+
+@pytest.mark.parametrize("more", [0, 1])
+def test_verbose_text_equals_the_references(more):
+    """ZopfliOptions::verbose / verbose_more: the library prints the reference's stderr text — block split
+    points (blocksplitter.c:148-180), "Iteration i: n bit" per block (squeeze.c:493), treesize and
+    compressed block size with the reference's byte counts (deflate.c:719-744), the final summary — in
+    the reference's order, although it computes all blocks of a call side by side."""
+    import subprocess
+    import sys
+    if not ol.have_ref():
+        pytest.skip("oracle/_ref not built")
+    body = (
+        "import sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import oracle_lib as ol\n"
+        "from zopfli_amd import ZopfliOptions, api, generate\n"
+        "data = generate('M', 1300000) + generate('R', 3000) + generate('X', 200000)\n"
+        % (os.path.dirname(os.path.dirname(__file__)), os.path.dirname(__file__)))
+    mine = body + ("out = api.compress(data, 0, ZopfliOptions(3, 1, 15, 1, %d), lib=ol.hosttest_library())\n" % more)
+    theirs = body + ("out = ol.ref_compress(data, 0, 3, 1, 15, 1, %d)\n" % more)
+    texts = []
+    for code in (mine, theirs):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        texts.append(r.stderr)
+    assert "block split points" in texts[1] and "treesize" in texts[1] and "Iteration" in texts[1]
+    assert texts[0] == texts[1]

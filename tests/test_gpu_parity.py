@@ -64,6 +64,65 @@ def test_match_table(gpu_ctx, case):
         t.free()
 
 
+@pytest.mark.parametrize("case", TABLE_CASES, ids=_ids)
+def test_hash_links(gpu_ctx, case):
+    """k_same + k_chain == the reference's hash state as static arrays (hash.c:100-137): same[] and the
+    links to the previous position of the same hash value, for both hashes, at every position of the
+    block and of the window before it."""
+    cls, n, blocks = case
+    data = generate(cls, n)
+    gpu_ctx.set_input(data)
+    t = gpu_ctx.build_tables(blocks)
+    try:
+        for b, (s, e) in enumerate(blocks):
+            if e == s:
+                continue
+            got = t.hash_links(b)
+            want = ol.OracleTable(data, s, e).hash_links()
+            for name, g, w in zip(("same", "prev1", "prev2"), got, want):
+                assert np.array_equal(g, w), f"block {b} {name}: first diff at window position {_first_diff(g, w)}"
+    finally:
+        t.free()
+
+
+def test_change_point_pool_overflow_and_retry():
+    """The change-point pool (records with more than 8 sublen change points) starting far too small
+    (ZOPFLI_AMD_POOL_ENTRIES): the build overflows and retries with a larger pool, a table built from a
+    parent whose pool is full falls through to a build of its own — the match records must not change."""
+    import subprocess
+    import sys
+    code = (
+        "import hashlib, sys\n"
+        "import numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from zopfli_amd import Context, api, generate\n"
+        "lib = api.library()\n"
+        "ctx = Context(0, lib)\n"
+        "h = hashlib.sha256()\n"
+        "for cls, n, parents, blocks in (('B', 60000, [(0, 60000)], [(0, 30000), (30000, 60000)]),\n"
+        "                                ('Z', 200000, [(0, 200000)], [(0, 40001), (40001, 200000)])):\n"
+        "    data = generate(cls, n)\n"
+        "    ctx.set_input(data)\n"
+        "    pt = ctx.build_tables(parents)\n"
+        "    t = ctx.build_tables(blocks, parent=pt)\n"
+        "    pt.free()\n"
+        "    for b, (s, e) in enumerate(blocks):\n"
+        "        for pos in range(s, e, 3):\n"
+        "            l, d, sub = t.find_longest_match(b, pos)\n"
+        "            h.update(np.array([l, d], dtype=np.uint16).tobytes() + sub[3:l + 1].tobytes())\n"
+        "    t.free()\n"
+        "print(h.hexdigest())\n" % os.path.dirname(os.path.dirname(__file__)))
+    res = {}
+    for entries in ("", "1000"):
+        env = dict(os.environ)
+        if entries:
+            env["ZOPFLI_AMD_POOL_ENTRIES"] = entries
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[entries] = r.stdout.split()[-1]
+    assert res[""] == res["1000"]
+
+
 # (class, total size, parent blocks, sub-blocks)
 REUSE_CASES = [
     ("T", 120000, [(0, 120000)], [(0, 50000), (50000, 50100), (50100, 120000)]),

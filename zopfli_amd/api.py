@@ -87,6 +87,7 @@ def bind(lib):
     lib.zmx_find_longest_match.argtypes = [vp, vp, sz, sz, P(ctypes.c_uint16), P(ctypes.c_uint16),
                                            P(ctypes.c_uint16)]
     lib.zmx_length_array_download.argtypes = [vp, vp, sz, P(ctypes.c_uint16)]
+    lib.zmx_hash_links_download.argtypes = [vp, vp, sz, P(ctypes.c_uint16), P(ctypes.c_uint16), P(ctypes.c_uint16)]
     lib.zmx_deflate_range.argtypes = [vp, opt, sz, sz, ctypes.c_int, P(_u8p), P(sz)]
     lib.zmx_chunks_merge.argtypes = [P(vp), P(sz), sz, P(ctypes.c_ubyte), P(_u8p), P(sz)]
     lib.zmx_last_timing.argtypes = [P(ctypes.c_double)]
@@ -354,6 +355,17 @@ class Tables:
                                                             ctypes.byref(d), ctypes.byref(l)),
                         "zmx_find_longest_match")
         return l.value, d.value, sub
+
+    def hash_links(self, block):
+        """same[], prev1[], prev2[] of the block's positions from windowstart on (zmx_hash_links_download)."""
+        import numpy as np
+        s, e = self.blocks[block]
+        n = e - max(0, s - 32768)
+        arrs = [np.zeros(max(n, 1), dtype=np.uint16) for _ in range(3)]
+        ptrs = [a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)) for a in arrs]
+        self.ctx._check(self.ctx.lib.zmx_hash_links_download(self.ctx.handle, self.handle, block, *ptrs),
+                        "zmx_hash_links_download")
+        return [a[:n] for a in arrs]
 
     def length_array(self, block):
         import numpy as np

@@ -521,9 +521,13 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
 
   // Change points beyond the 8 inline ones go to a pool; start with 4 entries per
   // position and grow on overflow (worst case 256 per position).
+  // (ZOPFLI_AMD_POOL_ENTRIES: test hook, the first pool has that many entries in all, so that the
+  // overflow / retry path and the fall-through from a reused parent pool run on small inputs)
+  static const u64 pool_entries = [] { const char* e = std::getenv("ZOPFLI_AMD_POOL_ENTRIES"); return e ? static_cast<u64>(std::atoll(e)) : 0ull; }();
   u64 per_pos = 4;
-  for (; !reuse;) {
+  for (bool first_try = true; !reuse; first_try = false) {
     u64 cap = std::max<u64>(pos_off * per_pos, 1u << 16);
+    if (first_try && pool_entries) cap = pool_entries;
     if (cap > 0xfffffff0ull) cap = 0xfffffff0ull;
     PoolFree(c, t->d_pool);
     t->d_pool = nullptr;
@@ -1089,6 +1093,22 @@ int zmx_find_longest_match(zmx_ctx* c, zmx_tables* t, size_t block, size_t pos, 
       for (unsigned l = prev + 1; l <= len; ++l) sublen[l] = static_cast<uint16_t>(dist);
       prev = len;
     }
+  }
+  return 0;
+}
+
+int zmx_hash_links_download(zmx_ctx* c, zmx_tables* t, size_t block, uint16_t* same, uint16_t* prev1, uint16_t* prev2) {
+  if (block >= t->nb) return FailMsg("zmx_hash_links_download: bad block");
+  DeviceGuard dev_guard(c->device);
+  HIPCHK(dev_guard.err);
+  const BlockDesc& d = t->blocks[block];
+  const size_t n = static_cast<size_t>(d.inend - d.ws);
+  std::vector<ushort4> lk(n);
+  if (n) HIPCHK(hipMemcpy(lk.data(), t->d_links + d.reg_off, n * sizeof(ushort4), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) {
+    prev1[i] = lk[i].x;
+    prev2[i] = lk[i].y;
+    same[i] = lk[i].z;
   }
   return 0;
 }

@@ -179,8 +179,8 @@ int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char
 
 // Appends merged chunks at (*out, *outsize, *bp), reference conventions.
 void EmitChunks(const std::vector<zamd::Chunk>& chunks, const unsigned char* in, unsigned char* bp,
-                unsigned char** out, size_t* outsize) {
-  zamd::MergeChunks(chunks, in, bp, out, outsize);
+                unsigned char** out, size_t* outsize, bool verbose = false) {
+  zamd::MergeChunks(chunks, in, bp, out, outsize, verbose);
 }
 
 void ResetTiming() {
@@ -263,7 +263,7 @@ void ZopfliDeflatePart(const ZopfliOptions* options, int btype, int final, const
   std::vector<zamd::Part> parts{{instart, inend, final != 0}};
   std::vector<zamd::Chunk> chunks;
   if (RunPartsSharded(*options, btype, in, parts, &chunks) != 0) Die("device error");
-  EmitChunks(chunks, in, bp, out, outsize);
+  EmitChunks(chunks, in, bp, out, outsize, options->verbose != 0);
 }
 
 void ZopfliDeflate(const ZopfliOptions* options, int btype, int final, const unsigned char* in,
@@ -275,7 +275,7 @@ void ZopfliDeflate(const ZopfliOptions* options, int btype, int final, const uns
     const std::vector<zamd::Part> parts = MasterBlocks(insize, final != 0);
     std::vector<zamd::Chunk> chunks;
     if (RunPartsSharded(*options, btype, in, parts, &chunks) != 0) Die("device error");
-    EmitChunks(chunks, in, bp, out, outsize);
+    EmitChunks(chunks, in, bp, out, outsize, options->verbose != 0);
   }
   if (options->verbose) {
     std::fprintf(stderr, "Original Size: %lu, Deflate: %lu, Compression: %f%% Removed\n",

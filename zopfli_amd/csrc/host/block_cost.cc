@@ -269,7 +269,7 @@ double CalculateBlockSizeAutoType(const Lz77Store& lz77, size_t lstart, size_t l
 }
 
 void EncodeBlock(const Lz77Store& lz77, size_t lstart, size_t lend, int btype, bool final_block,
-                 BitWriter* out) {
+                 BitWriter* out, size_t* tree_bits) {
   unsigned ll_lengths[kNumLL], d_lengths[kNumD];
   unsigned ll_codes[kNumLL], d_codes[kNumD];
   out->AddBits(final_block ? 1 : 0, 1);
@@ -282,7 +282,9 @@ void EncodeBlock(const Lz77Store& lz77, size_t lstart, size_t lend, int btype, b
     DynamicLengths(h, ll_lengths, d_lengths);
     size_t unused;
     const int enc = BestCodeLengthEncoding(ll_lengths, d_lengths, &unused);
+    const size_t before = out->BitCount();
     EncodeCodeLengths(ll_lengths, d_lengths, enc & 1, enc & 2, enc & 4, out);
+    if (tree_bits) *tree_bits = out->BitCount() - before;
   }
   LengthsToSymbols(ll_lengths, kNumLL, 15, ll_codes);
   LengthsToSymbols(d_lengths, kNumD, 15, d_codes);

@@ -35,7 +35,8 @@ size_t TreeSize(const unsigned* ll_lengths, const unsigned* d_lengths);
 
 // Emits one compressed block (btype 1 or 2) including its 3 header bits and
 // the end symbol (AddLZ77Block, deflate.c:682).
+// *tree_bits (optional): bits of the dynamic tree header (what the reference's -v prints as "treesize").
 void EncodeBlock(const Lz77Store& lz77, size_t lstart, size_t lend, int btype, bool final_block,
-                 BitWriter* out);
+                 BitWriter* out, size_t* tree_bits = nullptr);
 
 }  // namespace zamd

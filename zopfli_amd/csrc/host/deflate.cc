@@ -34,7 +34,24 @@ struct PartState {
   std::vector<size_t> splitpoints;   // final split points (symbol indices)
   std::vector<FinalBlock> finals;
   std::vector<Chunk> chunks;
+  std::string log;                   // verbose: what the reference prints for the part before its blocks are written
 };
+
+// "block split points: ..." as PrintBlockSplitPoints does (blocksplitter.c:148-180): uncompressed
+// offsets from the start of the store, decimal then hex.
+std::string SplitPointsLine(const Lz77Store& lz77, const std::vector<size_t>& points) {
+  std::string dec = "block split points: ", hex = "(hex:";
+  const size_t origin = lz77.size() ? lz77.pos(0) : 0;
+  char buf[32];
+  for (size_t p : points) {
+    const int v = static_cast<int>(lz77.pos(p) - origin);
+    std::snprintf(buf, sizeof(buf), "%d ", v);
+    dec += buf;
+    std::snprintf(buf, sizeof(buf), " %x", v);
+    hex += buf;
+  }
+  return dec + hex + ")\n";
+}
 
 Lz77Store StoreFromRun(const SymbolRun& run, size_t pos) {
   Lz77Store s;
@@ -80,7 +97,11 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
       Lz77Store s = StoreFromRun(runs[p], parts[p].instart);
       BitWriter w;
       EncodeBlock(s, 0, s.size(), 1, parts[p].final_part, &w);
-      st[p].chunks.push_back(BitsChunk(&w));
+      Chunk c = BitsChunk(&w);
+      c.log_block = true;
+      c.log_btype = 1;
+      c.log_unc = parts[p].inend - parts[p].instart;
+      st[p].chunks.push_back(std::move(c));
     });
     for (size_t p = 0; p < np; ++p) {
       for (auto& c : st[p].chunks) chunks->push_back(std::move(c));
@@ -103,6 +124,7 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
       Lz77Store s = StoreFromRun(greedy[p], parts[p].instart);
       std::vector<size_t> pts;
       BlockSplitLz77(s, static_cast<size_t>(options.blocksplittingmax), &pts);
+      if (options.verbose) st[p].log += SplitPointsLine(s, pts);   // blocksplitter.c:266-268
       split_bytes[p] = SplitPointsToBytes(s, pts, parts[p].instart);
     });
     ThreadTiming().split += Now() - t0;
@@ -136,6 +158,7 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
     const size_t npoints = s.blocks.size() - 1;
     double totalcost = 0;
     for (size_t i = 0; i <= npoints; ++i) {
+      s.log += runs[s.first_block + i].log;       // "Iteration i: n bit" (squeeze.c:493), block after block
       Lz77Store bs = StoreFromRun(runs[s.first_block + i], s.blocks[i].instart);
       totalcost += CalculateBlockSizeAutoType(bs, 0, bs.size());
       s.lz77.Append(bs);
@@ -144,6 +167,7 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
     if (options.blocksplitting && npoints > 1) {  // deflate.c:872-893
       std::vector<size_t> pts2;
       BlockSplitLz77(s.lz77, static_cast<size_t>(options.blocksplittingmax), &pts2);
+      if (options.verbose) s.log += SplitPointsLine(s.lz77, pts2);
       double totalcost2 = 0;
       for (size_t i = 0; i <= pts2.size(); ++i) {
         const size_t a = i == 0 ? 0 : pts2[i - 1];
@@ -213,17 +237,26 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
         s.chunks.push_back(std::move(c));
         continue;
       }
+      size_t tree_bits = 0;
+      int used_btype = 2;
       if (fixedcost < f.dynamic) {
+        used_btype = 1;
         if (f.expensive_fixed) {
           EncodeBlock(fixedstore, 0, fixedstore.size(), 1, final_block, &w);
         } else {
           EncodeBlock(s.lz77, f.lstart, f.lend, 1, final_block, &w);
         }
       } else {
-        EncodeBlock(s.lz77, f.lstart, f.lend, 2, final_block, &w);
+        EncodeBlock(s.lz77, f.lstart, f.lend, 2, final_block, &w, &tree_bits);
       }
-      s.chunks.push_back(BitsChunk(&w));
+      Chunk c = BitsChunk(&w);
+      c.log_block = true;
+      c.log_btype = used_btype;
+      c.log_tree_bits = tree_bits;
+      c.log_unc = s.lz77.ByteRange(f.lstart, f.lend);
+      s.chunks.push_back(std::move(c));
     }
+    if (options.verbose && !s.chunks.empty()) s.chunks.front().log_pre = std::move(s.log);
   });
   ThreadTiming().encode += Now() - t5;
 
@@ -280,7 +313,7 @@ unsigned PeekBits(const uint8_t* src, size_t src_bytes, size_t s0, unsigned n) {
 // OR-ed in afterwards.  Stored blocks follow AddNonCompressedBlock (deflate.c:625-665): pieces of
 // at most 65535 bytes, each byte-aligned after its 3 header bits.
 void MergeChunks(const std::vector<Chunk>& chunks, const unsigned char* in, unsigned char* bp,
-                 unsigned char** outp, size_t* outsize) {
+                 unsigned char** outp, size_t* outsize, bool verbose) {
   struct Place { size_t bit0; };
   std::vector<Place> place(chunks.size());
   // bit position 0 = the first bit of (*outp)[0]; *bp bits of the last byte are used
@@ -302,6 +335,20 @@ void MergeChunks(const std::vector<Chunk>& chunks, const unsigned char* in, unsi
         if (pos + piece >= c.end) break;
         pos += piece;
       }
+    }
+  }
+  if (verbose) {
+    // what the reference prints while it writes the blocks (deflate.c:719-744): byte counts of the
+    // growing output array, i.e. differences of ceil(bit position / 8)
+    for (size_t i = 0; i < chunks.size(); ++i) {
+      const Chunk& c = chunks[i];
+      if (!c.log_pre.empty()) std::fputs(c.log_pre.c_str(), stderr);
+      if (c.kind != Chunk::kBits || !c.log_block) continue;
+      const size_t p1 = place[i].bit0 + 3, p2 = p1 + c.log_tree_bits, p3 = place[i].bit0 + c.nbits;
+      if (c.log_btype == 2) std::fprintf(stderr, "treesize: %d\n", static_cast<int>((p2 + 7) / 8 - (p1 + 7) / 8));
+      const size_t compressed = (p3 + 7) / 8 - (p2 + 7) / 8;
+      std::fprintf(stderr, "compressed block size: %d (%dk) (unc: %d)\n", static_cast<int>(compressed),
+                   static_cast<int>(compressed / 1024), static_cast<int>(c.log_unc));
     }
   }
   const size_t newsize = (cur + 7) / 8;

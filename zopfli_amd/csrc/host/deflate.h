@@ -10,6 +10,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <string>
 #include <vector>
 
 #include "bit_writer.h"
@@ -29,6 +30,15 @@ struct Chunk {
   const uint8_t* view = nullptr;   // kBits: the packed bits; kStored: the raw bytes
   size_t view_bytes = 0;
 
+  // ZopfliOptions::verbose: the reference's stderr lines around this block, produced when the chunk
+  // is put into the stream (the byte counts it prints depend on the bit position, deflate.c:719-744).
+  // log_pre: printed before the block (block split points, iteration lines of the part's blocks);
+  // a compressed block then prints "treesize" (dynamic only) and "compressed block size".
+  std::string log_pre;
+  bool log_block = false;
+  int log_btype = 0;
+  size_t log_tree_bits = 0, log_unc = 0;
+
   const uint8_t* BitData() const { return view ? view : bits.data(); }
   size_t BitBytes() const { return view ? view_bytes : bits.size(); }
 };
@@ -46,7 +56,7 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
 // Appends chunks at (*out, *outsize, *bp), reference conventions (deflate.h:50-53, util.h:135-155);
 // `in` is the base of the resident input (stored chunks that still refer to it).
 void MergeChunks(const std::vector<Chunk>& chunks, const unsigned char* in, unsigned char* bp,
-                 unsigned char** out, size_t* outsize);
+                 unsigned char** out, size_t* outsize, bool verbose = false);
 
 // Stored chunks are serialised with their raw bytes (taken from `in`).  Returns a malloc'ed blob
 // (nullptr when out of memory).

@@ -206,7 +206,9 @@ int Lz77OptimalBatch(zmx_ctx* ctx, const ZopfliOptions& options, const std::vect
       // histogram only (deflate.c:584 -> :569 -> :383)
       const double c = BlockSizeFromHistogram(hh, 2);
       if (options.verbose_more || (options.verbose && c < s.bestcost)) {
-        std::fprintf(stderr, "Iteration %d: %d bit\n", i, static_cast<int>(c));
+        char line[64];
+        std::snprintf(line, sizeof(line), "Iteration %d: %d bit\n", i, static_cast<int>(c));
+        (*out)[b].log += line;   // (printed in the reference's order when the stream is assembled)
       }
       if (c < s.bestcost) {
         s.best_slot = slot[b];

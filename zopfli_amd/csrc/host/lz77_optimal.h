@@ -8,6 +8,7 @@
 // advance in lock-step, one device launch per iteration.
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 #include "zopfli_amd.h"
@@ -16,6 +17,7 @@ namespace zamd {
 
 struct SymbolRun {
   std::vector<uint16_t> litlens, dists;  // lz77.h:44-49 convention
+  std::string log;                       // ZopfliOptions::verbose: the block's "Iteration i: n bit" lines (squeeze.c:493)
 };
 
 struct Timing {

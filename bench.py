@@ -57,6 +57,18 @@ def _ref_piece(task):
     return len(out), time.perf_counter() - t0
 
 
+def usable_cpus():
+    """The CPUs this process may use: affinity and cgroup quota, not the box's hardware threads."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline_all_cores(shard, options):
     """SURVEY 8(d) secondary baseline: the real reference on EVERY host core — ZopfliDeflatePart per
     master block (deflate.c:916-923: the blocks are independent), one worker process per core, two
@@ -67,7 +79,7 @@ def cpu_baseline_all_cores(shard, options):
     import oracle_lib as ol
     if not ol.have_ref():
         return None
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     nblocks = min(len(shard) // MB, 2 * cores)
     if nblocks < 1:
         return None
@@ -83,7 +95,8 @@ def cpu_baseline_all_cores(shard, options):
         dt = time.perf_counter() - t0
     return {"value": round(nblocks / dt, 3), "unit": "MB/s", "cores": workers, "kind": "reference",
             "sample": f"first {nblocks} master blocks of the workload, ZopfliDeflatePart per master block in "
-                      f"{workers} worker processes (one per core), {dt:.1f} s wall, "
+                      f"{workers} worker processes (one per CPU this container may use: {os.cpu_count()} hardware "
+                      f"threads on the box, affinity + cgroup quota allow {cores}), {dt:.1f} s wall, "
                       f"{sum(r[1] for r in res):.0f} s of core time, {sum(r[0] for r in res)} bytes out"}
 
 

@@ -316,10 +316,11 @@ def test_full_size_round_trip(gpu_lib, case):
     assert hashlib.sha256(out).hexdigest() == case["sha256"]
 
 
-def test_row_budget_ranges():
-    """The DP edge rows of one launch are capped by ZOPFLI_AMD_ROW_BUDGET_GB; beyond it the blocks of
-    a batch are squeezed in several launch ranges.  20 MB of text needs ~1.2 GB of rows: with a 1 GB
-    budget the batch runs as two ranges and must still produce the reference's bytes."""
+def test_code_budget_smaller_batches():
+    """The DP edges of a batch (two bytes each, k_codes) are capped by ZOPFLI_AMD_CODE_BUDGET_MB; beyond it
+    the table build tells the host to come back with fewer master blocks (api.cc RunParts).  20 MB of
+    text needs ~0.4 GB of codes: with a 100 MB budget the request runs in several batches and must still
+    produce the reference's bytes."""
     import subprocess
     import sys
     code = (
@@ -329,12 +330,12 @@ def test_row_budget_ranges():
         "out = api.compress(generate('T', 20000000), 0, ZopfliOptions(2, 0))\n"
         "print(hashlib.sha256(out).hexdigest(), len(out))\n" % os.path.dirname(os.path.dirname(__file__)))
     res = {}
-    for budget in ("1", "96"):
-        env = dict(os.environ, ZOPFLI_AMD_ROW_BUDGET_GB=budget)
+    for budget in ("100", "98304"):
+        env = dict(os.environ, ZOPFLI_AMD_CODE_BUDGET_MB=budget)
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res[budget] = r.stdout.strip().split()
-    assert res["1"] == res["96"]
+    assert res["100"] == res["98304"]
 
 
 def test_reference_cli_linked_against_libzopfli_amd(tmp_path):

@@ -34,7 +34,7 @@
 // s_barrier per STEP (a run of positions of one 64-position group whose edge rows span at most
 // D3_SPAN ring slots; where a step ends depends only on dph[], never on DP values):
 //
-//   wave 1 (the walk and the ring)   walks step i: reads dph[] and k_edges' bad-edge bitmap,
+//   wave 1 (the walk and the ring)   walks step i: reads dph[] and k_badscan's bad-edge bitmap,
 //                       publishes a 6-word descriptor and the group's {row offset, kend}; keeps the
 //                       32 KB LDS row ring filled by LDS-DMA for step i - 1; turns the lengths the
 //                       chain wave left in LDS for step i - 3 into length_array.
@@ -50,11 +50,11 @@
 // bubble steps so that nobody reads the ring while wave 1 primes it.
 #pragma once
 
-// On the fast paths the mincost test of squeeze.c:293 is provably a no-op: k_edges verifies that
+// On the fast paths the mincost test of squeeze.c:293 is provably a no-op: k_wtab verifies that
 // every match edge of the position costs at least mincost (w >= mincost); rounding is monotone,
 // so fl(w + cj) >= fl(mincost + cj), hence "newCost < costs[j+k]" already implies
 // "costs[j+k] > mincostaddcostj".  A position with an edge below mincost (possible only through
-// rounding in the cost model) is reported in k_edges' bitmap and takes the generic path, which
+// rounding in the cost model) is reported in k_badscan's bitmap and takes the generic path, which
 // tests literally.
 //
 // The hot form.  The source is recorded as a small constant K (1 + index of the position in its
@@ -96,7 +96,7 @@
   }
 
 #define D3_NB 2u         // tile-building waves (waves 2..); wave 0 = the chain, wave 1 = the walk and the ring
-#define D3_SPAN 896u     // rows of four consecutive steps fit in the ring (4 * 896 + slack <= 4096)
+#define D3_SPAN 896u     // rows of four consecutive steps fit in the ring (4 * (896 + 511 of alignment) <= 8192)
 #define D3_DESC_CLEAN (1u << 25)   // descriptor word 0: a whole group, no flagged / two-register / bad-edge position
 #define D3_EV_NONE 0u
 #define D3_EV_SHORTCUT 1u
@@ -148,7 +148,7 @@ struct D3Walk {           // wave-uniform walker state (+ the per-lane dph prefe
   u32 pf_base = 0xffffffffu;
   u32 pf_sel = 0;
   uint2 pf_a = make_uint2(0, 0), pf_b = make_uint2(0, 0);
-  u32 pf_wa = 0, pf_wb = 0;   // the word of k_edges' bad-edge bitmap that holds the lane's position
+  u32 pf_wa = 0, pf_wb = 0;   // the word of k_badscan's bad-edge bitmap that holds the lane's position
 };
 
 struct D3Step {
@@ -184,7 +184,7 @@ __device__ __forceinline__ void d3_load_group(D3Walk& W, D3Group& G, const uint2
   // sits in lane (lane & 31) of the window, its edges reach cell register (kend + (lane & 31)) >> 6
   G.m_r1 = __ballot(G.kend + (lane & 31u) >= 64u);                    // needs cell register 1
   // not for the fast path: flagged, more than two registers, two registers in rows 0..31 (tile 2
-  // holds rows 32..63 only), or a match edge below mincost (k_edges' bitmap; see D3_RELAX_K)
+  // holds rows 32..63 only), or a match edge below mincost (k_badscan's bitmap; see D3_RELAX_K)
   G.m_bad = G.m_short | __ballot(G.kend + (lane & 31u) >= 128u) | (G.m_r1 & 0xffffffffull) |
             __ballot(act && ((bw >> ((pos_off + cur) & 31u)) & 1u) != 0);
   W.have_group = true;
@@ -314,12 +314,13 @@ struct Dp4Params {
   const uint2* dph;
   const double* cost;      // [nb_total][320]
   const double* mincost;   // [nb_total]
-  const double* rows;
-  const u64* row_base;
+  const u16* codes;        // the DP edges as weight codes (k_codes), block b from code_base[b] on
+  const u64* code_base;
   const u64* block_edges;
+  const double* wtab;      // [nb_total][ZMX_WTAB] the run's weights (k_wtab)
   u16* la;
   u64* prof;               // optional [nb_total][ZMX_PROF_N] counters (ZOPFLI_AMD_PROF), else null
-  const u32* badpos;       // k_edges' bad-edge bitmap
+  const u32* badpos;       // k_badscan's bad-edge bitmap
   const SegTask* tasks;
   const u32* task_off;     // [nb_total + 1] first task of each block
   float* lvl;              // [tasks] guessed value of cell q, refined by every run
@@ -331,7 +332,8 @@ struct Dp4Params {
   const u32* tiemask;      // [nb_total] bit e: a weight of the run can tie in the float rounding of binade e
   u32* stats;              // [8] tasks / accepted / re-run: state, level, tie / positions re-run / re-run: values
   float level_scale;       // test hook (ZOPFLI_AMD_SEG_SCALE): the guessed levels are multiplied by this
-  const u32* order;        // SPEC: launch order of the tasks (the long head tasks first), indexed from task0
+  const u32* wg_tasks;     // k_dp5_spec: [workgroups][4] the tasks of each workgroup (one block each; SEG_NONE = none),
+                           // the workgroups that hold a head first; task0 = first workgroup of the launch
   const void* dsc;         // k_dp5_spec: one row descriptor per block position (k_mkdesc)
   const u32* winflag;      // k_dp5_spec: per 32-position window, 1 = can take the fast path (k_mkdesc)
   const u32* win_off;      // [nb_total] first window of each block in winflag[]
@@ -361,7 +363,8 @@ struct D4Job {
 };
 
 #define D4_LDS_DECL                                                                                   \
-  __shared__ __align__(16) double s_ring[DP_FRONT + DP_RING + DP_MIRROR];                             \
+  __shared__ __align__(16) u16 s_ring[DP_FRONT + DP_RING + DP_MIRROR];   /* weight codes of the rows */ \
+  __shared__ __align__(16) double s_wtab[ZMX_WTAB];                      /* the run's weights */        \
   __shared__ __align__(16) double s_t1[2][64 * 64];   /* register-0 rows, row = position in the group */ \
   __shared__ __align__(16) double s_t2[2][32 * 64];   /* register-1 rows, row = position & 31 */      \
   __shared__ uint2 s_tab[D3_NB][64];                                                                  \
@@ -378,7 +381,8 @@ struct D4Job {
 // One job, by all four waves of the workgroup (every wave executes the same number of barriers).
 template <bool PROF>
 __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u32 b, const BlockDesc& bd,
-                                           double (&s_ring)[DP_FRONT + DP_RING + DP_MIRROR], double (&s_t1)[2][64 * 64],
+                                           u16 (&s_ring)[DP_FRONT + DP_RING + DP_MIRROR], double (&s_wtab)[ZMX_WTAB],
+                                           double (&s_t1)[2][64 * 64],
                                            double (&s_t2)[2][32 * 64], uint2 (&s_tab)[D3_NB][64], u32 (&s_desc)[3][8],
                                            uint2 (&s_tabc)[3][64], float (&s_xc)[DP_XN], u16 (&s_xl)[DP_XN],
                                            u32 (&s_lout)[2][128]) {
@@ -388,13 +392,18 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
   const u32 B = (u32)(bd.inend - bd.instart);
   const uint2* dbase = P.dph + bd.pos_off;
   u16* la = P.la + bd.la_off;
-  const double* rows = P.rows + P.row_base[b];
+  const u16* rows = P.codes + P.code_base[b];
   const u32 total_pad = (u32)((P.block_edges[b] + DP_PIECE - 1) & ~(u64)(DP_PIECE - 1));
   const double mincost = P.mincost[b];
   // squeeze.c:260: cost of (length 258, dist 1) = (0 + 0) + ll[285] + d[0]
   const double symbolcost258 = (double)(0 + 0) + P.cost[(u64)b * 320 + 285] + P.cost[(u64)b * 320 + 288];
   const double kInf = __longlong_as_double(0x7ff0000000000000ll);
-  const u32 ring_lds = (u32)(unsigned long)(__attribute__((address_space(3))) double*)s_ring;
+  const u32 ring_lds = (u32)(unsigned long)(__attribute__((address_space(3))) u16*)s_ring;
+  // the weight of the code in ring slot i (codes are byte offsets into the table; a slot that holds
+  // no code of this block — masked off by the caller — may hold anything: keep the read inside LDS)
+  auto ring_w = [&](const u16* slot) -> double {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(s_wtab) + ((u32)*slot & 0x3ff8u));
+  };
 #define D3_TICK() (PROF ? (u64)__builtin_readcyclecounter() : 0ull)
 
   if (wave == 0) {
@@ -584,7 +593,7 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
             if ((u32)s <= smax) {
               const u32 k1 = km1 + 64u * s;
               if (k1 < ke) {
-                const double w = row_code(s_ring[DP_FRONT + ((ro + k1) & (DP_RING - 1))]);
+                const double w = ring_w(&s_ring[DP_FRONT + ((ro + k1) & (DP_RING - 1))]);
                 const double mcl = k1 == 0 ? -kInf : mincost;
                 DP_RELAX(c[s], l[s], w, mcl)
               }
@@ -694,8 +703,8 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
         const u32 lim = a0 + DP_RING < total_pad ? a0 + DP_RING : total_pad;
         while (issued_end < lim) {
           const u32 slot = issued_end & (DP_RING - 1);
-          dp_dma_piece(rows + issued_end + lane * 2, ring_lds + (DP_FRONT + slot) * 8);
-          if (slot < DP_MIRROR) dp_dma_piece(rows + issued_end + lane * 2, ring_lds + (DP_FRONT + DP_RING + slot) * 8);
+          dp_dma_piece(rows + issued_end + lane * 8, ring_lds + (DP_FRONT + slot) * 2);
+          if (slot < DP_MIRROR) dp_dma_piece(rows + issued_end + lane * 8, ring_lds + (DP_FRONT + DP_RING + slot) * 2);
           issued_end += DP_PIECE;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -706,8 +715,8 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
         const u32 lim = a_prev + DP_RING < total_pad ? a_prev + DP_RING : total_pad;
         while (issued_end < lim) {
           const u32 slot = issued_end & (DP_RING - 1);
-          dp_dma_piece(rows + issued_end + lane * 2, ring_lds + (DP_FRONT + slot) * 8);
-          if (slot < DP_MIRROR) dp_dma_piece(rows + issued_end + lane * 2, ring_lds + (DP_FRONT + DP_RING + slot) * 8);
+          dp_dma_piece(rows + issued_end + lane * 8, ring_lds + (DP_FRONT + slot) * 2);
+          if (slot < DP_MIRROR) dp_dma_piece(rows + issued_end + lane * 8, ring_lds + (DP_FRONT + DP_RING + slot) * 2);
           issued_end += DP_PIECE;
         }
         if (cur.n) a_prev = cur.a_cur;
@@ -769,7 +778,7 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
       if (sn && sev != D3_EV_BUBBLE && sev != D3_EV_PRIME) {
         const uint2 tc = s_tabc[(it - 1) % 3][lane];
         wave_lds_sync();
-        s_tab[my][lane] = make_uint2(((tc.x & (DP_RING - 1)) - lane - 1) * 8u, tc.y);
+        s_tab[my][lane] = make_uint2(((tc.x & (DP_RING - 1)) - lane - 1) * 2u, tc.y);   // byte offset of slot row[-1 - lane]
         wave_lds_sync();
         double* t1 = s_t1[(it - 1) & 1];
         double* t2 = s_t2[(it - 1) & 1];
@@ -784,14 +793,14 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
           double va[16], vb[16];
 #pragma unroll
           for (int u = 0; u < 16; ++u) {
-            va[u] = reinterpret_cast<const double*>(ring0 + (int)ta[u].x)[lane];        // row[x] = edge k = x - p
-            vb[u] = reinterpret_cast<const double*>(ring0 + (int)tb[u].x)[lane + 32u];
+            va[u] = ring_w(reinterpret_cast<const u16*>(ring0 + (int)ta[u].x) + lane);        // row[x] = edge k = x - p
+            vb[u] = ring_w(reinterpret_cast<const u16*>(ring0 + (int)tb[u].x) + lane + 32u);
           }
           const u32 da = lane - pa - 1, db = lane + 32u - pb - 1;
 #pragma unroll
           for (int u = 0; u < 16; ++u) {
-            t1[(pa + u) * 64 + lane] = da - u < ta[u].y ? row_code(va[u]) : kInf;
-            t1[(pb + u) * 64 + lane] = db - u < tb[u].y ? row_code(vb[u]) : kInf;
+            t1[(pa + u) * 64 + lane] = da - u < ta[u].y ? va[u] : kInf;
+            t1[(pb + u) * 64 + lane] = db - u < tb[u].y ? vb[u] : kInf;
           }
           const u64 tk1c = D3_TICK();
           __syncthreads();
@@ -813,9 +822,9 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
               for (int u = 0; u < 16; ++u) t[u] = s_tab[my][p0 + u];
               double v0[16];
 #pragma unroll
-              for (int u = 0; u < 16; ++u) v0[u] = reinterpret_cast<const double*>(ring0 + (int)t[u].x)[wl];   // row[x] = edge k = x - p
+              for (int u = 0; u < 16; ++u) v0[u] = ring_w(reinterpret_cast<const u16*>(ring0 + (int)t[u].x) + wl);   // row[x] = edge k = x - p
 #pragma unroll
-              for (int u = 0; u < 16; ++u) t1[(p0 + u) * 64 + lane] = d0 - u < t[u].y ? row_code(v0[u]) : kInf;
+              for (int u = 0; u < 16; ++u) t1[(p0 + u) * 64 + lane] = d0 - u < t[u].y ? v0[u] : kInf;
             }
             p0 += 8;
             continue;
@@ -828,21 +837,21 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
           if (!two) {
             double v0[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v0[u] = reinterpret_cast<const double*>(ring0 + (int)t[u].x)[wl];
+            for (int u = 0; u < 8; ++u) v0[u] = ring_w(reinterpret_cast<const u16*>(ring0 + (int)t[u].x) + wl);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t1[(p0 + u) * 64 + lane] = d0 - u < t[u].y ? row_code(v0[u]) : kInf;
+            for (int u = 0; u < 8; ++u) t1[(p0 + u) * 64 + lane] = d0 - u < t[u].y ? v0[u] : kInf;
           } else {
             double v0[8], v1[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-              const double* row = reinterpret_cast<const double*>(ring0 + (int)t[u].x);
-              v0[u] = row[wl];
-              v1[u] = row[wl + 64];
+              const u16* row = reinterpret_cast<const u16*>(ring0 + (int)t[u].x);
+              v0[u] = ring_w(row + wl);
+              v1[u] = ring_w(row + wl + 64);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-              t1[(p0 + u) * 64 + lane] = d0 - u < t[u].y ? row_code(v0[u]) : kInf;
-              t2[((p0 + u) & 31) * 64 + lane] = d0 - u + 64 < t[u].y ? row_code(v1[u]) : kInf;
+              t1[(p0 + u) * 64 + lane] = d0 - u < t[u].y ? v0[u] : kInf;
+              t2[((p0 + u) & 31) * 64 + lane] = d0 - u + 64 < t[u].y ? v1[u] : kInf;
             }
           }
         }
@@ -904,6 +913,8 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
   const bool lead = threadIdx.x == 0;
   const double wmax = (double)P.wmax[b] + 1.0;
   const u32 tiemask = P.tiemask[b];
+  for (u32 i = threadIdx.x; i < ZMX_WTAB; i += blockDim.x) s_wtab[i] = P.wtab[(u64)b * ZMX_WTAB + i];
+  __syncthreads();
   u16* la_block = P.la + bd.la_off;
   d4_copy_over(P, t0, B, la_block);   // the head is exact
   double delta_prev = 0.0;     // what has to be added to exit[t - 1] to get the true values
@@ -959,7 +970,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
     J.over = nullptr;
     n_pos += (T.pend < B ? T.pend : B) - (J.start < B ? J.start : B);
     __syncthreads();     // every wave has read the old exit[t] / exit[t - 1]
-    d4_run_job<PROF>(P, J, b, bd, s_ring, s_t1, s_t2, s_tab, s_desc, s_tabc, s_xc, s_xl, s_lout);
+    d4_run_job<PROF>(P, J, b, bd, s_ring, s_wtab, s_t1, s_t2, s_tab, s_desc, s_tabc, s_xc, s_xl, s_lout);
     delta_prev = 0.0;
     rerun_prev = true;
   }

@@ -10,16 +10,17 @@
 // carry no flag (99 % of text), the wave fetches the 32 edge rows itself, straight from rows[] in
 // HBM/L2 into registers, already in the lane layout the chain wants:
 //
-//     lane l of row u  =  rows[roff_u + l - u - 1]   if 0 <= l - u - 1 < kend_u, else +inf
+//     lane l of row u  =  wtab[codes[roff_u + l - u - 1]]   if 0 <= l - u - 1 < kend_u, else +inf
 //
 // with everything per position on the scalar side: a ready-made buffer descriptor whose buffer IS
-// the row (base rows + roff, kend * 8 bytes; k_mkdesc) arrives by s_load (uniform address); lane l
-// asks for offset 8 (l - u - 1), which wraps below the row and overshoots beyond it, so the
-// hardware's range check drops those lanes before they reach the L1 (a plain 64-lane load of 8 bytes
-// per lane costs ~17 L1 accesses whatever the lanes point at: measured, the kernel was L1-bound)
-// and returns zero for them, which the row encoding (ZMX_ROW_KEY) turns into an edge nobody takes —
-// 2 VALU instructions and one buffer_load_dwordx2 per position, then the 8-instruction chain step
-// of k_dp4.  Other windows (long matches, shortcut flags, edges below mincost, ragged
+// the row's 16-bit weight codes (base codes + roff, kend * 2 bytes; k_mkdesc) arrives by s_load
+// (uniform address); lane l asks for offset 2 (l - u - 1), which wraps below the row and overshoots
+// beyond it, so the hardware's range check drops those lanes before they reach the L1 (a plain
+// 64-lane load costs an L1 access per 32 bytes of lanes whatever they point at: measured, the first
+// version was L1-bound) and returns zero for them — the code of "no edge", weight +inf.  The weight
+// itself comes from the run's table (k_wtab) that the four waves of the workgroup, four tasks of one
+// block, share in LDS: one buffer_load_ushort, one ds_read_b64 and one VALU instruction per position,
+// then the 8-instruction chain step of k_dp4.  Other windows (long matches, shortcut flags, edges below mincost, ragged
 // tails) take the generic path, position by position, with the reference's tests literally.
 #pragma once
 
@@ -36,13 +37,13 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
 typedef u32 d5_u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) d5_u32x4* d5_cdscp;
 
-// One buffer descriptor per block position whose buffer IS the position's edge row: base = its first
-// slot in rows[], kend * 8 bytes long (k_mkdesc, whenever the table set meets a new rows[] array).
+// One buffer descriptor per block position whose buffer IS the position's row of weight codes: base =
+// its first slot in codes[], kend * 2 bytes long (k_mkdesc, once per table build).
 struct MkDescParams {
   const BlockDesc* blocks;
   const uint2* dph;
-  const u64* row_base;
-  const double* rows;
+  const u64* code_base;
+  const u16* codes;
   d5_u32x4* dsc;
   const u32* win_off;   // [nb] first entry of each block in winflag[]
   u32* winflag;         // per 32-position window of a block (aligned to the block start): 1 = 32 positions, none flagged
@@ -63,11 +64,11 @@ __global__ __launch_bounds__(256) void k_mkdesc(MkDescParams P) {
   }
   if (p >= B) return;
   const uint2 dh = dhw;
-  const u64 a = reinterpret_cast<u64>(P.rows + P.row_base[blockIdx.y] + dh.x);
+  const u64 a = reinterpret_cast<u64>(P.codes + P.code_base[blockIdx.y] + dh.x);
   d5_u32x4 d;
   d.x = (u32)a;
   d.y = (u32)(a >> 32) & 0xffffu;     // stride 0
-  d.z = (dh.y & 0xffffu) * 8u;        // bytes in the row
+  d.z = (dh.y & 0xffffu) * 2u;        // bytes in the row
   d.w = 0x00020000u;                  // raw 32-bit data format
   P.dsc[bd.pos_off + p] = d;
 }
@@ -80,15 +81,19 @@ struct D5Cls {          // one window on the generic path: lane l < 32 = positio
 
 template <bool PROF>
 __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u32 b, const BlockDesc& bd,
-                                           float (&s_xc)[DP_XN], u16 (&s_xl)[DP_XN]) {
+                                           const double (&s_wtab)[ZMX_WTAB], float (&s_xc)[DP_XN], u16 (&s_xl)[DP_XN]) {
   const u32 lane = threadIdx.x & 63;
-  const u32 lane8 = lane * 8u;
+  const u32 lane2 = lane * 2u;
   const u32 B = (u32)(bd.inend - bd.instart);
   const uint2* __restrict__ dbase = uniform_ptr(P.dph + bd.pos_off);
   const u32* __restrict__ badpos = uniform_ptr(P.badpos + (bd.pos_off >> 5));
   const u32 bit_off = (u32)(bd.pos_off & 31);
   u16* la = P.la + bd.la_off;
-  const double* __restrict__ rows = uniform_ptr(P.rows + P.row_base[b]);
+  const u16* __restrict__ rows = uniform_ptr(P.codes + P.code_base[b]);
+  // the weight of a code (a byte offset into the run's table)
+  auto code_w = [&](u32 code) -> double {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(s_wtab) + code);
+  };
   const d5_u32x4* __restrict__ dsc = uniform_ptr(static_cast<const d5_u32x4*>(P.dsc) + bd.pos_off);
   typedef const __attribute__((address_space(4))) u32* cu32p;
   const cu32p winflag = (cu32p)uniform_ptr(P.winflag + P.win_off[b]);
@@ -129,19 +134,20 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
   u64 n_fast = 0, n_slow = 0;
   const u64 t_begin = PROF ? (u64)__builtin_readcyclecounter() : 0ull;
 
-  // rows of positions WB + U0 .. WB + U0 + 15 into WV: the row is the buffer; lanes below u + 1 (the
-  // offset wraps) and beyond u + kend are out of range, never reach the cache and come back as
-  // zero = 2^1023 decoded
+  // weights of the rows of positions WB + U0 .. WB + U0 + 15 into WV: the row's codes are the buffer;
+  // lanes below u + 1 (the offset wraps) and beyond u + kend are out of range, never reach the cache
+  // and come back as code 0 = +inf
 #define D5_ISSUE(WV, WB, U0)                                                                      \
   {                                                                                               \
     const d5_cdscp dw_ = (d5_cdscp)(dsc + (WB) + (U0));     /* uniform: s_load */                  \
+    u32 cd_[16];                                                                                  \
     _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                              \
       const d5_u32x4 d_ = dw_[u];                                                                 \
       const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                       \
           reinterpret_cast<void*>(((u64)d_.y << 32) | d_.x), (short)0, (int)d_.z, (int)d_.w);     \
-      const auto x_ = __builtin_amdgcn_raw_buffer_load_b64(rs_, (int)(lane8 - 8u * (u32)((U0) + u + 1)), 0, 0); \
-      WV[u] = __longlong_as_double((long long)(((u64)(x_[1] ^ (u32)(ZMX_ROW_KEY >> 32)) << 32) | x_[0])); \
+      cd_[u] = (u32)(u16)__builtin_amdgcn_raw_buffer_load_b16(rs_, (int)(lane2 - 2u * (u32)((U0) + u + 1)), 0, 0); \
     }                                                                                             \
+    _Pragma("unroll") for (int u = 0; u < 16; ++u) WV[u] = code_w(cd_[u]);                        \
   }
   // the chain over positions U0 .. U0 + 15 of the window at wbase
 #define D5_CHAIN(WV, U0)                                                                          \
@@ -160,7 +166,6 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
     const u64 two = ((u64)badw[(g >> 5) + 1] << 32) | badw[g >> 5];
     return (u32)(two >> (g & 31u)) == 0;
   };
-  u32 touched = 0, sink = 0;
   while (wbase < J.pend) {          // (J.pend = B + 1 on the last task: the window at B retires cell B)
     wbase = (u32)__builtin_amdgcn_readfirstlane((int)wbase);
     if (J.spec && la_lo == SEG_NONE && wbase >= J.pout) {
@@ -182,16 +187,6 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
       double wv0[16], wv1[16];
       D5_ISSUE(wv0, wbase, 0)
       D5_ISSUE(wv1, wbase, 16)
-      // Touch the rows of the next window (one word per 128-byte line over 8 KB from its first row) so
-      // that they are on their way from HBM to the L2 while this window's chain runs; the word read is
-      // folded into `sink` an iteration later, when it has long arrived.
-      sink ^= touched;
-      touched = 0;
-      if (wbase + 32u < B) {
-        const d5_u32x4 dn = ((d5_cdscp)(dsc + wbase + 32u))[0];
-        const char* tp = reinterpret_cast<const char*>(((u64)dn.y << 32) | dn.x);
-        touched = *reinterpret_cast<const u32*>(tp + lane * 128u);
-      }
       u32 lt_ = 0;                             // 1 + index of the last position that updated the cell
       D5_CHAIN(wv0, 0)
       D5_CHAIN(wv1, 16)
@@ -266,7 +261,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
           if ((u32)s <= smax) {
             const u32 k1 = km1 + 64u * s;
             if (k1 < ke) {
-              const double w = row_code(rows[ro + k1]);
+              const double w = code_w(rows[ro + k1]);
               const double mcl = k1 == 0 ? -kInf : mincost;
               DP_RELAX(c[s], l[s], w, mcl)
             }
@@ -289,7 +284,6 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
 #undef D5_ISSUE
 #undef D5_CHAIN
   if (J.la_lo == 1 && lane == 0) la[0] = 0;   // the head of the block
-  if ((sink ^ touched) == 0x9e3779b9u && lane == 77u) la[0] = 1;   // (never: lane < 64; keeps the touches alive)
   if (J.exit) {
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
@@ -312,11 +306,22 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
   }
 }
 
+// One workgroup = four waves = up to four tasks of ONE block (P.wg_tasks), sharing the run's weight
+// table in LDS; after the table is in place the waves go their own ways.
+#define D5_WG 4u
 template <bool PROF, int WAVES>
-__global__ __launch_bounds__(64, WAVES) void k_dp5_spec(Dp4Params P) {
-  __shared__ float s_xc[DP_XN];
-  __shared__ u16 s_xl[DP_XN];
-  const u32 t = P.order[P.task0 + blockIdx.x];
+__global__ __launch_bounds__(64 * D5_WG, WAVES) void k_dp5_spec(Dp4Params P) {
+  __shared__ __align__(16) double s_wtab[ZMX_WTAB];
+  __shared__ float s_xc[D5_WG][DP_XN];
+  __shared__ u16 s_xl[D5_WG][DP_XN];
+  const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const u32* wg = P.wg_tasks + (u64)(P.task0 + blockIdx.x) * D5_WG;
+  const u32 t0 = wg[0];
+  const u32 b0 = P.tasks[t0].block;
+  for (u32 i = threadIdx.x; i < ZMX_WTAB; i += 64 * D5_WG) s_wtab[i] = P.wtab[(u64)b0 * ZMX_WTAB + i];
+  __syncthreads();
+  const u32 t = wg[wave];
+  if (t == SEG_NONE) return;
   const SegTask T = P.tasks[t];
   const BlockDesc bd = P.blocks[T.block];
   const u32 B = (u32)(bd.inend - bd.instart);
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(64, WAVES) void k_dp5_spec(Dp4Params P) {
     J.level = P.est_bits ? P.est_bits[T.block] * ((float)T.q / (float)B) : P.lvl[t];
     J.level *= P.level_scale;
     if (!(J.level >= 16.0f)) J.level = 16.0f;
-    if (P.est_bits && threadIdx.x == 0) P.lvl[t] = J.level;
+    if (P.est_bits && (threadIdx.x & 63) == 0) P.lvl[t] = J.level;
   }
-  d5_run_job<PROF>(P, J, T.block, bd, s_xc, s_xl);
+  d5_run_job<PROF>(P, J, T.block, bd, s_wtab, s_xc[wave], s_xl[wave]);
 }

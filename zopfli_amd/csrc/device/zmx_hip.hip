@@ -27,7 +27,7 @@ namespace {
 
 thread_local std::string g_err;   // per calling thread (zmx_last_error)
 std::mutex g_stats_mutex;
-double g_kernel_seconds[3] = {0, 0, 0};  // k_edges, chain kernels (k_dp4_spec + k_dpcheck + k_dp4_fix), k_trace (HIP events)
+double g_kernel_seconds[3] = {0, 0, 0};  // k_wtab + k_badscan, chain kernels (k_dp5_spec + k_dpcheck + k_dp4_fix), k_trace (HIP events)
 double g_squeeze_launches = 0;
 double g_match_stats[4] = {0, 0, 0, 0};  // k_match2 seconds, k_same + k_chain seconds, table builds, positions matched
 double g_seg_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // tasks, accepted, re-run: state / level / tie, positions re-run, re-run: values, positions
@@ -61,6 +61,7 @@ struct DeviceGuard {
   ~DeviceGuard() { if (old >= 0) (void)hipSetDevice(old); }
 };
 
+constexpr int kTooLarge = -2;   // zmx_tables_build*: the batch does not fit the code budget, try fewer blocks
 constexpr u32 kMatchGrid = 1024;  // persistent workgroups: 256 CUs x 4 (LDS-limited)
 constexpr size_t kInputPad = 4096;
 
@@ -78,8 +79,6 @@ struct zmx_ctx {
   size_t insize = 0, in_cap = 0;
   const unsigned char* h_in = nullptr;  // caller's buffer (borrowed until the next zmx_set_input)
   u32* d_scratch = nullptr;  // k_match2 per-lane overflow change points
-  double* d_rows = nullptr;  // DP edge costs of the blocks of one k_edges / chain launch (grow-only)
-  size_t rows_cap = 0;
   // table arrays are recycled between batches and calls: hipMalloc/hipFree of multi-GB arrays
   // cost more than the kernels that fill them
   std::unordered_map<void*, size_t> pool_live;
@@ -112,17 +111,18 @@ struct zmx_tables {
   int* d_slot = nullptr;
   uint2* d_dph = nullptr;         // per position: DP row offset, kend | shortcut flag (k_rowscan)
   u64* d_block_edges = nullptr;   // per block: DP edges
-  u32* d_badpos = nullptr;        // bit per position: k_edges found a match edge below mincost (per run)
+  u32* d_badpos = nullptr;        // bit per position: it owns a match edge below mincost (k_badscan, per run)
   size_t badpos_words = 0;
-  u64* d_row_base = nullptr;      // per block: first slot in ctx->d_rows for its launch range
+  u64* d_code_base = nullptr;     // per block: first slot in d_codes
+  u16* d_codes = nullptr;         // the DP edges as weight codes (k_codes)
+  double* d_wtab = nullptr;       // [nb][ZMX_WTAB] the weights of the current run (k_wtab)
+  u32* d_badcodes = nullptr;      // [nb][40] the weights below mincost (k_wtab)
   u32* d_seg_off = nullptr;       // per block: first trace segment (cumulative)
   u32* d_extab = nullptr;         // per trace segment: exit table (k_trace_exits)
   uint2* d_seginfo = nullptr;     // per trace segment: entry, symbol offset (k_trace_link)
   std::vector<u32> seg_off;
   std::vector<u64> block_edges;
   std::vector<u32> tile_off;
-  std::vector<std::pair<u32, u32>> ranges;  // blocks [first, last) squeezed together (row budget)
-  u64 max_range_rows = 0;
   u32* d_counters = nullptr;  // 16 words, see MatchParams
   u32* d_flags = nullptr;     // 4 words
   u64* d_prof = nullptr;      // nb * ZMX_PROF_N counters when ZOPFLI_AMD_PROF is set
@@ -131,9 +131,9 @@ struct zmx_tables {
   std::vector<u32> task_off;  // [nb + 1]
   SegTask* d_tasks = nullptr;
   u32* d_task_off = nullptr;
-  u32* d_task_order = nullptr;
-  d5_u32x4* d_dsc = nullptr;       // per position: the buffer descriptor of its edge row (k_mkdesc)
-  const double* dsc_rows = nullptr; // the rows[] array the descriptors point into
+  u32* d_wg_tasks = nullptr;       // k_dp5_spec's workgroups: four tasks of one block each
+  u32 n_wg = 0;
+  d5_u32x4* d_dsc = nullptr;       // per position: the buffer descriptor of its row of weight codes (k_mkdesc)
   u32* d_winflag = nullptr;        // per 32-position window: fast path possible (k_mkdesc)
   u32* d_win_off = nullptr;        // [nb]
   std::vector<u32> win_off;
@@ -272,7 +272,6 @@ void zmx_ctx_destroy(zmx_ctx* c) {
   DeviceGuard dev_guard(c->device);
   (void)hipFree(c->d_in);
   (void)hipFree(c->d_scratch);
-  (void)hipFree(c->d_rows);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   for (auto& f : c->pool_free) (void)hipFree(f.first);
   for (auto& f : c->pool_live) (void)hipFree(f.first);
@@ -318,7 +317,10 @@ void zmx_tables_free(zmx_ctx* c, zmx_tables* t) {
   PoolFree(c, t->d_dph);
   PoolFree(c, t->d_block_edges);
   PoolFree(c, t->d_badpos);
-  PoolFree(c, t->d_row_base);
+  PoolFree(c, t->d_code_base);
+  PoolFree(c, t->d_codes);
+  PoolFree(c, t->d_wtab);
+  PoolFree(c, t->d_badcodes);
   PoolFree(c, t->d_seg_off);
   PoolFree(c, t->d_extab);
   PoolFree(c, t->d_seginfo);
@@ -327,7 +329,7 @@ void zmx_tables_free(zmx_ctx* c, zmx_tables* t) {
   PoolFree(c, t->d_prof);
   PoolFree(c, t->d_tasks);
   PoolFree(c, t->d_task_off);
-  PoolFree(c, t->d_task_order);
+  PoolFree(c, t->d_wg_tasks);
   PoolFree(c, t->d_dsc);
   PoolFree(c, t->d_winflag);
   PoolFree(c, t->d_win_off);
@@ -442,7 +444,9 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   HIPCHK(PoolAlloc(c, &t->d_block_edges, nb));
   t->badpos_words = pos_off / 32 + 4;
   HIPCHK(PoolAlloc(c, &t->d_badpos, t->badpos_words));
-  HIPCHK(PoolAlloc(c, &t->d_row_base, nb));
+  HIPCHK(PoolAlloc(c, &t->d_code_base, nb));
+  HIPCHK(PoolAlloc(c, &t->d_wtab, nb * ZMX_WTAB));
+  HIPCHK(PoolAlloc(c, &t->d_badcodes, nb * 40));
   HIPCHK(PoolAlloc(c, &t->d_counters, 16));
   HIPCHK(PoolAlloc(c, &t->d_flags, 4));
   HIPCHK(hipMemcpyAsync(t->d_blocks, t->blocks.data(), nb * sizeof(BlockDesc), hipMemcpyHostToDevice, c->stream));
@@ -572,7 +576,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     g_match_stats[3] += reuse ? static_cast<double>(tile_list.size()) * MT : match_positions;
   }
 
-  // DP row layout (k_rowscan) and the launch ranges that fit the row budget
+  // DP row layout (k_rowscan), then the edges as weight codes (k_codes) and a buffer descriptor per row
   RowScanParams rp;
   rp.blocks = t->d_blocks;
   rp.recs = t->d_recs;
@@ -583,28 +587,59 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   t->block_edges.resize(nb);
   HIPCHK(hipMemcpyAsync(t->block_edges.data(), t->d_block_edges, nb * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  static const u64 budget = [] {
-    u64 gb = 96;
-    if (const char* e = std::getenv("ZOPFLI_AMD_ROW_BUDGET_GB")) gb = std::max<long>(1, std::atol(e));
-    return gb * (1ull << 30) / sizeof(double);
-  }();
-  std::vector<u64> row_base(nb, 0);
-  u64 cur = 0;
-  u32 first = 0;
-  for (size_t b = 0; b < nb; ++b) {
-    const u64 pad = ((t->block_edges[b] + 127) & ~127ull) + 128;
-    if (cur + pad > budget && b > first) {
-      t->ranges.emplace_back(first, static_cast<u32>(b));
-      t->max_range_rows = std::max(t->max_range_rows, cur);
-      first = static_cast<u32>(b);
-      cur = 0;
+  {
+    // ZOPFLI_AMD_CODE_BUDGET_MB: what the codes of one batch may take (two bytes per DP edge; a position
+    // has 1..258 edges).  Beyond it the caller is told to come back with fewer blocks (kTooLarge).
+    static const u64 budget = [] {
+      u64 mb = 96ull << 10;
+      if (const char* e = std::getenv("ZOPFLI_AMD_CODE_BUDGET_MB")) mb = static_cast<u64>(std::max<long>(1, std::atol(e)));
+      return mb * (1ull << 20) / sizeof(u16);
+    }();
+    std::vector<u64> code_base(nb, 0);
+    u64 cur = 0;
+    for (size_t b = 0; b < nb; ++b) {
+      if (t->block_edges[b] > 0xffff0000ull) return FailMsg("zmx_tables_build: block too large (DP row offsets are 32-bit)");
+      code_base[b] = cur;
+      cur += ((t->block_edges[b] + DP_PIECE - 1) & ~static_cast<u64>(DP_PIECE - 1)) + DP_PIECE;   // (the ring's DMA reads whole pieces)
     }
-    row_base[b] = cur;
-    cur += pad;
+    if (cur > budget && nb > 1) {
+      g_err = "zmx_tables_build: the batch needs more room for its DP edges than ZOPFLI_AMD_CODE_BUDGET_MB allows";
+      return kTooLarge;
+    }
+    HIPCHK(PoolAlloc(c, &t->d_codes, cur));
+    HIPCHK(hipMemcpyAsync(t->d_code_base, code_base.data(), nb * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    CodeParams kp;
+    kp.blocks = t->d_blocks;
+    kp.tile_off = t->d_tile_off;
+    kp.nb_total = static_cast<u32>(nb);
+    kp.recs = t->d_recs;
+    kp.pool = t->d_pool;
+    kp.dph = t->d_dph;
+    kp.codes = t->d_codes;
+    kp.code_base = t->d_code_base;
+    if (tile_off[nb]) hipLaunchKernelGGL(k_codes, dim3(tile_off[nb]), dim3(256), 0, c->stream, kp);
+    HIPCHK(hipGetLastError());
+    // one descriptor per position and the window flags of k_dp5_spec
+    HIPCHK(PoolAlloc(c, &t->d_dsc, t->total_b));
+    t->win_off.assign(nb + 1, 0);
+    for (size_t b = 0; b < nb; ++b) t->win_off[b + 1] = t->win_off[b] + (t->bsize[b] + 31) / 32;
+    HIPCHK(PoolAlloc(c, &t->d_winflag, t->win_off[nb]));
+    HIPCHK(PoolAlloc(c, &t->d_win_off, nb + 1));
+    HIPCHK(hipMemcpyAsync(t->d_win_off, t->win_off.data(), (nb + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+    MkDescParams mp;
+    mp.blocks = t->d_blocks;
+    mp.dph = t->d_dph;
+    mp.code_base = t->d_code_base;
+    mp.codes = t->d_codes;
+    mp.dsc = t->d_dsc;
+    mp.win_off = t->d_win_off;
+    mp.winflag = t->d_winflag;
+    u32 max_b = 1;
+    for (size_t b = 0; b < nb; ++b) max_b = std::max(max_b, t->bsize[b]);
+    hipLaunchKernelGGL(k_mkdesc, dim3((max_b + 255) / 256, static_cast<unsigned>(nb)), dim3(256), 0, c->stream, mp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));   // (code_base is a local)
   }
-  t->ranges.emplace_back(first, static_cast<u32>(nb));
-  t->max_range_rows = std::max(t->max_range_rows, cur);
-  HIPCHK(hipMemcpyAsync(t->d_row_base, row_base.data(), nb * sizeof(u64), hipMemcpyHostToDevice, c->stream));
   // the chain's tasks (zmx_dp4.h): SEG_L positions each, the last one of a block takes the remainder
   {
     const u32 L = SegL(), warm = SegWarm();
@@ -626,7 +661,6 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
       t->task_off[b + 1] = static_cast<u32>(t->tasks.size());
     }
     const size_t nt = t->tasks.size();
-    HIPCHK(PoolAlloc(c, &t->d_task_order, nt));
     HIPCHK(PoolAlloc(c, &t->d_tasks, nt));
     HIPCHK(PoolAlloc(c, &t->d_task_off, nb + 1));
     HIPCHK(PoolAlloc(c, &t->d_lvl, nt));
@@ -641,16 +675,21 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     HIPCHK(hipMemsetAsync(t->d_segstats, 0, 8 * sizeof(u32), c->stream));
   }
   {
-    // the tasks' launch order, per launch range: the heads (several times the length of the others) first
-    std::vector<u32> order(t->tasks.size());
-    for (const auto& r : t->ranges) {
-      u32 at = t->task_off[r.first];
-      for (u32 b = r.first; b < r.second; ++b) order[at++] = t->task_off[b];
-      for (u32 b = r.first; b < r.second; ++b)
-        for (u32 k = t->task_off[b] + 1; k < t->task_off[b + 1]; ++k) order[at++] = k;
+    // k_dp5_spec's workgroups: four tasks of one block each (they share the block's weight table in
+    // LDS); the workgroups that hold a head (several times the length of the other tasks) go first
+    std::vector<u32> wg;
+    for (int pass = 0; pass < 2; ++pass) {
+      for (size_t b = 0; b < nb; ++b) {
+        const u32 a0 = t->task_off[b], a1 = t->task_off[b + 1];
+        for (u32 k = pass == 0 ? a0 : a0 + D5_WG; k < (pass == 0 ? std::min(a0 + D5_WG, a1) : a1); k += D5_WG) {
+          for (u32 w = 0; w < D5_WG; ++w) wg.push_back(k + w < a1 ? k + w : SEG_NONE);
+        }
+      }
     }
-    HIPCHK(hipMemcpyAsync(t->d_task_order, order.data(), order.size() * sizeof(u32), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));   // `order` is a local
+    t->n_wg = static_cast<u32>(wg.size() / D5_WG);
+    HIPCHK(PoolAlloc(c, &t->d_wg_tasks, wg.size()));
+    HIPCHK(hipMemcpyAsync(t->d_wg_tasks, wg.data(), wg.size() * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));   // `wg` is a local
   }
   // trace segments (zmx_trace.h)
   t->seg_off.assign(nb + 1, 0);
@@ -803,67 +842,34 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   HIPCHK(hipMemcpyAsync(t->d_mincost, mincost, nb * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(t->d_slot, slot, nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(t->d_runinfo, runinfo.data(), 3 * nb * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  if (t->max_range_rows > c->rows_cap) {
-    if (c->d_rows) HIPCHK(hipFree(c->d_rows));
-    c->d_rows = nullptr;
-    c->rows_cap = 0;
-    // (+ 2048 doubles: k_dp5_spec touches up to 8 KB beyond the first row of a window)
-    hipError_t e = DevAlloc(&c->d_rows, t->max_range_rows + 2048);
-    if (e != hipSuccess && !c->pool_free.empty()) {   // out of memory: drop the table cache and retry
-      for (auto& f : c->pool_free) (void)hipFree(f.first);
-      c->pool_free.clear();
-      c->pool_free_bytes = 0;
-      e = DevAlloc(&c->d_rows, t->max_range_rows + 2048);
-    }
-    HIPCHK(e);
-    c->rows_cap = t->max_range_rows;
-  }
-  if (t->dsc_rows != c->d_rows || !t->d_dsc) {   // first run, or rows[] has moved
-    if (!t->d_dsc) {
-      HIPCHK(PoolAlloc(c, &t->d_dsc, t->total_b));
-      t->win_off.assign(nb + 1, 0);
-      for (size_t b = 0; b < nb; ++b) t->win_off[b + 1] = t->win_off[b] + (t->bsize[b] + 31) / 32;
-      HIPCHK(PoolAlloc(c, &t->d_winflag, t->win_off[nb]));
-      HIPCHK(PoolAlloc(c, &t->d_win_off, nb + 1));
-      HIPCHK(hipMemcpyAsync(t->d_win_off, t->win_off.data(), (nb + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
-    }
-    MkDescParams mp;
-    mp.win_off = t->d_win_off;
-    mp.winflag = t->d_winflag;
-    mp.blocks = t->d_blocks;
-    mp.dph = t->d_dph;
-    mp.row_base = t->d_row_base;
-    mp.rows = c->d_rows;
-    mp.dsc = t->d_dsc;
-    u32 max_b = 1;
-    for (size_t b = 0; b < nb; ++b) max_b = std::max(max_b, t->bsize[b]);
-    hipLaunchKernelGGL(k_mkdesc, dim3((max_b + 255) / 256, static_cast<unsigned>(nb)), dim3(256), 0, c->stream, mp);
-    HIPCHK(hipGetLastError());
-    t->dsc_rows = c->d_rows;
-  }
   static const bool want_prof = std::getenv("ZOPFLI_AMD_PROF") != nullptr;
   if (want_prof && !t->d_prof) HIPCHK(PoolAlloc(c, &t->d_prof, nb * ZMX_PROF_N));
   if (t->d_prof) HIPCHK(hipMemsetAsync(t->d_prof, 0, nb * ZMX_PROF_N * sizeof(u64), c->stream));
-  EdgeParams ep;
-  ep.blocks = t->d_blocks;
-  ep.tile_off = t->d_tile_off;
-  ep.nb_total = static_cast<u32>(nb);
-  ep.recs = t->d_recs;
-  ep.pool = t->d_pool;
-  ep.dph = t->d_dph;
-  ep.cost = t->d_cost;
-  ep.rows = c->d_rows;
-  ep.row_base = t->d_row_base;
-  ep.mincost = t->d_mincost;
-  ep.badpos = t->d_badpos;
+  WtabParams wp;
+  wp.cost = t->d_cost;
+  wp.mincost = t->d_mincost;
+  wp.wtab = t->d_wtab;
+  wp.badcodes = t->d_badcodes;
+  BadScanParams bp;
+  bp.blocks = t->d_blocks;
+  bp.tile_off = t->d_tile_off;
+  bp.nb_total = static_cast<u32>(nb);
+  bp.dph = t->d_dph;
+  bp.codes = t->d_codes;
+  bp.code_base = t->d_code_base;
+  bp.badcodes = t->d_badcodes;
+  bp.badpos = t->d_badpos;
   Dp4Params cp;
   cp.blocks = t->d_blocks;
+  cp.block0 = 0;
+  cp.task0 = 0;
   cp.dph = t->d_dph;
   cp.cost = t->d_cost;
   cp.mincost = t->d_mincost;
-  cp.rows = c->d_rows;
-  cp.row_base = t->d_row_base;
+  cp.codes = t->d_codes;
+  cp.code_base = t->d_code_base;
   cp.block_edges = t->d_block_edges;
+  cp.wtab = t->d_wtab;
   cp.la = t->d_la;
   cp.prof = t->d_prof;
   cp.badpos = t->d_badpos;
@@ -880,7 +886,7 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   cp.stats = t->d_segstats;
   static const float level_scale = [] { const char* e = std::getenv("ZOPFLI_AMD_SEG_SCALE"); return e ? static_cast<float>(std::atof(e)) : 1.0f; }();
   cp.level_scale = level_scale;
-  cp.order = t->d_task_order;
+  cp.wg_tasks = t->d_wg_tasks;
   static const int seg_debug = [] { const char* e = std::getenv("ZOPFLI_AMD_SEG_DEBUG"); return e ? std::atoi(e) : 0; }();
   cp.debug = seg_debug;
   cp.dsc = t->d_dsc;
@@ -902,28 +908,29 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   tp.flags = t->d_flags;
   tp.extab = t->d_extab;
   tp.seginfo = t->d_seginfo;
+  tp.block0 = 0;
+  tp.seg0 = 0;
   double ksec[3] = {0, 0, 0};
   const dim3 dpdim(64 * (D3_NB + 2));
-  for (const auto& r : t->ranges) {
-    const unsigned nblk = r.second - r.first;
-    const unsigned tiles = t->tile_off[r.second] - t->tile_off[r.first];
-    ep.tile0 = t->tile_off[r.first];
-    cp.block0 = r.first;
-    cp.task0 = t->task_off[r.first];
-    const unsigned ntask = t->task_off[r.second] - t->task_off[r.first];
-    tp.block0 = r.first;
+  {
+    const unsigned nblk = static_cast<unsigned>(nb);
+    const unsigned tiles = t->tile_off[nb];
+    const unsigned ntask = t->task_off[nb];
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    if (tiles) hipLaunchKernelGGL(k_edges, dim3(tiles), dim3(256), 0, c->stream, ep);
+    // the run's weights per block, and (rarely) the positions that own an edge below mincost
+    hipLaunchKernelGGL(k_wtab, dim3(nblk), dim3(256), 0, c->stream, wp);
+    if (tiles) hipLaunchKernelGGL(k_badscan, dim3(tiles), dim3(256), 0, c->stream, bp);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
-    // the chain: every task speculatively on all CUs, then the per-block walk that accepts or re-runs
+    // the chain: every task speculatively on all CUs (four tasks of a block per workgroup, the workgroups
+    // with a head first; registers for 4 or 6 waves per SIMD: ZOPFLI_AMD_D5W), then the per-block walk
+    // that accepts or re-runs
     {
-      // every task one wave, the heads (exact, several times as long as the others, and all there is of
-      // a small block) first in the launch order (registers for 4 or 6 waves per SIMD: ZOPFLI_AMD_D5W)
       static const int d5w = [] { const char* e = std::getenv("ZOPFLI_AMD_D5W"); return e ? std::atoi(e) : 4; }();
-      if (cp.prof) hipLaunchKernelGGL((k_dp5_spec<true, 4>), dim3(ntask), dim3(64), 0, c->stream, cp);
-      else if (d5w == 6) hipLaunchKernelGGL((k_dp5_spec<false, 6>), dim3(ntask), dim3(64), 0, c->stream, cp);
-      else hipLaunchKernelGGL((k_dp5_spec<false, 4>), dim3(ntask), dim3(64), 0, c->stream, cp);
+      const dim3 g(t->n_wg), bdim(64 * D5_WG);
+      if (cp.prof) hipLaunchKernelGGL((k_dp5_spec<true, 4>), g, bdim, 0, c->stream, cp);
+      else if (d5w == 6) hipLaunchKernelGGL((k_dp5_spec<false, 6>), g, bdim, 0, c->stream, cp);
+      else hipLaunchKernelGGL((k_dp5_spec<false, 4>), g, bdim, 0, c->stream, cp);
     }
     if (ntask > nblk) {
       hipLaunchKernelGGL(k_dpcheck, dim3(ntask), dim3(64), 0, c->stream, cp);
@@ -932,8 +939,7 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[2], c->stream));
-    tp.seg0 = t->seg_off[r.first];
-    const unsigned nseg = t->seg_off[r.second] - t->seg_off[r.first];
+    const unsigned nseg = t->seg_off[nb];
     if (nseg) hipLaunchKernelGGL(k_trace_exits, dim3(nseg), dim3(TS_THREADS), 0, c->stream, tp);
     hipLaunchKernelGGL(k_trace_link, dim3(nblk), dim3(64), 0, c->stream, tp);
     if (nseg) hipLaunchKernelGGL(k_trace_emit, dim3(nseg), dim3(64), 0, c->stream, tp);

@@ -89,13 +89,6 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// rows[] holds every DP edge cost with the bits 0x7fe0 of its top half flipped: the all-zero word
-// that a buffer load returns for a lane outside its row (k_dp5_spec fetches a row with the row as
-// the buffer) then decodes to 2^1023, an edge nobody takes, and a real cost (>= 0, < 2^1023) never
-// encodes to zero.
-#define ZMX_ROW_KEY 0x7fe0000000000000ll
-__device__ __forceinline__ double row_code(double w) { return __longlong_as_double(__double_as_longlong(w) ^ ZMX_ROW_KEY); }
-
 // ----------------------------------------------------------------------------
 // K1a  same[]: run length ahead, bounded by the block end, capped at 65535
 // ----------------------------------------------------------------------------
@@ -345,9 +338,9 @@ __device__ __forceinline__ uint2 greedy_window(const u32* rbase, u32 wb, u32 lan
 //         kend = min(leng, inend - i), squeeze.c:286); dph[j] = {roff, kend |
 //         shortcut flag << 16} with roff the exclusive prefix sum of the row
 //         lengths (k = 2 is a dead slot so that row[k-1] addresses edge k).
-//     k_edges   (every run, all CUs)    cost(k, sublen[k]) of every edge
-//         (squeeze.c:146-157; depends on the run's cost model, not on the DP
-//         state), one lane per edge, written as doubles to rows[] in HBM.
+//     k_codes   (once per table build)  which of the run's 1127 weights every edge takes
+//         (squeeze.c:146-157 depends on the cost model only through the symbols), one lane per
+//         edge, 16 bits each; k_wtab (every run) the 1127 weights per block.
 //     zmx_dp4.h  (every run)  the chain through the float-rounded absolute costs, cut into
 //         verified tasks (k_dp4_spec / k_dpcheck / k_dp4_fix).
 //     zmx_trace.h  TraceBackwards + FollowPath + histogram, segmented (k_trace_exits /
@@ -403,29 +396,37 @@ __global__ __launch_bounds__(1024) void k_rowscan(RowScanParams P) {
   if (tid == 0) P.block_edges[blockIdx.x] = carry;
 }
 
-// ------------------------------------------------------------------ k_edges
+// ------------------------------------------------------------------ k_codes
+// The DP edges of a block as 16-bit WEIGHT CODES, written once per table build: the cost of an edge
+// (squeeze.c:146-157) depends on the run's cost model only through the symbols it is coded with, so
+// what is stored per edge is which of the 1127 weights of the run it takes:
+//     0                                      no edge (the dead slot k = 2 of a row)
+//     1 + byte                               literal (squeeze.c:278)
+//     257 + 30 (lsym - 257) + dsym           match of a length with symbol lsym at a distance with symbol dsym
+// stored times 8, i.e. as the byte offset of the weight in the run's table of doubles (k_wtab).  Two
+// bytes per edge instead of a double per edge per run: the squeeze runs read a quarter of the bytes,
+// write none, and the table build pays once.  A lane outside its row reads code 0 (the chain
+// kernels fetch a row as a buffer of its own: the range check returns zero), whose weight is +inf.
 #define EG_CAP 2048u   // edges expanded per wave at a time
+#define ZMX_NUM_W 1127u                 // weights of a run: 0 = +inf, 256 literals, 29 x 30 matches
+#define ZMX_WTAB 1152u                  // doubles per block in wtab[] (padded)
 
-struct EdgeParams {
+__device__ __forceinline__ u32 weight_code(u32 k, u32 dist) {
+  return (257u + 30u * (u32)(dev_length_symbol(k) - 257) + (u32)dev_dist_symbol(dist)) * 8u;
+}
+
+struct CodeParams {
   const BlockDesc* blocks;
   const u32* tile_off;     // [nb_total + 1] cumulative 2048-position tiles
   u32 nb_total;
-  u32 tile0;               // first tile of this launch
   const u32* recs;
   const u32* pool;
   const uint2* dph;
-  const double* cost;      // [nb_total][320]
-  double* rows;
-  const u64* row_base;     // [nb_total] first row slot of each block (in doubles)
-  const double* mincost;   // [nb_total]
-  u32* badpos;             // bit per position (pos_off + p): a match edge of it costs less than mincost (zeroed per run)
+  u16* codes;
+  const u64* code_base;    // [nb_total] first slot of each block in codes[]
 };
 
-__global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
-  __shared__ double s_ll[288];
-  __shared__ double s_d[32];
-  __shared__ double s_kll[260];              // ll[length symbol of k]
-  __shared__ u8 s_klb[260];                  // length extra bits of k
+__global__ __launch_bounds__(256) void k_codes(CodeParams P) {
   __shared__ u8 s_mark[4][EG_CAP];           // row starts, for the edge -> position map
   __shared__ u32 s_hoff[4][64];              // row offset in the sub-chunk | literal << 16 | overflow << 24
   __shared__ u32 s_hthr[4][64][2];           // 8 change-point thresholds (len - 3), ascending, 0xff padded
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
   __shared__ u32 s_hpool[4][64][2];          // overflow records: pool offset, count
 
   const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const u32 tile = P.tile0 + blockIdx.x;
+  const u32 tile = blockIdx.x;
   u32 lo = 0, hi = P.nb_total;
   while (hi - lo > 1) {
     const u32 mid = (lo + hi) >> 1;
@@ -445,21 +446,7 @@ __global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
   const u32 tp0 = (tile - P.tile_off[b]) * MT;
   const u32* rbase = P.recs + bd.pos_off * 8;
   const uint2* dbase = P.dph + bd.pos_off;
-  double* rows = P.rows + P.row_base[b];
-  // squeeze.c:293's mincost test is a no-op unless an edge costs less than mincost (possible only
-  // through rounding in the cost model): such positions are reported, the chain kernel tests them literally
-  const double mincost = P.mincost[b];
-
-  for (u32 i = tid; i < 288; i += 256) s_ll[i] = P.cost[(u64)b * 320 + i];
-  if (tid < 32) s_d[tid] = P.cost[(u64)b * 320 + 288 + tid];
-  __syncthreads();
-  for (u32 k = tid; k < 260; k += 256) {
-    const bool ok = k >= 3 && k <= ZMX_MAX_MATCH;
-    s_kll[k] = ok ? s_ll[dev_length_symbol(k)] : 0.0;
-    s_klb[k] = ok ? (u8)dev_length_extra_bits(k) : (u8)0;
-  }
-  __syncthreads();
-  const double kInf = __longlong_as_double(0x7ff0000000000000ll);
+  u16* codes = P.codes + P.code_base[b];
   u8* mark = s_mark[wid];
 
   for (u32 g = wid; g < MT / 64; g += 4) {
@@ -532,11 +519,11 @@ __global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
           const u32 p = own - 1;
           const u32 h = s_hoff[wid][p];
           const u32 k = e - ((h & 0xffffu) - rel_q) + 1;
-          double w;
+          u32 code;
           if (k == 1) {
-            w = s_ll[(h >> 16) & 255u];            // literal edge, squeeze.c:278
+            code = (1u + ((h >> 16) & 255u)) * 8u;   // literal edge, squeeze.c:278
           } else if (k == 2 || (h >> 24)) {
-            w = kInf;                              // dead slot (overflow rows are filled below)
+            code = 0;                                // dead slot (overflow rows are filled below)
           } else {
             const u32 x = k - 3;
             // first change point with len >= k: thresholds ascending, binary search over 8 bytes
@@ -545,15 +532,9 @@ __global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
             u32 half = idx ? thi : tlo;
             if (((half >> 8) & 255u) < x) { idx += 2; half >>= 16; }
             if ((half & 255u) < x) idx += 1;
-            const u32 dist = s_hdist[wid][p][idx];
-            // squeeze.c:155: (lbits + dbits) as int, then + ll, then + d
-            w = ((double)((int)s_klb[k] + dev_dist_extra_bits(dist)) + s_kll[k]) + s_d[dev_dist_symbol(dist)];
-            if (w < mincost) {
-              const u64 gp = bd.pos_off + base + p;
-              atomicOr(&P.badpos[gp >> 5], 1u << (gp & 31));
-            }
+            code = weight_code(k, s_hdist[wid][p][idx]);
           }
-          rows[(u64)off_q + e] = row_code(w);
+          codes[(u64)off_q + e] = (u16)code;
         }
       }
       // rows of records with more than 8 change points (pool): whole wave per position
@@ -570,12 +551,7 @@ __global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
             if ((P.pool[poff + mid] & 0xffffu) < k) plo = mid + 1; else phi = mid;
           }
           const u32 dist = plo < pn ? P.pool[poff + plo] >> 16 : 1u;
-          const double w = ((double)((int)s_klb[k] + dev_dist_extra_bits(dist)) + s_kll[k]) + s_d[dev_dist_symbol(dist)];
-          rows[(u64)roff_p + k - 1] = row_code(w);
-          if (w < mincost) {
-            const u64 gp = bd.pos_off + base + p;
-            atomicOr(&P.badpos[gp >> 5], 1u << (gp & 31));
-          }
+          codes[(u64)roff_p + k - 1] = (u16)weight_code(k, dist);
         }
       }
       q += n;
@@ -583,14 +559,95 @@ __global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
   }
 }
 
+// ------------------------------------------------------------------ k_wtab
+// The run's weights per block (GetCostStat, squeeze.c:146-157: (lbits + dbits) as int, then + ll,
+// then + d) and which match weights lie below mincost: squeeze.c:293's mincost test is a no-op for
+// every other edge (zmx_dp4.h), the positions that own an edge below it (possible only through
+// rounding in the cost model) are marked by k_badscan and take the chain kernels' literal path.
+struct WtabParams {
+  const double* cost;      // [nb][320]
+  const double* mincost;   // [nb]
+  double* wtab;            // [nb][ZMX_WTAB]
+  u32* badcodes;           // [nb][40]: word 0 = number of weights below mincost, words 4.. = their bitmap
+};
+
+__global__ __launch_bounds__(256) void k_wtab(WtabParams P) {
+  __shared__ u32 s_bad[40];
+  const u32 b = blockIdx.x, tid = threadIdx.x;
+  if (tid < 40) s_bad[tid] = 0;
+  __syncthreads();
+  const double* ll = P.cost + (u64)b * 320;
+  const double* d = ll + 288;
+  const double mincost = P.mincost[b];
+  for (u32 c = tid; c < ZMX_WTAB; c += 256) {
+    double w = __longlong_as_double(0x7ff0000000000000ll);    // code 0 and the padding: no edge
+    if (c >= 1 && c <= 256) {
+      w = ll[c - 1];
+    } else if (c >= 257 && c < ZMX_NUM_W) {
+      const u32 ls = 257u + (c - 257u) / 30u, ds = (c - 257u) % 30u;
+      const int lb = ls < 265 || ls == 285 ? 0 : (int)(ls - 261) / 4;
+      const int db = ds < 4 ? 0 : (int)ds / 2 - 1;
+      w = ((double)(lb + db) + ll[ls]) + d[ds];
+      if (w < mincost) {
+        atomicAdd(&s_bad[0], 1u);
+        atomicOr(&s_bad[4 + (c >> 5)], 1u << (c & 31));
+      }
+    }
+    P.wtab[(u64)b * ZMX_WTAB + c] = w;
+  }
+  __syncthreads();
+  if (tid < 40) P.badcodes[(u64)b * 40 + tid] = s_bad[tid];
+}
+
+// ---------------------------------------------------------------- k_badscan
+// Only for blocks whose run has a weight below mincost: mark the positions that own such an edge.
+struct BadScanParams {
+  const BlockDesc* blocks;
+  const u32* tile_off;
+  u32 nb_total;
+  const uint2* dph;
+  const u16* codes;
+  const u64* code_base;
+  const u32* badcodes;
+  u32* badpos;             // bit per position (pos_off + p), zeroed per run
+};
+
+__global__ __launch_bounds__(256) void k_badscan(BadScanParams P) {
+  const u32 tile = blockIdx.x;
+  u32 lo = 0, hi = P.nb_total;
+  while (hi - lo > 1) {
+    const u32 mid = (lo + hi) >> 1;
+    if (P.tile_off[mid] <= tile) lo = mid; else hi = mid;
+  }
+  const u32 b = lo;
+  const u32* bad = P.badcodes + (u64)b * 40;
+  if (bad[0] == 0) return;
+  const BlockDesc bd = P.blocks[b];
+  const u32 B = (u32)(bd.inend - bd.instart);
+  const u32 tp0 = (tile - P.tile_off[b]) * MT;
+  const u16* codes = P.codes + P.code_base[b];
+  for (u32 p = tp0 + threadIdx.x; p < tp0 + MT && p < B; p += 256) {
+    const uint2 dh = P.dph[bd.pos_off + p];
+    const u32 kend = dh.y & 0xffffu;
+    bool any = false;
+    for (u32 k = 3; k <= kend; ++k) {
+      const u32 c = (u32)codes[(u64)dh.x + k - 1] >> 3;
+      any |= ((bad[4 + (c >> 5)] >> (c & 31)) & 1u) != 0;
+    }
+    if (any) {
+      const u64 gp = bd.pos_off + p;
+      atomicOr(&P.badpos[gp >> 5], 1u << (gp & 31));
+    }
+  }
+}
+
 // ------------------------------------------- shared by the chain kernels (zmx_dp4.h)
 #define ZMX_PROF_N 32u                // u64 profiling counters per block (ZOPFLI_AMD_PROF)
-#define DP_RING 4096u                 // doubles in the LDS ring (32 KB)
-#define DP_PIECE 128u                 // doubles per LDS-DMA instruction (64 lanes x 16 B)
-#define DP_SPAN (DP_RING / 2 - 256u)  // row span of one sub-chunk: the next one is always resident too
+#define DP_RING 8192u                 // weight codes in the LDS ring (16 KB)
+#define DP_PIECE 512u                 // codes per LDS-DMA instruction (64 lanes x 16 B)
 #define DP_XN 704u                    // long-run shortcut staging: 384 cells
 #define DP_FRONT 64u                  // slack before the ring: masked-off lanes address up to 64 slots back
-#define DP_MIRROR 384u                // the first 3 pieces are mirrored behind the ring: a row never wraps
+#define DP_MIRROR 512u                // the first piece is mirrored behind the ring: a row (<= 258 slots) never wraps
 
 // One position of the chain on cell register `CS` (round S): the edge values `WV`
 // were preloaded, invalid lanes hold +inf.  MCL = mincost (or -inf on the literal
@@ -609,7 +666,7 @@ __global__ __launch_bounds__(256) void k_edges(EdgeParams P) {
 // One 1 KiB piece HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: lane i moves 16 B to
 // M0 + 16 i).  Issued as asm so that the compiler does not order every later LDS read
 // behind it with vmcnt(0); the consumer side waits explicitly before a barrier.
-__device__ __forceinline__ void dp_dma_piece(const double* lane_src, u32 lds_byte_off) {
+__device__ __forceinline__ void dp_dma_piece(const u16* lane_src, u32 lds_byte_off) {
   lds_byte_off = (u32)__builtin_amdgcn_readfirstlane((int)lds_byte_off);   // wave-uniform by construction
   u32 keep;
   asm volatile(

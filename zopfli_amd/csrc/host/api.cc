@@ -104,12 +104,19 @@ std::vector<zamd::Part> MasterBlocks(size_t insize, bool final) {
 
 int RunParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const std::vector<zamd::Part>& parts,
              std::vector<zamd::Chunk>* chunks) {
-  const size_t step = PartsPerBatch();
-  for (size_t a = 0; a < parts.size(); a += step) {
+  size_t step = PartsPerBatch();
+  for (size_t a = 0; a < parts.size();) {
     const size_t b = a + step < parts.size() ? a + step : parts.size();
-    std::vector<zamd::Part> group(parts.begin() + a, parts.begin() + b);
-    const int rc = zamd::DeflateParts(ctx, options, btype, group, chunks);
+    std::vector<zamd::Part> group(parts.begin() + static_cast<long>(a), parts.begin() + static_cast<long>(b));
+    std::vector<zamd::Chunk> got;
+    const int rc = zamd::DeflateParts(ctx, options, btype, group, &got);
+    if (rc == -2 && b - a > 1) {   // the DP edges of the batch do not fit the device layer's budget: smaller batches
+      step = (b - a + 1) / 2;
+      continue;
+    }
     if (rc) return rc;
+    for (auto& c : got) chunks->push_back(std::move(c));
+    a = b;
   }
   return 0;
 }

@@ -1,8 +1,10 @@
 #include "block_split.h"
 
 #include <algorithm>
+#include <vector>
 
 #include "block_cost.h"
+#include "thread_pool.h"
 
 namespace zamd {
 
@@ -19,16 +21,23 @@ struct SplitCost {
 };
 
 // Minimum of f over [start, end): exhaustive below 1024 candidates, otherwise
-// a 9-point recursive refinement that stops as soon as a round does not improve.
+// a 9-point recursive refinement that stops as soon as a round does not improve
+// (blocksplitter.c:43-96).  The candidates of a round are independent block-size evaluations: they
+// run on the worker pool when this call is not itself inside a parallel loop — a request of one
+// master block (every zopflipng IDAT below 1 MB) has no other parallelism to offer.
 size_t FindMinimum(const SplitCost& f, size_t start, size_t end, double* smallest) {
   if (end - start < 1024) {
+    const size_t n = end - start;
+    std::vector<double> v(n);
+    ParallelFor((n + 15) / 16, [&](size_t c) {
+      for (size_t i = c * 16; i < n && i < c * 16 + 16; ++i) v[i] = f(start + i);
+    });
     double best = kLarge;
     size_t arg = start;
-    for (size_t i = start; i < end; ++i) {
-      const double v = f(i);
-      if (v < best) {
-        best = v;
-        arg = i;
+    for (size_t i = 0; i < n; ++i) {
+      if (v[i] < best) {      // strict: the first minimum, as the reference's loop
+        best = v[i];
+        arg = start + i;
       }
     }
     *smallest = best;
@@ -41,10 +50,8 @@ size_t FindMinimum(const SplitCost& f, size_t start, size_t end, double* smalles
   size_t pos = start;
   while (end - start > kProbes) {
     const size_t step = (end - start) / (kProbes + 1);
-    for (int i = 0; i < kProbes; ++i) {
-      probe[i] = start + (i + 1) * step;
-      value[i] = f(probe[i]);
-    }
+    for (int i = 0; i < kProbes; ++i) probe[i] = start + (i + 1) * step;
+    ParallelFor(kProbes, [&](size_t i) { value[i] = f(probe[i]); });
     int arg = 0;
     for (int i = 1; i < kProbes; ++i) {
       if (value[i] < value[arg]) arg = i;

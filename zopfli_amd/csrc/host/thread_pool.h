@@ -17,8 +17,31 @@
 #include <vector>
 
 #include <pthread.h>
+#include <sched.h>
+
+#include <cstdio>
+#include <cstring>
 
 namespace zamd {
+
+// The processors this process may run on: the online count cut down by the scheduling affinity.  A
+// cgroup CPU quota is deliberately NOT applied: the host phases are bursts of a few milliseconds, and
+// a quota of n CPUs' worth of time per 100 ms period still lets such a burst spread over every core
+// (measured on the 256-thread box with a 16-CPU quota: the split and encode phases take 2.5x longer
+// on 16 threads than on 64).
+inline unsigned UsableCpus() {
+  static const unsigned n = [] {
+    unsigned hc = std::thread::hardware_concurrency();
+    if (hc == 0) hc = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+      const unsigned a = static_cast<unsigned>(CPU_COUNT(&set));
+      if (a > 0 && a < hc) hc = a;
+    }
+    return hc;
+  }();
+  return n;
+}
 
 inline unsigned HostThreads() {
   static const unsigned n = [] {
@@ -26,9 +49,9 @@ inline unsigned HostThreads() {
       const int v = std::atoi(e);
       if (v > 0) return static_cast<unsigned>(v);
     }
-    const unsigned hc = std::thread::hardware_concurrency();
+    const unsigned hc = UsableCpus();
     const unsigned cap = 64;  // beyond this the wake-up cost outweighs the per-block work
-    return hc ? (hc < cap ? hc : cap) : 1u;
+    return hc < cap ? hc : cap;
   }();
   return n;
 }
@@ -39,9 +62,9 @@ inline unsigned HostThreads() {
 inline unsigned WideThreads() {
   static const unsigned n = [] {
     if (std::getenv("ZOPFLI_AMD_THREADS")) return HostThreads();   // an explicit budget covers both pools
-    const unsigned hc = std::thread::hardware_concurrency();
+    const unsigned hc = UsableCpus();
     const unsigned cap = 128;
-    const unsigned w = hc ? (hc < cap ? hc : cap) : 1u;
+    const unsigned w = hc < cap ? hc : cap;
     return w > HostThreads() ? w : HostThreads();
   }();
   return n;

@@ -225,7 +225,6 @@ def test_squeeze_runs(gpu_ctx, case):
 # (environment, what the task statistics must show)
 CHAIN_ENVS = [
     ({}, lambda st: st["tasks"] > 100 and st["accepted"] > 0),
-    ({"ZOPFLI_AMD_D5W": "6"}, lambda st: st["tasks"] > 100 and st["accepted"] > 0),         # the 6-waves-per-SIMD build of k_dp5_spec
     ({"ZOPFLI_AMD_SEG_L": "0"}, lambda st: st["tasks"] == 0),                                   # the serial chain
     ({"ZOPFLI_AMD_SEG_WARM": "64", "ZOPFLI_AMD_SEG_HEAD": "0"}, lambda st: st["rerun_state"] > 0),                           # warm-up too short: states differ
     ({"ZOPFLI_AMD_SEG_SCALE": "1.9"}, lambda st: st["rerun_level"] + st["rerun_values"] > 0),                         # wrong binade guessed

@@ -339,6 +339,9 @@ struct Dp4Params {
   const u32* win_off;      // [nb_total] first window of each block in winflag[]
   int debug;               // ZOPFLI_AMD_SEG_DEBUG: k_dp4_fix prints its decisions
   u16* over;               // [tasks][SEG_OVER] lengths of the cells a speculative task computed beyond its pend
+  u32* redo_count;         // k_dpscan: number of tasks to run a second time ...
+  u32* redo_wg;            // ... and their workgroups for k_dp5_spec ([count][4]: the task, then SEG_NONE)
+  int redo_pass;           // k_dp5_spec: 1 = this launch runs P.redo_wg (workgroups beyond *redo_count have nothing to do)
 };
 
 // What one pass over a stretch of the chain does.  k_dp5_spec's jobs: the head of a block (exact: the
@@ -884,6 +887,50 @@ __global__ __launch_bounds__(64) void k_dpcheck(Dp4Params P) {
   if (threadIdx.x == 0) P.chk[t] = r;
 }
 
+// The acceptance test of a task whose entry state matched its predecessor's exit state up to the
+// shift delta: 0 = accept, 1 = the guessed or the shifted values leave the binade, 2 = a weight of
+// the run can tie in that binade's float rounding.
+__device__ __forceinline__ u32 d4_accept(float vmin, double vmax, double delta, double wmax, u32 tiemask) {
+  if (delta == 0.0) return 0;
+  const int e = (int)((__float_as_uint(vmin) >> 23) & 255u) - 127;
+  const double lo = ldexp(1.0, e), hi = ldexp(1.0, e + 1);
+  const bool pure = vmin >= 16.0f && vmax + wmax < hi && (double)vmin + delta >= lo && vmax + wmax + delta < hi;
+  if (!pure) return 1;
+  return ((tiemask >> (e & 31)) & 1u) != 0 ? 2u : 0u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_dpscan: between the speculative pass and the fix pass.  A task that only missed because its
+// guessed level was off (wrong binade, or a warm-up that crossed one) is worth a second speculative
+// run: the chain of shifts gives its true level to within an ulp or two, and a run started from THAT
+// level usually reproduces the true entry state exactly (shift 0: accepted whatever binades the task
+// crosses afterwards).  One wave per block walks the checks, assuming every task will be accepted in
+// the end, and lists the tasks to run again with their new levels; k_dp5_spec runs the list, k_dpcheck
+// checks everything again, and only what still fails is left to the serial pass.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_dpscan(Dp4Params P) {
+  const u32 b = P.block0 + blockIdx.x;
+  const u32 t0 = P.task_off[b], t1 = P.task_off[b + 1];
+  if (threadIdx.x != 0) return;
+  const double wmax = (double)P.wmax[b] + 1.0;
+  const u32 tiemask = P.tiemask[b];
+  double delta_prev = 0.0;
+  for (u32 t = t0 + 1; t < t1; ++t) {
+    const SegCheck ck = P.chk[t];
+    const double delta = delta_prev + ck.d;
+    bool ok = ck.match == 1 && d4_accept(ck.vmin, (double)P.exit[t].vmax, delta, wmax, tiemask) == 0;
+    if (!ok && ck.match != 0) {          // same structure, wrong level: again from the level the chain implies
+      const u32 slot = atomicAdd(P.redo_count, 1u);
+      u32* wg = P.redo_wg + (u64)slot * 4;
+      wg[0] = t; wg[1] = SEG_NONE; wg[2] = SEG_NONE; wg[3] = SEG_NONE;
+      P.lvl[t] = (float)((double)P.lvl[t] + delta);
+    }
+    // (the exit snapshots at hand are those of the first run: whatever becomes of this task, its exit
+    //  there plus `delta` is the best estimate of the true state the next task starts from)
+    delta_prev = delta;
+  }
+}
+
 // A task of the speculative pass stops at its first window base >= pend and has the lengths of the
 // cells from pend on in its side buffer, not in length_array: its successor may have started writing
 // at a SMALLER base than the one it stopped at (walks out of step after a long-run shortcut), and two
@@ -920,6 +967,8 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
   double delta_prev = 0.0;     // what has to be added to exit[t - 1] to get the true values
   bool rerun_prev = false;     // exit[t - 1] was rewritten by this workgroup: P.chk[t] is stale
   u32 n_ok = 0, n_state = 0, n_level = 0, n_tie = 0, n_pos = 0, n_values = 0;
+  const u64 cyc0 = __builtin_readcyclecounter();
+  u64 cyc_run = 0;
   for (u32 t = t0 + 1; t < t1; ++t) {
     SegCheck ck;
     if (rerun_prev) ck = d4_check(&P.exit[t - 1], &P.entry[t], lane);   // every wave computes the same
@@ -929,17 +978,11 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
     if (lead) P.lvl[t] = (float)((double)P.lvl[t] + delta);
     bool ok = ck.match == 1;
     u32 why = 0;
-    if (ok && delta != 0.0) {
-      const float vmin = ck.vmin;
-      const double vmax = (double)P.exit[t].vmax;
-      const int e = (int)((__float_as_uint(vmin) >> 23) & 255u) - 127;
-      const double lo = ldexp(1.0, e), hi = ldexp(1.0, e + 1);
-      const bool pure = vmin >= 16.0f && vmax + wmax < hi && (double)vmin + delta >= lo && vmax + wmax + delta < hi;
-      const bool tie = ((tiemask >> (e & 31)) & 1u) != 0;
-      if (!pure) { ok = false; why = 1; }
-      else if (tie) { ok = false; why = 2; }
+    if (ok) {
+      why = d4_accept(ck.vmin, (double)P.exit[t].vmax, delta, wmax, tiemask);
+      ok = why == 0;
     }
-    if (P.debug && lead) {
+    if (P.debug == 1 && lead) {
       printf("fix b %u t %u pout %u: match %u d %.6f delta %.6f vmin %.4f vmax %.4f why %u ok %d entry base %u exit-1 base %u\n", b,
              t - t0, P.tasks[t].pout, ck.match, ck.d, delta, (double)ck.vmin, (double)P.exit[t].vmax, why, ok ? 1 : 0,
              P.entry[t].base, P.exit[t - 1].base);
@@ -970,9 +1013,16 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
     J.over = nullptr;
     n_pos += (T.pend < B ? T.pend : B) - (J.start < B ? J.start : B);
     __syncthreads();     // every wave has read the old exit[t] / exit[t - 1]
+    const u64 cr0 = __builtin_readcyclecounter();
     d4_run_job<PROF>(P, J, b, bd, s_ring, s_wtab, s_t1, s_t2, s_tab, s_desc, s_tabc, s_xc, s_xl, s_lout);
+    cyc_run += __builtin_readcyclecounter() - cr0;
     delta_prev = 0.0;
     rerun_prev = true;
+  }
+  if (P.debug >= 2 && lead) {
+    printf("fix b %u: %u tasks ok %u state %u values %u level %u tie %u, %u positions re-run, %llu cycles in all, %llu in re-runs\n", b,
+           t1 - t0, n_ok, n_state, n_values, n_level, n_tie, n_pos, (unsigned long long)(__builtin_readcyclecounter() - cyc0),
+           (unsigned long long)cyc_run);
   }
   if (lead && P.stats) {
     atomicAdd(&P.stats[0], t1 - t0);

@@ -47,7 +47,8 @@ struct MkDescParams {
   d5_u32x4* dsc;
   const u32* win_off;   // [nb] first entry of each block in winflag[]
   u32* winflag;         // per 32-position window of a block (aligned to the block start): 1 = 32 positions, none flagged
-                        // for the long-run shortcut, none with an edge beyond cell register 0 of a window at that place
+                        // for the long-run shortcut, none with an edge beyond cell register 0 of a window at that
+                        // place; 2 = 32 positions, none flagged, edges of any length; 0 = neither
 };
 
 __global__ __launch_bounds__(256) void k_mkdesc(MkDescParams P) {
@@ -57,10 +58,13 @@ __global__ __launch_bounds__(256) void k_mkdesc(MkDescParams P) {
   const u32 lane = threadIdx.x & 63;
   uint2 dhw = make_uint2(0, 0);
   if (p < B) dhw = P.dph[bd.pos_off + p];
-  // (whole waves take part in the ballot; a wave covers two windows)
-  const u64 notfast = __ballot(p >= B || (dhw.y >> 16) != 0 || (dhw.y & 0xffffu) + (lane & 31u) >= 64u);
+  // (whole waves take part in the ballots; a wave covers two windows)
+  const bool flagged = p >= B || (dhw.y >> 16) != 0;
+  const u64 not1 = __ballot(flagged || (dhw.y & 0xffffu) + (lane & 31u) >= 64u);    // an edge beyond cell register 0
+  const u64 not2 = __ballot(flagged);                                                // flagged for the shortcut, or short
   if ((lane & 31u) == 0 && p < B) {
-    P.winflag[P.win_off[blockIdx.y] + (p >> 5)] = ((u32)(notfast >> (lane & 32u)) == 0) ? 1u : 0u;
+    const u32 sh = lane & 32u;
+    P.winflag[P.win_off[blockIdx.y] + (p >> 5)] = (u32)(not1 >> sh) == 0 ? 1u : (u32)(not2 >> sh) == 0 ? 2u : 0u;
   }
   if (p >= B) return;
   const uint2 dh = dhw;
@@ -159,12 +163,13 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
   }
   // a window that can take the fast path: at a multiple of 32 from the block start, statically
   // clean (k_mkdesc) and without an edge below mincost in this run (k_edges' bitmap)
-  auto is_clean = [&](u32 wb) -> bool {
-    if ((wb & 31u) != 0 || wb + 32u > B) return false;
-    if (winflag[wb >> 5] == 0) return false;
+  auto win_kind = [&](u32 wb) -> u32 {     // 1 / 2: cell registers the window's edges reach; 0: generic
+    if ((wb & 31u) != 0 || wb + 32u > B) return 0u;
+    const u32 f = winflag[wb >> 5];
+    if (f == 0) return 0u;
     const u32 g = bit_off + wb;
     const u64 two = ((u64)badw[(g >> 5) + 1] << 32) | badw[g >> 5];
-    return (u32)(two >> (g & 31u)) == 0;
+    return (u32)(two >> (g & 31u)) == 0 ? f : 0u;
   };
   while (wbase < J.pend) {          // (J.pend = B + 1 on the last task: the window at B retires cell B)
     wbase = (u32)__builtin_amdgcn_readfirstlane((int)wbase);
@@ -178,12 +183,13 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
       vmax = 0.0f;
     }
     bool jumped = false;
-    const bool fastwin = is_clean(wbase);
-    if (fastwin) {
-      // ---- 32 positions, one cell register, no flags: the rows come straight into registers, then
-      //      the chain (the other waves of the SIMD run while this one waits for its rows: requesting the
-      //      next window's rows before this window's chain was measured slower — 188 registers, two
-      //      waves per SIMD instead of four)
+    const u32 kind = win_kind(wbase);
+    if (kind == 1) {
+      // ---- 32 positions, one cell register, no flags: the rows' weights come straight into registers,
+      //      then the chain.  The other waves of the SIMD run while this one waits for its rows.
+      //      Requesting the next window's codes half a window ahead of the chain was measured SLOWER,
+      //      twice: with the registers for three waves per SIMD (dp 97 vs 91 ms per 15 runs) and, spilling,
+      //      for four (119 ms); six waves per SIMD spill as well (the D5W = 6 build: 2.6x slower).
       double wv0[16], wv1[16];
       D5_ISSUE(wv0, wbase, 0)
       D5_ISSUE(wv1, wbase, 16)
@@ -192,6 +198,61 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
       D5_CHAIN(wv1, 16)
       l[0] = lt_ ? wbase + lt_ : l[0];
       reach = reach > 63 ? reach : 63;
+      noshort = false;
+      n_fast += 32;
+    } else if (kind == 2) {
+      // ---- the same with longer edges (matches of more than 32 bytes: markup, source code): a second
+      //      request per row for lanes 64 .. 127 of it and a second relaxation off the chain's critical
+      //      path (register 1 is never the source of a position of this window); the few rows that
+      //      reach further fetch the rest on demand.  No edge of the window lies below mincost
+      //      (win_kind), so squeeze.c:293's test is a no-op here as well.
+      u32 lt_ = 0, lt1_ = 0;
+#pragma unroll 1
+      for (int h = 0; h < 4; ++h) {          // (eight positions at a time, a real loop: the registers of four waves per SIMD)
+        const d5_cdscp dw_ = (d5_cdscp)(dsc + wbase + 8u * h);
+        double wa[8], wb[8];
+        u32 ca[8], cb[8];
+        u32 ke8[8];
+        u64 ra8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const d5_u32x4 d_ = dw_[u];
+          ke8[u] = d_.z >> 1;
+          ra8[u] = ((u64)d_.y << 32) | d_.x;
+          const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(
+              reinterpret_cast<void*>(ra8[u]), (short)0, (int)d_.z, (int)d_.w);
+          const int vo = (int)(lane2 - 2u * (u32)(8 * h + u + 1));
+          ca[u] = (u32)(u16)__builtin_amdgcn_raw_buffer_load_b16(rs_, vo, 0, 0);
+          cb[u] = (u32)(u16)__builtin_amdgcn_raw_buffer_load_b16(rs_, vo + 128, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { wa[u] = code_w(ca[u]); wb[u] = code_w(cb[u]); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const u32 p = (u32)(8 * h + u);
+          const double cj = (double)rdlane_f32(c[0], p);
+          D3_RELAX_K(c[0], lt_, wa[u], p + 1u)
+          D3_RELAX_K(c[1], lt1_, wb[u], p + 1u)
+          if (ke8[u] + p >= 128u) {            // the row reaches cell register 2 or beyond
+            const u16* row = reinterpret_cast<const u16*>(ra8[u]);
+            const u32 src1 = wbase + p + 1;
+            reach = reach > ke8[u] + p ? reach : ke8[u] + p;
+#pragma unroll
+            for (int s = 2; s < 6; ++s) {
+              const u32 k1 = lane + 64u * s - p - 1;
+              if (k1 < ke8[u]) {
+                const double nc = code_w(row[k1]) + cj;
+                const bool upd = nc < (double)c[s];
+                c[s] = upd ? (float)nc : c[s];
+                l[s] = upd ? src1 : l[s];
+              }
+            }
+          }
+        }
+      }
+      l[0] = lt_ ? wbase + lt_ : l[0];
+      l[1] = lt1_ ? wbase + lt1_ : l[1];
+      reach = reach > 127 ? reach : 127;
       noshort = false;
       n_fast += 32;
     } else {
@@ -315,7 +376,8 @@ __global__ __launch_bounds__(64 * D5_WG, WAVES) void k_dp5_spec(Dp4Params P) {
   __shared__ float s_xc[D5_WG][DP_XN];
   __shared__ u16 s_xl[D5_WG][DP_XN];
   const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const u32* wg = P.wg_tasks + (u64)(P.task0 + blockIdx.x) * D5_WG;
+  if (P.redo_pass && blockIdx.x >= *P.redo_count) return;
+  const u32* wg = (P.redo_pass ? P.redo_wg : P.wg_tasks) + (u64)(P.task0 + blockIdx.x) * D5_WG;
   const u32 t0 = wg[0];
   const u32 b0 = P.tasks[t0].block;
   for (u32 i = threadIdx.x; i < ZMX_WTAB; i += 64 * D5_WG) s_wtab[i] = P.wtab[(u64)b0 * ZMX_WTAB + i];
@@ -346,7 +408,7 @@ __global__ __launch_bounds__(64 * D5_WG, WAVES) void k_dp5_spec(Dp4Params P) {
     J.spec = true;
     J.la_lo = SEG_NONE;
     J.level = P.est_bits ? P.est_bits[T.block] * ((float)T.q / (float)B) : P.lvl[t];
-    J.level *= P.level_scale;
+    if (!P.redo_pass) J.level *= P.level_scale;
     if (!(J.level >= 16.0f)) J.level = 16.0f;
     if (P.est_bits && (threadIdx.x & 63) == 0) P.lvl[t] = J.level;
   }

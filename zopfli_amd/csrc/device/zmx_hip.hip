@@ -142,6 +142,7 @@ struct zmx_tables {
   SegSnap* d_exit = nullptr;
   SegCheck* d_chk = nullptr;
   u16* d_over = nullptr;      // [tasks][SEG_OVER]
+  u32* d_redo = nullptr;      // [1 + 3 pad + tasks * 4]: k_dpscan's list of tasks to run a second time
   float* d_runinfo = nullptr; // [3][nb]: wmax, tie mask (as bits), estimated block cost
   u32* d_segstats = nullptr;  // 8 words
   std::vector<u32> h_hist;    // the histograms of the last greedy parse / squeeze run (host copy)
@@ -338,6 +339,7 @@ void zmx_tables_free(zmx_ctx* c, zmx_tables* t) {
   PoolFree(c, t->d_exit);
   PoolFree(c, t->d_chk);
   PoolFree(c, t->d_over);
+  PoolFree(c, t->d_redo);
   PoolFree(c, t->d_runinfo);
   PoolFree(c, t->d_segstats);
   delete t;
@@ -668,6 +670,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     HIPCHK(PoolAlloc(c, &t->d_exit, nt));
     HIPCHK(PoolAlloc(c, &t->d_chk, nt));
     HIPCHK(PoolAlloc(c, &t->d_over, nt * SEG_OVER));
+    HIPCHK(PoolAlloc(c, &t->d_redo, 4 + nt * 4));
     HIPCHK(PoolAlloc(c, &t->d_runinfo, 3 * nb));
     HIPCHK(PoolAlloc(c, &t->d_segstats, 8));
     HIPCHK(hipMemcpyAsync(t->d_tasks, t->tasks.data(), nt * sizeof(SegTask), hipMemcpyHostToDevice, c->stream));
@@ -889,6 +892,9 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   cp.wg_tasks = t->d_wg_tasks;
   static const int seg_debug = [] { const char* e = std::getenv("ZOPFLI_AMD_SEG_DEBUG"); return e ? std::atoi(e) : 0; }();
   cp.debug = seg_debug;
+  cp.redo_count = t->d_redo;
+  cp.redo_wg = t->d_redo + 4;
+  cp.redo_pass = 0;
   cp.dsc = t->d_dsc;
   cp.winflag = t->d_winflag;
   cp.win_off = t->d_win_off;
@@ -923,17 +929,30 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
     // the chain: every task speculatively on all CUs (four tasks of a block per workgroup, the workgroups
-    // with a head first; registers for 4 or 6 waves per SIMD: ZOPFLI_AMD_D5W), then the per-block walk
-    // that accepts or re-runs
+    // with a head first), then the per-block walk that accepts or re-runs
     {
-      static const int d5w = [] { const char* e = std::getenv("ZOPFLI_AMD_D5W"); return e ? std::atoi(e) : 4; }();
       const dim3 g(t->n_wg), bdim(64 * D5_WG);
       if (cp.prof) hipLaunchKernelGGL((k_dp5_spec<true, 4>), g, bdim, 0, c->stream, cp);
-      else if (d5w == 6) hipLaunchKernelGGL((k_dp5_spec<false, 6>), g, bdim, 0, c->stream, cp);
       else hipLaunchKernelGGL((k_dp5_spec<false, 4>), g, bdim, 0, c->stream, cp);
     }
     if (ntask > nblk) {
       hipLaunchKernelGGL(k_dpcheck, dim3(ntask), dim3(64), 0, c->stream, cp);
+      // a second speculative run, from the level the chain of shifts implies, for the tasks that only
+      // missed their level (ZOPFLI_AMD_SEG_REDO=0: leave them to the serial pass)
+      static const bool redo = [] { const char* e = std::getenv("ZOPFLI_AMD_SEG_REDO"); return !e || std::atoi(e) != 0; }();
+      if (redo) {
+        HIPCHK(hipMemsetAsync(t->d_redo, 0, sizeof(u32), c->stream));
+        hipLaunchKernelGGL(k_dpscan, dim3(nblk), dim3(64), 0, c->stream, cp);
+        Dp4Params c2 = cp;
+        c2.redo_pass = 1;
+        c2.est_bits = nullptr;
+        // (at most a quarter of the tasks: beyond that the guesses were so poor that the serial pass
+        //  is not the problem)
+        const unsigned cap = std::max(1u, ntask / 4);
+        if (cp.prof) hipLaunchKernelGGL((k_dp5_spec<true, 4>), dim3(cap), dim3(64 * D5_WG), 0, c->stream, c2);
+        else hipLaunchKernelGGL((k_dp5_spec<false, 4>), dim3(cap), dim3(64 * D5_WG), 0, c->stream, c2);
+        hipLaunchKernelGGL(k_dpcheck, dim3(ntask), dim3(64), 0, c->stream, cp);
+      }
       if (cp.prof) hipLaunchKernelGGL(k_dp4_fix<true>, dim3(nblk), dpdim, 0, c->stream, cp);
       else hipLaunchKernelGGL(k_dp4_fix<false>, dim3(nblk), dpdim, 0, c->stream, cp);
     }

@@ -591,15 +591,41 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
           const u32 km1 = lane - pw - 1;
           const u32 smax = (ke + pw) >> 6;
           reach = reach > ke + pw ? reach : ke + pw;
+          if (smax < 2) {
 #pragma unroll
-          for (int s = 0; s < 6; ++s) {
-            if ((u32)s <= smax) {
-              const u32 k1 = km1 + 64u * s;
-              if (k1 < ke) {
-                const double w = ring_w(&s_ring[DP_FRONT + ((ro + k1) & (DP_RING - 1))]);
-                const double mcl = k1 == 0 ? -kInf : mincost;
-                DP_RELAX(c[s], l[s], w, mcl)
+            for (int s = 0; s < 2; ++s) {
+              if ((u32)s <= smax) {
+                const u32 k1 = km1 + 64u * s;
+                if (k1 < ke) {
+                  const double w = ring_w(&s_ring[DP_FRONT + ((ro + k1) & (DP_RING - 1))]);
+                  const double mcl = k1 == 0 ? -kInf : mincost;
+                  DP_RELAX(c[s], l[s], w, mcl)
+                }
               }
+            }
+          } else {
+            // a long row (runs, long repeats): all six registers, branch-free, so that the six code
+            // reads and then the six weight reads are in flight together instead of one dependent
+            // pair of LDS round trips per register.  A lane outside the row takes slot "FRONT - 1 -
+            // lane", whatever it holds, and +inf instead of its weight.
+            u32 cd[6];
+            double wv[6];
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+              const u32 k1 = km1 + 64u * s;
+              cd[s] = s_ring[DP_FRONT + ((ro + (k1 < ke ? k1 : 0u)) & (DP_RING - 1))];
+            }
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+              const u32 k1 = km1 + 64u * s;
+              const double w = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(s_wtab) + (cd[s] & 0x3ff8u));
+              wv[s] = k1 < ke ? w : kInf;
+            }
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+              const u32 k1 = km1 + 64u * s;
+              const double mcl = k1 == 0 ? -kInf : mincost;
+              DP_RELAX(c[s], l[s], wv[s], mcl)
             }
           }
         }

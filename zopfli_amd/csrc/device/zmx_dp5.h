@@ -317,15 +317,33 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
         const u32 km1 = lane - p - 1;
         const u32 smax = (ke + p) >> 6;
         reach = reach > ke + p ? reach : ke + p;
+        if (smax < 2) {
 #pragma unroll
-        for (int s = 0; s < 6; ++s) {
-          if ((u32)s <= smax) {
-            const u32 k1 = km1 + 64u * s;
-            if (k1 < ke) {
-              const double w = code_w(rows[ro + k1]);
-              const double mcl = k1 == 0 ? -kInf : mincost;
-              DP_RELAX(c[s], l[s], w, mcl)
+          for (int s = 0; s < 2; ++s) {
+            if ((u32)s <= smax) {
+              const u32 k1 = km1 + 64u * s;
+              if (k1 < ke) {
+                const double w = code_w(rows[ro + k1]);
+                const double mcl = k1 == 0 ? -kInf : mincost;
+                DP_RELAX(c[s], l[s], w, mcl)
+              }
             }
+          }
+        } else {
+          // a long row: all six registers, branch-free, the six code loads in flight together (a lane
+          // outside the row reads the row's first code and takes +inf instead of its weight)
+          u32 cd[6];
+#pragma unroll
+          for (int s = 0; s < 6; ++s) {
+            const u32 k1 = km1 + 64u * s;
+            cd[s] = rows[ro + (k1 < ke ? k1 : 0u)];
+          }
+#pragma unroll
+          for (int s = 0; s < 6; ++s) {
+            const u32 k1 = km1 + 64u * s;
+            const double w = k1 < ke ? code_w(cd[s]) : kInf;
+            const double mcl = k1 == 0 ? -kInf : mincost;
+            DP_RELAX(c[s], l[s], w, mcl)
           }
         }
         noshort = false;

@@ -96,7 +96,8 @@
   }
 
 #define D3_NB 2u         // tile-building waves (waves 2..); wave 0 = the chain, wave 1 = the walk and the ring
-#define D3_SPAN 896u     // rows of four consecutive steps fit in the ring (4 * (896 + 511 of alignment) <= 8192)
+#define D3_SPAN 3584u    // rows of four consecutive steps fit in the ring (4 * (3584 + 511 of alignment) <= 16384);
+                         // a row has up to 258 slots: at least 13 positions per step
 #define D3_DESC_CLEAN (1u << 25)   // descriptor word 0: a whole group, no flagged / two-register / bad-edge position
 #define D3_EV_NONE 0u
 #define D3_EV_SHORTCUT 1u

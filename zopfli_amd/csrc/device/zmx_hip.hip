@@ -806,7 +806,9 @@ static void RunInfo(const double* cost, const u32* hist, u32 B, float* wmax_out,
   }
   *wmax_out = static_cast<float>(wmax) + 1.0f;
   *tiemask_out = mask;
-  double est = 2.5 * B;   // no parse to go by: the tasks' levels are refined by the run itself
+  // no parse to go by (the fixed-tree re-parse, deflate.c:770-781, which is tried on blocks that
+  // compress badly): close to 8 bits per byte; the run refines the tasks' levels itself
+  double est = 8.0 * B;
   if (hist) {
     est = 0;
     for (int i = 0; i < ZMX_NUM_LL; ++i) est += hist[i] * (ll[i] + (i > 256 ? lbits(i) : 0));
@@ -946,9 +948,8 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
         Dp4Params c2 = cp;
         c2.redo_pass = 1;
         c2.est_bits = nullptr;
-        // (at most a quarter of the tasks: beyond that the guesses were so poor that the serial pass
-        //  is not the problem)
-        const unsigned cap = std::max(1u, ntask / 4);
+        // (one workgroup per listed task; the workgroups beyond the list have nothing to do)
+        const unsigned cap = ntask;
         if (cp.prof) hipLaunchKernelGGL((k_dp5_spec<true, 4>), dim3(cap), dim3(64 * D5_WG), 0, c->stream, c2);
         else hipLaunchKernelGGL((k_dp5_spec<false, 4>), dim3(cap), dim3(64 * D5_WG), 0, c->stream, c2);
         hipLaunchKernelGGL(k_dpcheck, dim3(ntask), dim3(64), 0, c->stream, cp);

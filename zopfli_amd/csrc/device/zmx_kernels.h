@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256) void k_badscan(BadScanParams P) {
 
 // ------------------------------------------- shared by the chain kernels (zmx_dp4.h)
 #define ZMX_PROF_N 32u                // u64 profiling counters per block (ZOPFLI_AMD_PROF)
-#define DP_RING 8192u                 // weight codes in the LDS ring (16 KB)
+#define DP_RING 16384u                // weight codes in the LDS ring (32 KB)
 #define DP_PIECE 512u                 // codes per LDS-DMA instruction (64 lanes x 16 B)
 #define DP_XN 704u                    // long-run shortcut staging: 384 cells
 #define DP_FRONT 64u                  // slack before the ring: masked-off lanes address up to 64 slots back

@@ -24,6 +24,17 @@ def main(paths):
             out[k]["launches"] = n
             for c, x in v.items():
                 out[k][c] = x / n
+    # the chain of one squeeze run = k_dp5_spec (both passes) + k_dpcheck + k_dpscan + k_dp4_fix: totals over
+    # all their launches divided by the number of squeeze runs (= launches of k_dp4_fix)
+    runs = out.get("k_dp4_fix", {}).get("launches", 0)
+    if runs:
+        chain = collections.defaultdict(float)
+        for k in ("k_dp5_spec", "k_dpcheck", "k_dpscan", "k_dp4_fix"):
+            for c, x in out.get(k, {}).items():
+                if c != "launches":
+                    chain[c] += x * out[k]["launches"] / runs
+        chain["launches"] = runs
+        out["chain"] = dict(chain)
     for k, v in out.items():
         if "FETCH_SIZE" in v:
             v["fetch_bytes"] = v["FETCH_SIZE"] * 1024 * 2

@@ -396,6 +396,18 @@ def main():
             "breakdown_s_per_step": {k: round(v / args.steps, 4) for k, v in timing_acc.items()
                                      if k not in ("squeeze_launches", "table_builds", "positions_matched")},
         }
+        tasks_per_launch = seg_acc.get("tasks", 0.0) / launches if launches else 0.0
+        if world == 1 and tasks_per_launch and ksec > 0:
+            # Predicted strong-scaling ceiling from the chain's latency: a squeeze run cannot take less than one
+            # round of task waves (a task is a serial chain of ~4600 positions) however few blocks a GPU holds;
+            # the merge on rank 0 and the gather do not shrink either.  T(N) = c + (T1 - c) / N.
+            rounds = max(1.0, tasks_per_launch / (256 * 16))
+            c = (ksec / rounds + timing_acc.get("merge", 0.0) + timing_acc.get("gather", 0.0)) / args.steps
+            t1 = ms / 1e3
+            line["strong_scaling_model"] = {
+                "formula": "T(N) = c + (T1 - c)/N, c = runs x (chain time / rounds of task waves) + merge + gather",
+                "wave_rounds_per_run": round(rounds, 2), "c_ms": round(c * 1e3, 2),
+                "predicted_speedup": {str(n): round(t1 / (c + (t1 - c) / n), 2) for n in (2, 4, 8)}}
         if world == 1 and not args.no_cpu_baseline:
             sample = shard[:min(args.cpu_sample, size)]
             res = cpu_baseline(sample, options)

@@ -335,13 +335,16 @@ struct Dp4Params {
   float level_scale;       // test hook (ZOPFLI_AMD_SEG_SCALE): the guessed levels are multiplied by this
   const u32* wg_tasks;     // k_dp5_spec: [workgroups][4] the tasks of each workgroup (one block each; SEG_NONE = none),
                            // the workgroups that hold a head first; task0 = first workgroup of the launch
-  const void* dsc;         // k_dp5_spec: one row descriptor per block position (k_mkdesc)
+  const u32* wmeta;        // k_dp5_spec: [windows][40] the record of each 32-position window (k_mkdesc)
+  const u32* winroff;      // k_dp5_spec: [windows] first row of each window (k_mkdesc)
   const u32* winflag;      // k_dp5_spec: per 32-position window, 1 = can take the fast path (k_mkdesc)
   const u32* win_off;      // [nb_total] first window of each block in winflag[]
   int debug;               // ZOPFLI_AMD_SEG_DEBUG: k_dp4_fix prints its decisions
   u16* over;               // [tasks][SEG_OVER] lengths of the cells a speculative task computed beyond its pend
   u32* redo_count;         // k_dpscan: number of tasks to run a second time ...
   u32* redo_wg;            // ... and their workgroups for k_dp5_spec ([count][4]: the task, then SEG_NONE)
+  int int_path;            // k_dp5_spec: 1 = clean windows inside the workgroup's binade take the integer chain step (ZOPFLI_AMD_INT_PATH)
+  int fix_lean_min;        // k_dp4_fix: a task with this many generic windows is re-run by the lean one-wave job
   int redo_pass;           // k_dp5_spec: 1 = this launch runs P.redo_wg (workgroups beyond *redo_count have nothing to do)
 };
 
@@ -970,94 +973,4 @@ __device__ __forceinline__ void d4_copy_over(const Dp4Params& P, u32 t, u32 B, u
   for (u32 i = threadIdx.x; pend + i < stop && pend + i <= B; i += blockDim.x) la[pend + i] = over[i];
 }
 
-// ---------------------------------------------------------------------------------------------
-// FIX: one workgroup per block walks the block's tasks in order, accepts every task whose entry
-// state is the true state up to a shift that keeps the task inside its binade, and runs the others
-// again from the true state — the serial chain, for exactly the stretches that need it.
-// ---------------------------------------------------------------------------------------------
-template <bool PROF>
-__global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
-  D4_LDS_DECL
-  const u32 b = P.block0 + blockIdx.x;
-  const BlockDesc bd = P.blocks[b];
-  const u32 B = (u32)(bd.inend - bd.instart);
-  if (B == 0) return;
-  const u32 t0 = P.task_off[b], t1 = P.task_off[b + 1];
-  const u32 lane = threadIdx.x & 63;
-  const bool lead = threadIdx.x == 0;
-  const double wmax = (double)P.wmax[b] + 1.0;
-  const u32 tiemask = P.tiemask[b];
-  for (u32 i = threadIdx.x; i < ZMX_WTAB; i += blockDim.x) s_wtab[i] = P.wtab[(u64)b * ZMX_WTAB + i];
-  __syncthreads();
-  u16* la_block = P.la + bd.la_off;
-  d4_copy_over(P, t0, B, la_block);   // the head is exact
-  double delta_prev = 0.0;     // what has to be added to exit[t - 1] to get the true values
-  bool rerun_prev = false;     // exit[t - 1] was rewritten by this workgroup: P.chk[t] is stale
-  u32 n_ok = 0, n_state = 0, n_level = 0, n_tie = 0, n_pos = 0, n_values = 0;
-  const u64 cyc0 = __builtin_readcyclecounter();
-  u64 cyc_run = 0;
-  for (u32 t = t0 + 1; t < t1; ++t) {
-    SegCheck ck;
-    if (rerun_prev) ck = d4_check(&P.exit[t - 1], &P.entry[t], lane);   // every wave computes the same
-    else ck = P.chk[t];
-    const double delta = delta_prev + ck.d;
-    // the guess to start the next run of this task from
-    if (lead) P.lvl[t] = (float)((double)P.lvl[t] + delta);
-    bool ok = ck.match == 1;
-    u32 why = 0;
-    if (ok) {
-      why = d4_accept(ck.vmin, (double)P.exit[t].vmax, delta, wmax, tiemask);
-      ok = why == 0;
-    }
-    if (P.debug == 1 && lead) {
-      printf("fix b %u t %u pout %u: match %u d %.6f delta %.6f vmin %.4f vmax %.4f why %u ok %d entry base %u exit-1 base %u\n", b,
-             t - t0, P.tasks[t].pout, ck.match, ck.d, delta, (double)ck.vmin, (double)P.exit[t].vmax, why, ok ? 1 : 0,
-             P.entry[t].base, P.exit[t - 1].base);
-    }
-    if (ok) {
-      d4_copy_over(P, t, B, la_block);
-      delta_prev = delta;
-      rerun_prev = false;
-      ++n_ok;
-      continue;
-    }
-    if (ck.match == 0) ++n_state; else if (ck.match == 2) ++n_values; else if (why == 1) ++n_level; else ++n_tie;
-    const SegTask T = P.tasks[t];
-    D4Job J;
-    J.start = P.exit[t - 1].base;
-    J.noshort = P.exit[t - 1].noshort;
-    J.pout = 0;
-    J.pend = T.pend;
-    J.la_lo = J.start;
-    J.over_lo = SEG_NONE;    // (this workgroup is the only writer of the block's length_array now)
-    J.spec = false;
-    J.load = true;
-    J.level = 0.0f;
-    J.delta = delta_prev;
-    J.init = &P.exit[t - 1];
-    J.entry = nullptr;
-    J.exit = &P.exit[t];
-    J.over = nullptr;
-    n_pos += (T.pend < B ? T.pend : B) - (J.start < B ? J.start : B);
-    __syncthreads();     // every wave has read the old exit[t] / exit[t - 1]
-    const u64 cr0 = __builtin_readcyclecounter();
-    d4_run_job<PROF>(P, J, b, bd, s_ring, s_wtab, s_t1, s_t2, s_tab, s_desc, s_tabc, s_xc, s_xl, s_lout);
-    cyc_run += __builtin_readcyclecounter() - cr0;
-    delta_prev = 0.0;
-    rerun_prev = true;
-  }
-  if (P.debug >= 2 && lead) {
-    printf("fix b %u: %u tasks ok %u state %u values %u level %u tie %u, %u positions re-run, %llu cycles in all, %llu in re-runs\n", b,
-           t1 - t0, n_ok, n_state, n_values, n_level, n_tie, n_pos, (unsigned long long)(__builtin_readcyclecounter() - cyc0),
-           (unsigned long long)cyc_run);
-  }
-  if (lead && P.stats) {
-    atomicAdd(&P.stats[0], t1 - t0);
-    atomicAdd(&P.stats[1], n_ok);
-    atomicAdd(&P.stats[2], n_state);
-    atomicAdd(&P.stats[3], n_level);
-    atomicAdd(&P.stats[4], n_tie);
-    atomicAdd(&P.stats[5], n_pos);
-    atomicAdd(&P.stats[6], n_values);
-  }
-}
+// (k_dp4_fix, the serial pass, is at the end of zmx_dp5.h: it uses the jobs of both files)

@@ -37,18 +37,31 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
 typedef u32 d5_u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) d5_u32x4* d5_cdscp;
 
-// One buffer descriptor per block position whose buffer IS the position's row of weight codes: base =
-// its first slot in codes[], kend * 2 bytes long (k_mkdesc, once per table build).
+// What k_dp5_spec needs to fetch the rows of a 32-position window (aligned to the block start).  The rows of
+// consecutive positions are consecutive in codes[] (dph's offsets are a running sum of the row lengths), so the
+// wave copies the window's codes into LDS in one piece and lane l finds code l - u - 1 of row u at index
+// rel[u] + l of the copy.  Everything a window needs besides the codes is ONE 40-word record (wmeta), fetched by
+// ONE vector load a window ahead: words 0..31 = (rel[u] + 32) << 16 | kend[u], 32 / 33 = where the window's rows
+// start / end in the block's codes, 34 = the window's class (1 = 32 positions, none flagged for the long-run
+// shortcut, no edge beyond cell register 0; 2 = none flagged, edges of any length; 0 = neither).
+//
+// Why this shape — what round 2 measured on the way (all bit-exact, profiles/): a 16-byte buffer descriptor per
+// position and a buffer_load per row: the CU's address unit is busy 16 cycles per wave-wide load whatever the
+// lanes do, 256 cycles per position with 16 waves; descriptors built by SALU from packed row lengths: 30
+// instructions per position around a chain step of six, and a wave issues one instruction per four cycles at
+// best; s_load for the per-window words: SMEM shares its counter with LDS, so nothing scalar can be in flight
+// across a window; and, throughout, three dependent memory round trips per window that four waves per SIMD do
+// not hide (95 % of a window's 9 000 cycles were waiting).
+#define D5_WM 40u          // words per window in wmeta[]
+#define D5_STAGE_BYTES 4352u    // a wave's staging area: >= 4096 + 16, >= 6 DP_XN
+#define D5_STAGE_HALF 2176u     // two halves of >= 2048 + 16 for the LDS-DMA double buffer
 struct MkDescParams {
   const BlockDesc* blocks;
   const uint2* dph;
-  const u64* code_base;
-  const u16* codes;
-  d5_u32x4* dsc;
-  const u32* win_off;   // [nb] first entry of each block in winflag[]
-  u32* winflag;         // per 32-position window of a block (aligned to the block start): 1 = 32 positions, none flagged
-                        // for the long-run shortcut, none with an edge beyond cell register 0 of a window at that
-                        // place; 2 = 32 positions, none flagged, edges of any length; 0 = neither
+  u32* wmeta;           // [windows + 1 per block][D5_WM]
+  u32* winroff;         // [windows + 1 per block] = wmeta word 32 (the scalar path of windows nobody prefetched)
+  const u32* win_off;   // [nb] first window of each block in winflag[] / winroff[] / wmeta[]
+  u32* winflag;         // [windows + 1 per block] = wmeta word 34
 };
 
 __global__ __launch_bounds__(256) void k_mkdesc(MkDescParams P) {
@@ -58,23 +71,112 @@ __global__ __launch_bounds__(256) void k_mkdesc(MkDescParams P) {
   const u32 lane = threadIdx.x & 63;
   uint2 dhw = make_uint2(0, 0);
   if (p < B) dhw = P.dph[bd.pos_off + p];
-  // (whole waves take part in the ballots; a wave covers two windows)
+  // (whole waves take part in the ballots and the shuffle; a wave covers two windows)
   const bool flagged = p >= B || (dhw.y >> 16) != 0;
   const u64 not1 = __ballot(flagged || (dhw.y & 0xffffu) + (lane & 31u) >= 64u);    // an edge beyond cell register 0
   const u64 not2 = __ballot(flagged);                                                // flagged for the shortcut, or short
+  const u32 first = (u32)__shfl((int)dhw.x, (int)(lane & 32u), 64);                  // row offset of the window's first position
+  const u32 w = P.win_off[blockIdx.y] + (p >> 5);
+  u32* wm = P.wmeta + (u64)w * D5_WM;
+  const u32 kend = dhw.y & 0xffffu;
+  if (p < ((B + 31u) & ~31u)) wm[p & 31u] = p < B ? ((dhw.x - first + 32u - ((p & 31u) + 1u)) << 16) | kend : 0u;
   if ((lane & 31u) == 0 && p < B) {
     const u32 sh = lane & 32u;
-    P.winflag[P.win_off[blockIdx.y] + (p >> 5)] = (u32)(not1 >> sh) == 0 ? 1u : (u32)(not2 >> sh) == 0 ? 2u : 0u;
+    const u32 f = (u32)(not1 >> sh) == 0 ? 1u : (u32)(not2 >> sh) == 0 ? 2u : 0u;
+    P.winflag[w] = f;
+    P.winroff[w] = dhw.x;
+    wm[32] = dhw.x;
+    wm[34] = f;
   }
-  if (p >= B) return;
-  const uint2 dh = dhw;
-  const u64 a = reinterpret_cast<u64>(P.codes + P.code_base[blockIdx.y] + dh.x);
-  d5_u32x4 d;
-  d.x = (u32)a;
-  d.y = (u32)(a >> 32) & 0xffffu;     // stride 0
-  d.z = (dh.y & 0xffffu) * 2u;        // bytes in the row
-  d.w = 0x00020000u;                  // raw 32-bit data format
-  P.dsc[bd.pos_off + p] = d;
+  if (p < B && ((p & 31u) == 31u || p + 1 == B)) wm[33] = dhw.x + kend;           // where the window's rows end
+  if (p + 1 == B) {      // one record past the last window: where the block's rows end, class 0
+    P.winroff[w + 1] = dhw.x + kend;
+    P.winflag[w + 1] = 0;
+    wm[D5_WM + 32] = dhw.x + kend;
+    wm[D5_WM + 33] = dhw.x + kend;
+    wm[D5_WM + 34] = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The chain step in INTEGER arithmetic, exact inside one binade.
+//
+// Let every value a window touches lie in [2^e, 2^(e+1)): floats there are the multiples of u = 2^(e-23),
+// doubles the multiples of g = 2^(e-52) = u / 2^29, and the bit patterns of the floats are consecutive
+// integers.  For a source cell cj = Cj u and a weight w the reference computes (squeeze.c:290-299)
+//     nc = fl64(cj + w) = cj + r g,   r = RNE(w / g)        (cj is a multiple of 2^29 g: the rounding only sees w)
+//     nc < (double)c   <=>   Cj 2^29 + r < C 2^29   <=>   Cj + (r >> 29) < C
+//     (float)nc = (Cj + (r >> 29) + [r mod 2^29 > 2^28]) u           (no tie: r mod 2^29 != 2^28)
+// so with the two small integers RH = r >> 29 and RR = RH + [r mod 2^29 > 2^28] per weight, on the BIT
+// PATTERNS of the floats:   update <=> bits(cj) + RH < bits(c),   bits(c) <- min(bits(c), bits(cj) + RR)
+// (if bits(cj) + RH < bits(c) then bits(cj) + RR <= bits(c), so the min is the update; otherwise it leaves
+// c alone) — five full-rate 32-bit VALU instructions instead of six double-precision ones.  r is the very
+// integer the tie mask is computed from (RunInfo, zmx_hip.hip); a binade in which a weight can tie is never
+// taken.  D5IntTab is the table {RR, RH} of one binade, built by the workgroup from the run's weights;
+// a window takes the integer path only if its 32 source cells lie in that binade and, with 33 times the
+// largest weight on top (a cell can become a source 32 times over), stay below its end.
+// ---------------------------------------------------------------------------------------------
+struct D5IntTab {
+  bool on;             // the workgroup has a table: s_itab[code >> 3] = {RR, RH} (no edge: 2^30 both)
+  u32 lo;              // bit pattern of 2^e
+  u32 span;            // 33 x the largest finite RR (saturated)
+};
+#define D5_NOEDGE 0x40000000u
+// the lane mask of bits [OFS, OFS + WIDTH) (WIDTH < 64; only the low six bits of either operand count)
+#define D5_BFM(M, WIDTH, OFS) asm("s_bfm_b64 %0, %1, %2" : "=s"(M) : "s"(WIDTH), "n"(OFS))
+
+// RNE(w 2^(52 - e)) for a finite w >= 0, by integer arithmetic on the mantissa (as RunInfo does it)
+__device__ __forceinline__ u64 d5_rne_scaled(double w, int e) {
+  const u64 bits = (u64)__double_as_longlong(w);
+  const int ew = (int)((bits >> 52) & 0x7ffu);
+  if (ew == 0) return 0;                                // zero (subnormals: far below any g)
+  const u64 m = (bits & 0xfffffffffffffull) | (1ull << 52);   // w = m 2^(ew - 1075)
+  const int sh = e - (ew - 1023);                       // r = RNE(m / 2^sh)
+  if (sh <= 0) return sh < -10 ? ~0ull : m << -sh;
+  if (sh >= 64) return 0;
+  const u64 q = m >> sh, rem = m & ((1ull << sh) - 1), half = 1ull << (sh - 1);
+  return q + ((rem > half || (rem == half && (q & 1))) ? 1 : 0);
+}
+
+// max / min over the 64 lanes of a wave (four DPP rows), the result uniform
+__device__ __forceinline__ u32 d5_max64(u32 v) {
+#define D5_DPP_STEP(CTRL) { const u32 t_ = (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false); v = v > t_ ? v : t_; }
+  D5_DPP_STEP(0x111) D5_DPP_STEP(0x112) D5_DPP_STEP(0x114) D5_DPP_STEP(0x118)
+#undef D5_DPP_STEP
+  const u32 a = (u32)__builtin_amdgcn_readlane((int)v, 15), b2 = (u32)__builtin_amdgcn_readlane((int)v, 31);
+  const u32 a3 = (u32)__builtin_amdgcn_readlane((int)v, 47), a4 = (u32)__builtin_amdgcn_readlane((int)v, 63);
+  const u32 m1 = a > b2 ? a : b2, m2 = a3 > a4 ? a3 : a4;
+  return m1 > m2 ? m1 : m2;
+}
+__device__ __forceinline__ u32 d5_min64(u32 v) {
+#define D5_DPP_STEP(CTRL) { const u32 t_ = (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false); v = v < t_ ? v : t_; }
+  D5_DPP_STEP(0x111) D5_DPP_STEP(0x112) D5_DPP_STEP(0x114) D5_DPP_STEP(0x118)
+#undef D5_DPP_STEP
+  const u32 a = (u32)__builtin_amdgcn_readlane((int)v, 15), b2 = (u32)__builtin_amdgcn_readlane((int)v, 31);
+  const u32 a3 = (u32)__builtin_amdgcn_readlane((int)v, 47), a4 = (u32)__builtin_amdgcn_readlane((int)v, 63);
+  const u32 m1 = a < b2 ? a : b2, m2 = a3 < a4 ? a3 : a4;
+  return m1 < m2 ? m1 : m2;
+}
+
+// The workgroup builds the table of binade `e` from the run's weights (s_wtab is in place); returns false
+// (every thread alike) when the binade is out of range or a weight can tie there.
+__device__ __forceinline__ void d5_build_inttab(const double (&s_wtab)[ZMX_WTAB], uint2 (&s_itab)[ZMX_WTAB], u32& s_rmax, int e) {
+  for (u32 i = threadIdx.x; i < ZMX_WTAB; i += blockDim.x) {
+    const double w = s_wtab[i];
+    uint2 v = make_uint2(D5_NOEDGE, D5_NOEDGE);
+    if (w < 1e300 && i != 0) {
+      const u64 r = d5_rne_scaled(w, e);
+      const u64 rh = r >> 29;
+      u32 rr = 0xfffffu;                // (a weight that large: the span test keeps every window out)
+      if (rh < 0xfffffull) {
+        rr = (u32)rh + ((r & 0x1fffffffull) > 0x10000000ull ? 1u : 0u);
+        v.x = rr;
+        v.y = (u32)rh;
+      }
+      atomicMax(&s_rmax, rr);
+    }
+    s_itab[i] = v;
+  }
 }
 
 struct D5Cls {          // one window on the generic path: lane l < 32 = position wbase + l
@@ -85,9 +187,17 @@ struct D5Cls {          // one window on the generic path: lane l < 32 = positio
 
 template <bool PROF>
 __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u32 b, const BlockDesc& bd,
-                                           const double (&s_wtab)[ZMX_WTAB], float (&s_xc)[DP_XN], u16 (&s_xl)[DP_XN]) {
+                                           const double (&s_wtab)[ZMX_WTAB], float* s_xc, u16* s_xl, u16* s_stage,
+                                           const uint2 (&s_itab)[ZMX_WTAB], const D5IntTab& IT) {
+  typedef __attribute__((address_space(3))) const u16* lds_u16p;
+  typedef __attribute__((address_space(3))) d5_u32x4* lds_u4p;
+  // (the LDS byte address of the wave's staging area, halved: it joins the scalar part of the lanes' addresses)
+  const u32 stage_half = (u32)__builtin_amdgcn_readfirstlane((int)((u32)(size_t)(__attribute__((address_space(3))) void*)s_stage >> 1));
   const u32 lane = threadIdx.x & 63;
   const u32 lane2 = lane * 2u;
+  // (byte offset of lane l into the row of position u of a window: 2 (l - u - 1), wrapping below the row so that
+  //  the buffer's range check drops the lane.  It has to be ONE register: a negative register plus a positive
+  //  instruction offset is out of range for the hardware even where the sum is not — measured, wrong data.)
   const u32 B = (u32)(bd.inend - bd.instart);
   const uint2* __restrict__ dbase = uniform_ptr(P.dph + bd.pos_off);
   const u32* __restrict__ badpos = uniform_ptr(P.badpos + (bd.pos_off >> 5));
@@ -98,9 +208,11 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
   auto code_w = [&](u32 code) -> double {
     return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(s_wtab) + code);
   };
-  const d5_u32x4* __restrict__ dsc = uniform_ptr(static_cast<const d5_u32x4*>(P.dsc) + bd.pos_off);
   typedef const __attribute__((address_space(4))) u32* cu32p;
   const cu32p winflag = (cu32p)uniform_ptr(P.winflag + P.win_off[b]);
+  const cu32p winroff = (cu32p)uniform_ptr(P.winroff + P.win_off[b]);
+  const u32* __restrict__ wmeta = uniform_ptr(P.wmeta + (u64)P.win_off[b] * D5_WM);
+  const u64 rows_addr = reinterpret_cast<u64>(rows);
   const cu32p badw = (cu32p)badpos;
   const double mincost = P.mincost[b];
   const double symbolcost258 = (double)(0 + 0) + P.cost[(u64)b * 320 + 285] + P.cost[(u64)b * 320 + 288];
@@ -135,23 +247,25 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
   float vmax = 0.0f;
   u32 wbase = (u32)__builtin_amdgcn_readfirstlane((int)J.start);
   bool noshort = J.noshort != 0;
-  u64 n_fast = 0, n_slow = 0;
+  u64 n_fast = 0, n_slow = 0, n_int = 0;
+  u64 kc[4] = {0, 0, 0, 0}, kn[4] = {0, 0, 0, 0};   // PROF: cycles / positions per window class: integer, class 1 in doubles, class 2, generic
+  u64 pw[4] = {0, 0, 0, 0};   // PROF, integer windows: class decision, wait for the prefetched data, staging + prefetch issue, retire
+  u64 pq[3] = {0, 0, 0};   // PROF: cycles of the integer windows: issuing the row fetches, waiting for them, the chain
   const u64 t_begin = PROF ? (u64)__builtin_readcyclecounter() : 0ull;
 
-  // weights of the rows of positions WB + U0 .. WB + U0 + 15 into WV: the row's codes are the buffer;
-  // lanes below u + 1 (the offset wraps) and beyond u + kend are out of range, never reach the cache
-  // and come back as code 0 = +inf
-#define D5_ISSUE(WV, WB, U0)                                                                      \
+  // The codes of the rows of positions U0 .. U0 + 15 of a window whose codes are staged in LDS (below): lane l
+  // wants code l - u - 1 of row u, staged at index rel[u] + l (+ where the copy starts: in LB, per lane); the lanes
+  // that have one are bits u + 1 .. u + kend, the others get code 0 = no edge.  META: the window's record, word u
+  // in lane u.  Per position: v_readlane, s_lshr, v_add_lshl, ds_read_u16, s_bfm, v_cndmask.
+#define D5_PICK16(CD, META, LB, U0)                                                               \
   {                                                                                               \
-    const d5_cdscp dw_ = (d5_cdscp)(dsc + (WB) + (U0));     /* uniform: s_load */                  \
-    u32 cd_[16];                                                                                  \
     _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                              \
-      const d5_u32x4 d_ = dw_[u];                                                                 \
-      const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(                       \
-          reinterpret_cast<void*>(((u64)d_.y << 32) | d_.x), (short)0, (int)d_.z, (int)d_.w);     \
-      cd_[u] = (u32)(u16)__builtin_amdgcn_raw_buffer_load_b16(rs_, (int)(lane2 - 2u * (u32)((U0) + u + 1)), 0, 0); \
+      const u32 w_ = rdlane_u32(META, (u32)((U0) + u));                                           \
+      const u32 v_ = *(lds_u16p)((LB + (w_ >> 16)) << 1);                                         \
+      u64 m_;                                                                                     \
+      D5_BFM(m_, w_, (U0) + u + 1);                                                               \
+      CD[u] = __builtin_amdgcn_inverse_ballot_w64(m_) ? v_ : 0u;                                  \
     }                                                                                             \
-    _Pragma("unroll") for (int u = 0; u < 16; ++u) WV[u] = code_w(cd_[u]);                        \
   }
   // the chain over positions U0 .. U0 + 15 of the window at wbase
 #define D5_CHAIN(WV, U0)                                                                          \
@@ -159,6 +273,16 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
     _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                              \
       const double cj = (double)rdlane_f32(c[0], (u32)((U0) + u));                                \
       D3_RELAX_K(c[0], lt_, WV[u], (u32)((U0) + u + 1))                                           \
+    }                                                                                             \
+  }
+  // the integer step (D5IntTab) over positions U0 .. U0 + 15
+#define D5_CHAIN_I(WV, U0)                                                                        \
+  {                                                                                               \
+    _Pragma("unroll") for (int u = 0; u < 16; ++u) {                                              \
+      const u32 sj_ = rdlane_u32(cb, (u32)((U0) + u));                                            \
+      const u32 t_ = sj_ + WV[u].x, th_ = sj_ + WV[u].y;                                          \
+      lt_ = th_ < cb ? (u32)((U0) + u + 1) : lt_;                                                 \
+      cb = cb < t_ ? cb : t_;                                                                     \
     }                                                                                             \
   }
   // a window that can take the fast path: at a multiple of 32 from the block start, statically
@@ -170,6 +294,16 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
     const u32 g = bit_off + wb;
     const u64 two = ((u64)badw[(g >> 5) + 1] << 32) | badw[g >> 5];
     return (u32)(two >> (g & 31u)) == 0 ? f : 0u;
+  };
+  // What a class-1 window has requested for the window after it (nothing scalar: SMEM shares its counter with
+  // LDS): that window's record — with the two words of k_badscan's bitmap that cover it in lanes 40 and 41 —
+  // and the first 2 KB of its codes.
+  typedef __attribute__((address_space(1))) const d5_u32x4* glb_u4p;
+  u32 pf_w = SEG_NONE, pf_meta = 0;
+  const u32* __restrict__ badpos_v = P.badpos + (bd.pos_off >> 5);
+  auto meta_load = [&](u32 w) -> u32 {
+    const u32* a_ = lane < 40 ? wmeta + (u64)w * D5_WM + (lane < 35 ? lane : 0u) : badpos_v + ((bit_off + 32u * w) >> 5) + (lane & 1u);
+    return *a_;
   };
   while (wbase < J.pend) {          // (J.pend = B + 1 on the last task: the window at B retires cell B)
     wbase = (u32)__builtin_amdgcn_readfirstlane((int)wbase);
@@ -183,47 +317,148 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
       vmax = 0.0f;
     }
     bool jumped = false;
-    const u32 kind = win_kind(wbase);
+    const u64 tw0 = PROF ? (u64)__builtin_readcyclecounter() : 0ull;
+    const u64 np0 = n_fast + n_slow;
+    u32 pcls = 3;
+    u32 kind;
+    if (pf_w == (wbase >> 5) && (wbase & 31u) == 0 && wbase + 32u <= B) {
+      const u32 f = rdlane_u32(pf_meta, 34), g = bit_off + wbase;
+      const u64 two = ((u64)rdlane_u32(pf_meta, 41) << 32) | rdlane_u32(pf_meta, 40);
+      kind = f != 0 && (u32)(two >> (g & 31u)) == 0 ? f : 0u;
+    } else {
+      kind = win_kind(wbase);
+    }
     if (kind == 1) {
-      // ---- 32 positions, one cell register, no flags: the rows' weights come straight into registers,
-      //      then the chain.  The other waves of the SIMD run while this one waits for its rows.
-      //      Requesting the next window's codes half a window ahead of the chain was measured SLOWER,
-      //      twice: with the registers for three waves per SIMD (dp 97 vs 91 ms per 15 runs) and, spilling,
-      //      for four (119 ms); six waves per SIMD spill as well (the D5W = 6 build: 2.6x slower).
-      double wv0[16], wv1[16];
-      D5_ISSUE(wv0, wbase, 0)
-      D5_ISSUE(wv1, wbase, 16)
+      // ---- 32 positions, one cell register, no flags
       u32 lt_ = 0;                             // 1 + index of the last position that updated the cell
-      D5_CHAIN(wv0, 0)
-      D5_CHAIN(wv1, 16)
+      bool ipath = false;
+      pcls = 1;
+      const u64 ta_ = PROF ? (u64)__builtin_readcyclecounter() : 0ull;
+      u64 tb_ = 0;
+      if (IT.on) {
+        // every finite cell of the register inside the binade (cells not reached yet, 1e30f, become sources with a
+        // value one of the others gave them: the span covers that)
+        const u32 cb = __float_as_uint(c[0]);
+        const u32 mx = d5_max64(cb < 0x70000000u ? cb : 0u), mn = d5_min64(cb);
+        ipath = mn >= IT.lo && mx + IT.span < IT.lo + 0x800000u;
+      }
+      // The window's rows are consecutive in codes[] (at most 32 x 63 codes): the wave copies them into its LDS
+      // staging area, normally from the registers the previous window asked for them in.
+      const u32 wi_ = wbase >> 5;
+      // The codes arrive by LDS-DMA (no registers in between: eight more live VGPRs made the allocator spill in the
+      // chain), into one of two 2 KB halves of the staging area, the one the previous window asked for them in.
+      u32 meta_;
+      u32 half_ = (wi_ & 1u) * D5_STAGE_HALF;                  // byte offset of this window's half
+      if (pf_w == wi_) {
+        meta_ = pf_meta;
+      } else {                                   // (the first window of a task, or after a window of another class)
+        meta_ = meta_load(wi_);
+        const u16* src_ = reinterpret_cast<const u16*>((rows_addr + 2ull * winroff[wi_]) & ~15ull) + 8u * lane;
+        dp_dma_piece(src_, (stage_half << 1) + half_);
+        dp_dma_piece(src_ + 512, (stage_half << 1) + half_ + 1024u);
+      }
+      const u32 r0_ = rdlane_u32(meta_, 32), r1_ = rdlane_u32(meta_, 33);
+      const u64 ad_ = rows_addr + 2ull * r0_, a0_ = ad_ & ~15ull;
+      const u32 off_ = (u32)(ad_ - a0_);                       // bytes the staged copy starts before the first row
+      const u32 nb_ = 2u * (r1_ - r0_) + off_;
+      if (nb_ > 2048u) {                                       // rare (rows of 33+ codes on average): the whole area, now
+        half_ = 0;
+        const u16* src_ = reinterpret_cast<const u16*>(a0_) + 8u * lane;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (u32 k = 0; k < 4; ++k) dp_dma_piece(src_ + 512u * k, (stage_half << 1) + 1024u * k);
+        pf_w = SEG_NONE;
+      } else {
+        // the next window's record and codes: in flight while this one is worked on
+        const u16* src_ = reinterpret_cast<const u16*>((rows_addr + 2ull * r1_) & ~15ull) + 8u * lane;
+        const u32 nh_ = ((wi_ + 1u) & 1u) * D5_STAGE_HALF;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (this window's codes are in place; they were asked for a window ago)
+        if (PROF) tb_ = __builtin_readcyclecounter();
+        pf_meta = meta_load(wi_ + 1u);
+        dp_dma_piece(src_, (stage_half << 1) + nh_);
+        dp_dma_piece(src_ + 512, (stage_half << 1) + nh_ + 1024u);
+        pf_w = wi_ + 1u;
+      }
+      if (nb_ > 2048u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const u32 lb_ = lane + (stage_half + ((half_ + off_) >> 1) - 32u);   // lane + (staged index of the window's first code) - 32, the LDS base included
+      if (ipath) {
+        // ---- every source of the window and every sum it can form lie in the table's binade: the integer step
+        u32 cd0[16], cd1[16];
+        u64 tq0 = 0, tq1 = 0, tq2 = 0;
+        if (PROF) tq0 = __builtin_readcyclecounter();
+        D5_PICK16(cd0, meta_, lb_, 0)
+        D5_PICK16(cd1, meta_, lb_, 16)
+        if (PROF) { tq1 = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tq2 = __builtin_readcyclecounter(); }
+        uint2 wi0[16], wi1[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wi0[u] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(s_itab) + cd0[u]);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wi1[u] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(s_itab) + cd1[u]);
+        u32 cb = __float_as_uint(c[0]);
+        D5_CHAIN_I(wi0, 0)
+        D5_CHAIN_I(wi1, 16)
+        c[0] = __uint_as_float(cb);
+        if (PROF) {
+          pcls = 0;
+          n_int += 32;
+          const u64 tq3 = __builtin_readcyclecounter();
+          pq[0] += tq1 - tq0; pq[1] += tq2 - tq1; pq[2] += tq3 - tq2;
+          pw[0] += ta_ - tw0; pw[1] += tb_ > ta_ ? tb_ - ta_ : 0; pw[2] += tb_ > ta_ ? tq0 - tb_ : 0;
+        }
+      } else {
+        // ---- the reference's arithmetic (the head of a block, windows that straddle a binade, a binade with a
+        //      possible tie): eight positions at a time, a real loop — few registers, it is the rare case
+#pragma unroll 1
+        for (u32 g = 0; g < 32u; g += 8u) {
+          double wv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const u32 w_ = rdlane_u32(meta_, g + (u32)u);
+            const u32 v_ = *(lds_u16p)((lb_ + (w_ >> 16)) << 1);
+            u64 m_;
+            asm("s_bfm_b64 %0, %1, %2" : "=s"(m_) : "s"(w_), "s"(g + (u32)u + 1u));
+            wv[u] = code_w(__builtin_amdgcn_inverse_ballot_w64(m_) ? v_ : 0u);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const double cj = (double)rdlane_f32(c[0], g + (u32)u);
+            D3_RELAX_K(c[0], lt_, wv[u], g + (u32)u + 1u)
+          }
+        }
+      }
       l[0] = lt_ ? wbase + lt_ : l[0];
       reach = reach > 63 ? reach : 63;
       noshort = false;
       n_fast += 32;
     } else if (kind == 2) {
+      if (pf_w != SEG_NONE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pf_w = SEG_NONE; }   // (codes on their way into the staging area)
       // ---- the same with longer edges (matches of more than 32 bytes: markup, source code): a second
       //      request per row for lanes 64 .. 127 of it and a second relaxation off the chain's critical
       //      path (register 1 is never the source of a position of this window); the few rows that
       //      reach further fetch the rest on demand.  No edge of the window lies below mincost
       //      (win_kind), so squeeze.c:293's test is a no-op here as well.
+      pcls = 2;
       u32 lt_ = 0, lt1_ = 0;
+      const u32 wi_ = wbase >> 5;
+      u64 rb_ = rows_addr + 2ull * winroff[wi_];
 #pragma unroll 1
       for (int h = 0; h < 4; ++h) {          // (eight positions at a time, a real loop: the registers of four waves per SIMD)
-        const d5_cdscp dw_ = (d5_cdscp)(dsc + wbase + 8u * h);
+        const d5_cdscp km_ = (d5_cdscp)(wmeta + (u64)wi_ * D5_WM + 8u * (u32)h);
+        const d5_u32x4 kw_[2] = {km_[0], km_[1]};
         double wa[8], wb[8];
         u32 ca[8], cb[8];
         u32 ke8[8];
         u64 ra8[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const d5_u32x4 d_ = dw_[u];
-          ke8[u] = d_.z >> 1;
-          ra8[u] = ((u64)d_.y << 32) | d_.x;
+          ke8[u] = kw_[u >> 2][u & 3] & 0xffffu;
+          ra8[u] = rb_;
           const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(
-              reinterpret_cast<void*>(ra8[u]), (short)0, (int)d_.z, (int)d_.w);
+              reinterpret_cast<void*>(rb_), (short)0, (int)(2u * ke8[u]), 0x00020000);
           const int vo = (int)(lane2 - 2u * (u32)(8 * h + u + 1));
           ca[u] = (u32)(u16)__builtin_amdgcn_raw_buffer_load_b16(rs_, vo, 0, 0);
           cb[u] = (u32)(u16)__builtin_amdgcn_raw_buffer_load_b16(rs_, vo + 128, 0, 0);
+          rb_ += 2u * ke8[u];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) { wa[u] = code_w(ca[u]); wb[u] = code_w(cb[u]); }
@@ -257,6 +492,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
       n_fast += 32;
     } else {
       // ---- position by position
+      if (pf_w != SEG_NONE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pf_w = SEG_NONE; }   // (the shortcut spills cells where codes may be landing)
       D5Cls W;
       W.nav = B - wbase < 32u ? B - wbase : 32u;
       {
@@ -350,6 +586,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
         ++n_slow;
       }
     }
+    if (PROF) { kc[pcls] += (u64)__builtin_readcyclecounter() - tw0; kn[pcls] += n_fast + n_slow - np0; }
     if (jumped) continue;
     // ---- cells wbase .. wbase + 31 are final
     {
@@ -360,8 +597,9 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
       wbase += 32;
     }
   }
-#undef D5_ISSUE
+#undef D5_PICK16
 #undef D5_CHAIN
+#undef D5_CHAIN_I
   if (J.la_lo == 1 && lane == 0) la[0] = 0;   // the head of the block
   if (J.exit) {
 #pragma unroll
@@ -379,6 +617,10 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
     atomicAdd(&o[2], n_fast); atomicAdd(&o[3], n_slow); atomicAdd(&o[4], n_fast + n_slow);
     atomicAdd(&o[5], (u64)__builtin_readcyclecounter() - t_begin); atomicAdd(&o[6], n_fast);
     atomicAdd(&o[14], n_slow);
+    atomicAdd(&o[10], n_int);
+    for (int i = 0; i < 3; ++i) atomicAdd(&o[20 + i], pw[i]);
+    for (int i = 0; i < 4; ++i) { atomicAdd(&o[24 + i], kc[i]); atomicAdd(&o[28 + i], kn[i]); }
+    atomicAdd(&o[11], pq[0]); atomicAdd(&o[12], pq[1]); atomicAdd(&o[13], pq[2]);
     const u64 dt = (u64)__builtin_readcyclecounter() - t_begin;
     atomicMax(&o[7], dt);                               // the longest task of the block
     if (J.la_lo == 1) atomicAdd(&o[8], dt);             // the head task
@@ -391,15 +633,43 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
 template <bool PROF, int WAVES>
 __global__ __launch_bounds__(64 * D5_WG, WAVES) void k_dp5_spec(Dp4Params P) {
   __shared__ __align__(16) double s_wtab[ZMX_WTAB];
-  __shared__ float s_xc[D5_WG][DP_XN];
-  __shared__ u16 s_xl[D5_WG][DP_XN];
+  // per wave: the staged codes of a window (4 KB + the alignment slack), or the cells of a long-run shortcut
+  __shared__ __align__(16) unsigned char s_buf[D5_WG][D5_STAGE_BYTES];
+  __shared__ __align__(8) uint2 s_itab[ZMX_WTAB];
+  __shared__ u32 s_rmax;
   const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (P.redo_pass && blockIdx.x >= *P.redo_count) return;
   const u32* wg = (P.redo_pass ? P.redo_wg : P.wg_tasks) + (u64)(P.task0 + blockIdx.x) * D5_WG;
   const u32 t0 = wg[0];
   const u32 b0 = P.tasks[t0].block;
   for (u32 i = threadIdx.x; i < ZMX_WTAB; i += 64 * D5_WG) s_wtab[i] = P.wtab[(u64)b0 * ZMX_WTAB + i];
+  if (threadIdx.x == 0) s_rmax = 0;
   __syncthreads();
+  // the level a speculative task starts from
+  auto task_level = [&](u32 tt) -> float {
+    const SegTask K = P.tasks[tt];
+    float lv = P.est_bits ? P.est_bits[K.block] * ((float)K.q / (float)(u32)(P.blocks[K.block].inend - P.blocks[K.block].instart)) : P.lvl[tt];
+    if (!P.redo_pass) lv *= P.level_scale;
+    return lv >= 16.0f ? lv : 16.0f;
+  };
+  // the binade of the workgroup's integer table (zmx_dp5.h, D5IntTab): that of its first speculative task
+  D5IntTab IT;
+  IT.on = false; IT.lo = 0; IT.span = 0;
+  {
+    const u32 tl = P.tasks[t0].pout != 0 ? t0 : wg[1];
+    if (tl != SEG_NONE && P.int_path) {
+      const u32 lb = __float_as_uint(task_level(tl));
+      const int e = (int)(lb >> 23) - 127;
+      if (e >= 4 && e < 31 && ((P.tiemask[b0] >> (e & 31)) & 1u) == 0) {
+        d5_build_inttab(s_wtab, s_itab, s_rmax, e);
+        __syncthreads();
+        const u32 rm = s_rmax;
+        IT.on = true;
+        IT.lo = lb & 0x7f800000u;
+        IT.span = rm < 0x100000u ? 33u * rm : 0x40000000u;
+      }
+    }
+  }
   const u32 t = wg[wave];
   if (t == SEG_NONE) return;
   const SegTask T = P.tasks[t];
@@ -425,10 +695,124 @@ __global__ __launch_bounds__(64 * D5_WG, WAVES) void k_dp5_spec(Dp4Params P) {
   } else {
     J.spec = true;
     J.la_lo = SEG_NONE;
-    J.level = P.est_bits ? P.est_bits[T.block] * ((float)T.q / (float)B) : P.lvl[t];
-    if (!P.redo_pass) J.level *= P.level_scale;
-    if (!(J.level >= 16.0f)) J.level = 16.0f;
+    J.level = task_level(t);
     if (P.est_bits && (threadIdx.x & 63) == 0) P.lvl[t] = J.level;
   }
-  d5_run_job<PROF>(P, J, T.block, bd, s_wtab, s_xc[wave], s_xl[wave]);
+  d5_run_job<PROF>(P, J, T.block, bd, s_wtab, reinterpret_cast<float*>(s_buf[wave]), reinterpret_cast<u16*>(s_buf[wave] + 4u * DP_XN),
+                   reinterpret_cast<u16*>(s_buf[wave]), s_itab, IT);
+}
+
+// ---------------------------------------------------------------------------------------------
+// FIX: one workgroup per block walks the block's tasks in order, accepts every task whose entry
+// state is the true state up to a shift that keeps the task inside its binade, and runs the others
+// again from the true state — the serial chain, for exactly the stretches that need it.  A re-run uses
+// k_dp4's four-wave pipeline (d4_run_job: 57 cycles per position on text, but a ring restart and two
+// bubble steps per long-run shortcut and 14 positions per step where rows are 258 wide), or, for a
+// task with at least P.fix_lean_min windows of the generic kind (shortcut flags, long rows), the lean
+// one-wave job of k_dp5_spec (d5_run_job in load mode: a shortcut is a handful of LDS operations).
+// ---------------------------------------------------------------------------------------------
+template <bool PROF>
+__global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
+  D4_LDS_DECL
+  const u32 b = P.block0 + blockIdx.x;
+  const BlockDesc bd = P.blocks[b];
+  const u32 B = (u32)(bd.inend - bd.instart);
+  if (B == 0) return;
+  const u32 t0 = P.task_off[b], t1 = P.task_off[b + 1];
+  const u32 lane = threadIdx.x & 63;
+  const bool lead = threadIdx.x == 0;
+  const double wmax = (double)P.wmax[b] + 1.0;
+  const u32 tiemask = P.tiemask[b];
+  for (u32 i = threadIdx.x; i < ZMX_WTAB; i += blockDim.x) s_wtab[i] = P.wtab[(u64)b * ZMX_WTAB + i];
+  __syncthreads();
+  u16* la_block = P.la + bd.la_off;
+  d4_copy_over(P, t0, B, la_block);   // the head is exact
+  double delta_prev = 0.0;     // what has to be added to exit[t - 1] to get the true values
+  bool rerun_prev = false;     // exit[t - 1] was rewritten by this workgroup: P.chk[t] is stale
+  u32 n_ok = 0, n_state = 0, n_level = 0, n_tie = 0, n_pos = 0, n_values = 0, n_lean = 0;
+  const u32* winflag = P.winflag + P.win_off[b];
+  const u64 cyc0 = __builtin_readcyclecounter();
+  u64 cyc_run = 0;
+  for (u32 t = t0 + 1; t < t1; ++t) {
+    SegCheck ck;
+    if (rerun_prev) ck = d4_check(&P.exit[t - 1], &P.entry[t], lane);   // every wave computes the same
+    else ck = P.chk[t];
+    const double delta = delta_prev + ck.d;
+    // the guess to start the next run of this task from
+    if (lead) P.lvl[t] = (float)((double)P.lvl[t] + delta);
+    bool ok = ck.match == 1;
+    u32 why = 0;
+    if (ok) {
+      why = d4_accept(ck.vmin, (double)P.exit[t].vmax, delta, wmax, tiemask);
+      ok = why == 0;
+    }
+    if (P.debug == 1 && lead) {
+      printf("fix b %u t %u pout %u: match %u d %.6f delta %.6f vmin %.4f vmax %.4f why %u ok %d entry base %u exit-1 base %u\n", b,
+             t - t0, P.tasks[t].pout, ck.match, ck.d, delta, (double)ck.vmin, (double)P.exit[t].vmax, why, ok ? 1 : 0,
+             P.entry[t].base, P.exit[t - 1].base);
+    }
+    if (ok) {
+      d4_copy_over(P, t, B, la_block);
+      delta_prev = delta;
+      rerun_prev = false;
+      ++n_ok;
+      continue;
+    }
+    if (ck.match == 0) ++n_state; else if (ck.match == 2) ++n_values; else if (why == 1) ++n_level; else ++n_tie;
+    const SegTask T = P.tasks[t];
+    D4Job J;
+    J.start = P.exit[t - 1].base;
+    J.noshort = P.exit[t - 1].noshort;
+    J.pout = 0;
+    J.pend = T.pend;
+    J.la_lo = J.start;
+    J.over_lo = SEG_NONE;    // (this workgroup is the only writer of the block's length_array now)
+    J.spec = false;
+    J.load = true;
+    J.level = 0.0f;
+    J.delta = delta_prev;
+    J.init = &P.exit[t - 1];
+    J.entry = nullptr;
+    J.exit = &P.exit[t];
+    J.over = nullptr;
+    n_pos += (T.pend < B ? T.pend : B) - (J.start < B ? J.start : B);
+    // windows of the task that k_dp5_spec's fast paths cannot take (k_mkdesc)
+    const u32 w0 = J.start >> 5, w1 = ((T.pend < B ? T.pend : B) + 31u) >> 5;
+    u32 generic = 0;
+    for (u32 w = w0 + threadIdx.x; w < w1; w += blockDim.x) generic += winflag[w] == 0 ? 1u : 0u;
+    // (the barrier also means: every wave has read the old exit[t] / exit[t - 1])
+    const bool lean = __syncthreads_count((int)generic) >= P.fix_lean_min ? true : false;
+    const u64 cr0 = __builtin_readcyclecounter();
+    if (lean) {
+      ++n_lean;
+      if (threadIdx.x < 64) {
+        D5IntTab IT;
+        IT.on = false; IT.lo = 0; IT.span = 0;
+        d5_run_job<PROF>(P, J, b, bd, s_wtab, s_xc, s_xl, s_ring, *reinterpret_cast<const uint2 (*)[ZMX_WTAB]>(&s_t1[0][0]), IT);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    } else {
+      d4_run_job<PROF>(P, J, b, bd, s_ring, s_wtab, s_t1, s_t2, s_tab, s_desc, s_tabc, s_xc, s_xl, s_lout);
+    }
+    cyc_run += __builtin_readcyclecounter() - cr0;
+    delta_prev = 0.0;
+    rerun_prev = true;
+  }
+  if (P.debug >= 2 && lead) {
+    printf("fix b %u: %u tasks ok %u state %u values %u level %u tie %u lean %u, %u positions re-run, %llu cycles in all, %llu in re-runs\n", b,
+           t1 - t0, n_ok, n_state, n_values, n_level, n_tie, n_lean, n_pos, (unsigned long long)(__builtin_readcyclecounter() - cyc0),
+           (unsigned long long)cyc_run);
+  }
+  if (lead && P.stats) {
+    atomicAdd(&P.stats[0], t1 - t0);
+    atomicAdd(&P.stats[1], n_ok);
+    atomicAdd(&P.stats[2], n_state);
+    atomicAdd(&P.stats[3], n_level);
+    atomicAdd(&P.stats[4], n_tie);
+    atomicAdd(&P.stats[5], n_pos);
+    atomicAdd(&P.stats[6], n_values);
+    atomicAdd(&P.stats[7], n_lean);
+  }
 }

@@ -133,7 +133,8 @@ struct zmx_tables {
   u32* d_task_off = nullptr;
   u32* d_wg_tasks = nullptr;       // k_dp5_spec's workgroups: four tasks of one block each
   u32 n_wg = 0;
-  d5_u32x4* d_dsc = nullptr;       // per position: the buffer descriptor of its row of weight codes (k_mkdesc)
+  u32* d_wmeta = nullptr;          // per 32-position window: 40 words, what k_dp5_spec needs to fetch its rows (k_mkdesc)
+  u32* d_winroff = nullptr;        // per 32-position window: offset of its first row in the block's codes (k_mkdesc)
   u32* d_winflag = nullptr;        // per 32-position window: fast path possible (k_mkdesc)
   u32* d_win_off = nullptr;        // [nb]
   std::vector<u32> win_off;
@@ -331,7 +332,8 @@ void zmx_tables_free(zmx_ctx* c, zmx_tables* t) {
   PoolFree(c, t->d_tasks);
   PoolFree(c, t->d_task_off);
   PoolFree(c, t->d_wg_tasks);
-  PoolFree(c, t->d_dsc);
+  PoolFree(c, t->d_wmeta);
+  PoolFree(c, t->d_winroff);
   PoolFree(c, t->d_winflag);
   PoolFree(c, t->d_win_off);
   PoolFree(c, t->d_lvl);
@@ -362,7 +364,7 @@ static unsigned EnvU32(const char* name, unsigned dflt, unsigned lo, unsigned hi
 static unsigned SegL() { static const unsigned v = EnvU32("ZOPFLI_AMD_SEG_L", 4096, 0, 1u << 24) & ~63u; return v; }
 // The first task of a block is exact by construction and runs beside the others: let it cover the
 // stretch where the costs double every few thousand positions and no guess would stay in its binade.
-static unsigned SegHead() { static const unsigned v = EnvU32("ZOPFLI_AMD_SEG_HEAD", 32768, 0, 1u << 24) & ~63u; return v; }
+static unsigned SegHead() { static const unsigned v = EnvU32("ZOPFLI_AMD_SEG_HEAD", 16384, 0, 1u << 24) & ~63u; return v; }
 static unsigned SegWarm() { static const unsigned v = (EnvU32("ZOPFLI_AMD_SEG_WARM", 512, 64, 1u << 20) + 63u) & ~63u; return v; }
 
 static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_tables* t, zmx_tables* parent = nullptr) {
@@ -608,7 +610,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
       g_err = "zmx_tables_build: the batch needs more room for its DP edges than ZOPFLI_AMD_CODE_BUDGET_MB allows";
       return kTooLarge;
     }
-    HIPCHK(PoolAlloc(c, &t->d_codes, cur));
+    HIPCHK(PoolAlloc(c, &t->d_codes, cur + 2048));   // (k_dp5_spec stages whole KB: it reads a little past a window's rows)
     HIPCHK(hipMemcpyAsync(t->d_code_base, code_base.data(), nb * sizeof(u64), hipMemcpyHostToDevice, c->stream));
     CodeParams kp;
     kp.blocks = t->d_blocks;
@@ -621,19 +623,19 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     kp.code_base = t->d_code_base;
     if (tile_off[nb]) hipLaunchKernelGGL(k_codes, dim3(tile_off[nb]), dim3(256), 0, c->stream, kp);
     HIPCHK(hipGetLastError());
-    // one descriptor per position and the window flags of k_dp5_spec
-    HIPCHK(PoolAlloc(c, &t->d_dsc, t->total_b));
+    // row lengths, first rows and flags of the 32-position windows of k_dp5_spec
     t->win_off.assign(nb + 1, 0);
-    for (size_t b = 0; b < nb; ++b) t->win_off[b + 1] = t->win_off[b] + (t->bsize[b] + 31) / 32;
+    for (size_t b = 0; b < nb; ++b) t->win_off[b + 1] = t->win_off[b] + (t->bsize[b] + 31) / 32 + 1;   // (+ 1: where the block's rows end)
     HIPCHK(PoolAlloc(c, &t->d_winflag, t->win_off[nb]));
+    HIPCHK(PoolAlloc(c, &t->d_winroff, t->win_off[nb]));
+    HIPCHK(PoolAlloc(c, &t->d_wmeta, (static_cast<size_t>(t->win_off[nb]) + 2) * D5_WM));
     HIPCHK(PoolAlloc(c, &t->d_win_off, nb + 1));
     HIPCHK(hipMemcpyAsync(t->d_win_off, t->win_off.data(), (nb + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
     MkDescParams mp;
     mp.blocks = t->d_blocks;
     mp.dph = t->d_dph;
-    mp.code_base = t->d_code_base;
-    mp.codes = t->d_codes;
-    mp.dsc = t->d_dsc;
+    mp.wmeta = t->d_wmeta;
+    mp.winroff = t->d_winroff;
     mp.win_off = t->d_win_off;
     mp.winflag = t->d_winflag;
     u32 max_b = 1;
@@ -894,10 +896,16 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   cp.wg_tasks = t->d_wg_tasks;
   static const int seg_debug = [] { const char* e = std::getenv("ZOPFLI_AMD_SEG_DEBUG"); return e ? std::atoi(e) : 0; }();
   cp.debug = seg_debug;
+  // (ZOPFLI_AMD_FIX_LEAN: 0 = every serial re-run by the lean one-wave job, large = none; zmx_dp5.h)
+  static const int fix_lean = [] { const char* e = std::getenv("ZOPFLI_AMD_FIX_LEAN"); return e ? std::atoi(e) : 1000000; }();
+  cp.fix_lean_min = fix_lean;
+  static const int int_path = [] { const char* e = std::getenv("ZOPFLI_AMD_INT_PATH"); return e ? std::atoi(e) : 1; }();
+  cp.int_path = int_path;
   cp.redo_count = t->d_redo;
   cp.redo_wg = t->d_redo + 4;
   cp.redo_pass = 0;
-  cp.dsc = t->d_dsc;
+  cp.wmeta = t->d_wmeta;
+  cp.winroff = t->d_winroff;
   cp.winflag = t->d_winflag;
   cp.win_off = t->d_win_off;
   HIPCHK(hipMemsetAsync(t->d_badpos, 0, t->badpos_words * sizeof(u32), c->stream));
@@ -998,15 +1006,20 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
       for (unsigned k = 0; k < ZMX_PROF_N; ++k) a[k] += static_cast<double>(pr[b * ZMX_PROF_N + k]);
     std::fprintf(stderr, "squeeze prof: edges %.2f ms chain %.2f ms trace %.2f ms; chain wave busy %.1f cycles/position, "
                  "%.0f steps, fast %.1f%% of %.0f positions walked (%zu in the blocks); tasks %u accepted %u re-run "
-                 "state %u values %u level %u tie %u (%u positions)\n",
+                 "state %u values %u level %u tie %u (%u positions, %u by the lean job)\n",
                  ksec[0] * 1e3, ksec[1] * 1e3, ksec[2] * 1e3, a[1] / a[4], a[0],
                  100.0 * a[2] / (a[2] + a[3] + 1e-9), a[4], t->total_b, segstats[0], segstats[1], segstats[2],
-                 segstats[6], segstats[3], segstats[4], segstats[5]);
+                 segstats[6], segstats[3], segstats[4], segstats[5], segstats[7]);
     {
       double mx = 0, hd = 0;
       for (size_t b = 0; b < nb; ++b) { mx = std::max(mx, static_cast<double>(pr[b * ZMX_PROF_N + 7])); hd = std::max(hd, static_cast<double>(pr[b * ZMX_PROF_N + 8])); }
-      std::fprintf(stderr, "  k_dp5_spec: longest task %.0f cycles, longest head task %.0f cycles\n", mx, hd);
+      std::fprintf(stderr, "  k_dp5_spec: longest task %.0f cycles, longest head task %.0f cycles; %.1f%% of the positions walked by the integer step (cycles per position there: fetch issue %.1f, fetch wait %.1f, gather + chain %.1f)\n", mx, hd, 100.0 * a[10] / (a[4] + 1e-9), a[11] / (a[10] + 1e-9), a[12] / (a[10] + 1e-9), a[13] / (a[10] + 1e-9));
     }
+    std::fprintf(stderr, "  k_dp5_spec integer windows, cycles per position: class decision %.1f, waiting for the prefetched record and codes %.1f, prefetch issue %.1f\n",
+                 a[20] / (a[10] + 1e-9), a[21] / (a[10] + 1e-9), a[22] / (a[10] + 1e-9));
+    std::fprintf(stderr, "  k_dp5_spec windows: integer %.1f%% of positions at %.0f cycles each, class 1 in doubles %.1f%% at %.0f, class 2 %.1f%% at %.0f, generic %.1f%% at %.0f\n",
+                 100.0 * a[28] / (a[4] + 1e-9), a[24] / (a[28] + 1e-9), 100.0 * a[29] / (a[4] + 1e-9), a[25] / (a[29] + 1e-9),
+                 100.0 * a[30] / (a[4] + 1e-9), a[26] / (a[30] + 1e-9), 100.0 * a[31] / (a[4] + 1e-9), a[27] / (a[31] + 1e-9));
     const char* nm[5] = {"32", "16", "8", "8 (two registers)", "generic"};
     for (int i = 0; i < 5; ++i)
       std::fprintf(stderr, "  path %-18s %5.1f%% of positions, %6.1f cycles/position\n", nm[i], 100.0 * a[6 + 2 * i] / a[4],

@@ -1,7 +1,7 @@
 """Generates tests/golden/vectors.json from the REAL reference (oracle/_ref/libzopfli_ref.so,
 compiled from /root/reference by oracle/Makefile).  Run in the build container:
 
-    python tests/golden/make_golden.py [--big | --big2 | --extra]
+    python tests/golden/make_golden.py [--big | --big2 | --extra | --part]
 
 Each vector: synthetic class / size / seed (zopfli_amd.datagen) or a literal input, the
 ZopfliOptions used, the format, and the SHA-256 + length of the reference's output.
@@ -110,7 +110,33 @@ def big2_cases():
     return cs
 
 
+def part_cases():
+    """ZopfliDeflatePart over ONE block far beyond the reference's 1 MB master blocks (blocksplitting 0: the whole
+    range is one deflate block, deflate.c:811-842) — the 32-bit DP row offsets of round 1 stopped at 16 MB."""
+    return [dict(input=dict(kind="class", cls="T", size=20500000, seed=None), instart=300000, inend=20400000, btype=2,
+                 final=1, numiterations=2, blocksplitting=0)]
+
+
+def run_part(case):
+    import oracle_lib as ol
+    data = make_input(case["input"])
+    out, bp = ol.ref_deflate_part(data, case["instart"], case["inend"], case["btype"], case["final"],
+                                  case["numiterations"], case["blocksplitting"])
+    case = dict(case)
+    case["sha256"] = hashlib.sha256(out).hexdigest()
+    case["outsize"] = len(out)
+    case["bp"] = bp
+    return case
+
+
 def main():
+    if "--part" in sys.argv:
+        done = [run_part(c) for c in part_cases()]
+        path = os.path.join(HERE, "vectors_part.json")
+        with open(path, "w") as f:
+            json.dump(done, f, indent=1)
+        print("wrote", path, len(done), "vectors")
+        return
     big = "--big" in sys.argv
     extra = "--extra" in sys.argv
     big2 = "--big2" in sys.argv

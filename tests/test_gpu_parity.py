@@ -315,6 +315,28 @@ def test_full_size_round_trip(gpu_lib, case):
     assert hashlib.sha256(out).hexdigest() == case["sha256"]
 
 
+def _part_cases():
+    path = os.path.join(os.path.dirname(GOLDEN), "vectors_part.json")
+    if not os.path.exists(path):
+        return []
+    with open(path) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("case", _part_cases(), ids=lambda c: "part-%d" % (c["inend"] - c["instart"]))
+def test_deflate_part_one_20mb_block(gpu_lib, case):
+    """ZopfliDeflatePart with blocksplitting off over 20.1 MB = ONE deflate block with a dictionary before it
+    (deflate.c:811-842): 32-bit DP row offsets stopped round 1 at 16 MB per block.  Against the reference's
+    SHA-256 (tests/golden/vectors_part.json, make_golden.py --part)."""
+    data = _input(case["input"])
+    opt = ZopfliOptions(case["numiterations"], case["blocksplitting"], 15)
+    out, bp = api.deflate_part(data, case["instart"], case["inend"], case["btype"], case["final"], opt, lib=gpu_lib)
+    assert len(out) == case["outsize"] and bp == case["bp"]
+    assert hashlib.sha256(out).hexdigest() == case["sha256"]
+    d = zlib.decompressobj(-15, zdict=data[case["instart"] - 32768:case["instart"]])
+    assert d.decompress(out) == data[case["instart"]:case["inend"]]
+
+
 def test_code_budget_smaller_batches():
     """The DP edges of a batch (two bytes each, k_codes) are capped by ZOPFLI_AMD_CODE_BUDGET_MB; beyond it
     the table build tells the host to come back with fewer master blocks (api.cc RunParts).  20 MB of

@@ -387,7 +387,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     d.reg_off = reg_off;
     d.la_off = la_off;
     const u64 B = d.inend - d.instart, L = d.inend - d.ws;
-    if (B > 16000000ull) return FailMsg("zmx_tables_build: block too large (DP row offsets are 32-bit)");
+    if (B > 0x7fff0000ull) return FailMsg("zmx_tables_build: block too large (positions are 32-bit)");
     t->bsize[b] = static_cast<u32>(B);
     pos_off += B;
     reg_off += (L + 7) & ~7ull;

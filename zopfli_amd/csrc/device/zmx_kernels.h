@@ -363,7 +363,7 @@ __global__ __launch_bounds__(1024) void k_rowscan(RowScanParams P) {
   const u32 tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const u32* rbase = P.recs + bd.pos_off * 8;
   uint2* out = P.dph + bd.pos_off;
-  u32 carry = 0;
+  u64 carry = 0;     // (64 bits: the host refuses a block whose rows do not fit 32-bit offsets, it has to see the real sum)
   for (u32 t0 = 0; t0 < B; t0 += 1024) {
     const u32 jj = t0 + tid;
     const bool act = jj < B;
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(1024) void k_rowscan(RowScanParams P) {
       if (w < wid) woff += v;
       tot += v;
     }
-    if (act) out[jj] = make_uint2(carry + woff + incl - kend, kend | (sflag << 16));
+    if (act) out[jj] = make_uint2((u32)carry + woff + incl - kend, kend | (sflag << 16));
     carry += tot;
     __syncthreads();
   }

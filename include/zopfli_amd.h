@@ -159,6 +159,23 @@ int zmx_store_download_batch(zmx_ctx* ctx, zmx_tables* tables, size_t n, const s
                              const int32_t* slot, const size_t* nsym, uint16_t* const* litlens,
                              uint16_t* const* dists);
 
+/* The deflate bit writer on the device: AddLZ77Data + the end symbol (deflate.c:297-333, :735-737) of a compressed
+ * block whose LZ77 symbols are a whole store of `tables` — only the bits come down, not the symbols.
+ * codes[j * 320 + s] = (Huffman code of symbol s, bit-reversed as the stream wants it) | (code length << 16) for
+ * the 288 litlen symbols, then the 32 distance symbols, of job j (LengthsToSymbols, tree.c:50-69, on the host).
+ * Job j's symbols start at bit `bit_start` of out[j] (the caller puts the block header and the tree in front: those
+ * bits come back zero), out[j] has room for (bit_start + nbits + 7) / 8 bytes; `nbits` = what the caller expects
+ * the symbols and the end symbol to take (from the histogram) and is checked. */
+typedef struct zmx_enc_job {
+  uint32_t block;      /* block of the table set */
+  int32_t slot;        /* which of its two stores */
+  uint32_t nsym;       /* symbols in that store */
+  uint32_t bit_start;
+  uint64_t nbits;
+} zmx_enc_job;
+int zmx_encode_blocks(zmx_ctx* ctx, zmx_tables* tables, size_t njobs, const zmx_enc_job* jobs,
+                      const uint32_t* codes, unsigned char* const* out);
+
 /* Parity probe: the ZopfliFindLongestMatch result for one position of one
  * block, expanded to the reference's sublen[259] convention. */
 int zmx_find_longest_match(zmx_ctx* ctx, zmx_tables* tables, size_t block, size_t pos,

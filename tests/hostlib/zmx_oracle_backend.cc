@@ -135,6 +135,44 @@ int zmx_store_download_batch(zmx_ctx* c, zmx_tables* t, size_t n, const size_t* 
   return 0;
 }
 
+// (CPU stand-in for the device bit writer: the same contract, symbol by symbol)
+int zmx_encode_blocks(zmx_ctx*, zmx_tables* t, size_t njobs, const zmx_enc_job* jobs, const uint32_t* codes,
+                      unsigned char* const* out) {
+  for (size_t j = 0; j < njobs; ++j) {
+    const zmx_enc_job& q = jobs[j];
+    const BlockData& d = t->blocks[q.block];
+    if (q.nsym > d.nsym[q.slot]) return -1;
+    const uint32_t* cd = codes + j * 320;
+    unsigned char* o = out[j];
+    uint64_t pos = q.bit_start;
+    auto put = [&](uint64_t v, unsigned n) {
+      for (unsigned i = 0; i < n; ++i, ++pos) o[pos >> 3] |= static_cast<unsigned char>(((v >> i) & 1u) << (pos & 7));
+    };
+    auto flog2 = [](unsigned v) { return 31 - __builtin_clz(v); };
+    for (size_t i = 0; i < q.nsym; ++i) {
+      const unsigned litlen = d.litlens[q.slot][i], dist = d.dists[q.slot][i];
+      if (dist == 0) {
+        put(cd[litlen] & 0xffffu, cd[litlen] >> 16);
+        continue;
+      }
+      unsigned ls, le;
+      if (litlen < 11) { ls = 254 + litlen; le = 0; }
+      else if (litlen == 258) { ls = 285; le = 0; }
+      else { le = static_cast<unsigned>(flog2(litlen - 3) - 2); ls = 261 + 4 * le + (((litlen - 3) >> le) & 3); }
+      unsigned ds, de;
+      if (dist < 5) { ds = dist - 1; de = 0; }
+      else { const int l = flog2(dist - 1); ds = static_cast<unsigned>(2 * l) + (((dist - 1) >> (l - 1)) & 1); de = static_cast<unsigned>(l - 1); }
+      put(cd[ls] & 0xffffu, cd[ls] >> 16);
+      put((litlen - 3) & ((1u << le) - 1), le);
+      put(cd[288 + ds] & 0xffffu, cd[288 + ds] >> 16);
+      put((dist - 1) & ((1u << de) - 1), de);
+    }
+    put(cd[256] & 0xffffu, cd[256] >> 16);
+    if (pos - q.bit_start != q.nbits) return -1;
+  }
+  return 0;
+}
+
 int zmx_find_longest_match(zmx_ctx*, zmx_tables* t, size_t block, size_t pos, uint16_t* sublen,
                            uint16_t* distance, uint16_t* length) {
   zo_find_longest_match(t->blocks[block].table, pos, sublen, distance, length);

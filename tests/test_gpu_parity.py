@@ -315,6 +315,92 @@ def test_full_size_round_trip(gpu_lib, case):
     assert hashlib.sha256(out).hexdigest() == case["sha256"]
 
 
+def _fixed_codes():
+    """The fixed tree (deflate.c:343-349) as zmx_encode_blocks wants it: bit-reversed canonical code | length << 16."""
+    ll_len = [8] * 144 + [9] * 112 + [7] * 24 + [8] * 8
+    d_len = [5] * 32
+
+    def canon(lens):
+        maxl = max(lens)
+        cnt = [0] * (maxl + 1)
+        for n in lens:
+            cnt[n] += 1
+        cnt[0] = 0
+        nxt, code = [0] * (maxl + 1), 0
+        for b in range(1, maxl + 1):
+            code = (code + cnt[b - 1]) << 1
+            nxt[b] = code
+        out = []
+        for n in lens:
+            c = nxt[n]
+            nxt[n] += 1
+            out.append(int(format(c, "0%db" % n)[::-1], 2) | (n << 16))
+        return out
+    return np.array(canon(ll_len) + canon(d_len), dtype=np.uint32), ll_len, d_len
+
+
+def _py_symbol_bits(ll, dd, codes, bit_start):
+    """AddLZ77Data + end symbol (deflate.c:297-333) in plain Python: (bytes, nbits)."""
+    acc, pos = 0, bit_start
+    codes = [int(c) for c in codes]
+
+    def put(v, n):
+        nonlocal acc, pos
+        acc |= (int(v) & ((1 << n) - 1)) << pos
+        pos += n
+    for litlen, dist in zip(ll.tolist(), dd.tolist()):
+        if dist == 0:
+            put(codes[litlen] & 0xffff, codes[litlen] >> 16)
+            continue
+        if litlen < 11:
+            ls, le = 254 + litlen, 0
+        elif litlen == 258:
+            ls, le = 285, 0
+        else:
+            le = (litlen - 3).bit_length() - 1 - 2
+            ls = 261 + 4 * le + (((litlen - 3) >> le) & 3)
+        if dist < 5:
+            ds, de = dist - 1, 0
+        else:
+            lg = (dist - 1).bit_length() - 1
+            ds, de = 2 * lg + (((dist - 1) >> (lg - 1)) & 1), lg - 1
+        put(codes[ls] & 0xffff, codes[ls] >> 16)
+        put((litlen - 3) & ((1 << le) - 1), le)
+        put(codes[288 + ds] & 0xffff, codes[288 + ds] >> 16)
+        put((dist - 1) & ((1 << de) - 1), de)
+    put(codes[256] & 0xffff, codes[256] >> 16)
+    return acc.to_bytes((pos + 7) // 8, "little"), pos - bit_start
+
+
+@pytest.mark.parametrize("cls", ["T", "M", "Z"])
+def test_device_bit_writer(gpu_ctx, cls):
+    """zmx_encode_blocks (deflate.c:297-333 + the end symbol on the device) against a bit-by-bit Python writer:
+    greedy stores of blocks of ragged sizes (symbol counts around the 2048-symbol tiles), header offsets 0 / 3 / 77,
+    both with one code table per job.  The host-side use of it is covered by every stream test."""
+    data = generate(cls, 300000)
+    gpu_ctx.set_input(data)
+    blocks = [(0, 1), (1, 2500), (2500, 100000), (100000, 100007), (100007, 300000)]
+    t = gpu_ctx.build_tables(blocks)
+    nsym, _ = t.greedy(0)
+    codes, _, _ = _fixed_codes()
+    starts = [0, 3, 77, 31, 64]
+    want, jobs = [], []
+    for b in range(len(blocks)):
+        ll, dd = t.store(b, 0, nsym[b])
+        by, nb = _py_symbol_bits(ll, dd, codes, starts[b])
+        want.append(by)
+        jobs.append((b, 0, int(nsym[b]), starts[b], nb))
+    got = t.encode_blocks(jobs, np.tile(codes, (len(jobs), 1)))
+    for b in range(len(blocks)):
+        assert got[b] == want[b], f"block {b}: {len(got[b])} bytes against {len(want[b])}"
+    # a wrong expectation is reported, not written
+    bad = list(jobs[2])
+    bad[4] += 1
+    with pytest.raises(RuntimeError):
+        t.encode_blocks([tuple(bad)], codes)
+    t.free()
+
+
 def _part_cases():
     path = os.path.join(os.path.dirname(GOLDEN), "vectors_part.json")
     if not os.path.exists(path):

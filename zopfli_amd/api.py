@@ -346,6 +346,26 @@ class Tables:
                         "zmx_store_download")
         return ll[:int(nsym)], dd[:int(nsym)]
 
+    def encode_blocks(self, jobs, codes):
+        """zmx_encode_blocks: jobs = [(block, slot, nsym, bit_start, nbits)], codes = uint32 [njobs, 320]
+        (reversed code | length << 16).  Returns one bytes object per job (header bits zero)."""
+        import numpy as np
+
+        class Job(ctypes.Structure):
+            _fields_ = [("block", ctypes.c_uint32), ("slot", ctypes.c_int32), ("nsym", ctypes.c_uint32),
+                        ("bit_start", ctypes.c_uint32), ("nbits", ctypes.c_uint64)]
+        n = len(jobs)
+        arr = (Job * n)(*[Job(*map(int, j)) for j in jobs])
+        codes = np.ascontiguousarray(codes, dtype=np.uint32).reshape(n, 320)
+        bufs = [np.zeros((int(j[3]) + int(j[4]) + 7) // 8 + 8, dtype=np.uint8) for j in jobs]
+        ptrs = (ctypes.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        fn = self.ctx.lib.zmx_encode_blocks
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        self.ctx._check(fn(self.ctx.handle, self.handle, n, ctypes.cast(arr, ctypes.c_void_p),
+                           codes.ctypes.data_as(ctypes.c_void_p), ctypes.cast(ptrs, ctypes.c_void_p)), "zmx_encode_blocks")
+        return [bytes(b[:(int(j[3]) + int(j[4]) + 7) // 8]) for b, j in zip(bufs, jobs)]
+
     def find_longest_match(self, block, pos):
         import numpy as np
         sub = np.zeros(259, dtype=np.uint16)

@@ -18,6 +18,7 @@
 #include "zmx_match2.h"
 #include "zmx_dp4.h"
 #include "zmx_dp5.h"
+#include "zmx_encode.h"
 #include "zmx_trace.h"
 #include "zmx_greedy.h"
 #include "zopfli_amd.h"
@@ -1087,6 +1088,87 @@ int zmx_store_download_batch(zmx_ctx* c, zmx_tables* t, size_t n, const size_t* 
       ll[k] = static_cast<uint16_t>(s[k] & 0xffffu);
       dd[k] = static_cast<uint16_t>(s[k] >> 16);
     }
+  });
+  return 0;
+}
+
+int zmx_encode_blocks(zmx_ctx* c, zmx_tables* t, size_t njobs, const zmx_enc_job* jobs, const uint32_t* codes,
+                      unsigned char* const* out) {
+  if (njobs == 0) return 0;
+  std::vector<EncJob> ej(njobs);
+  std::vector<u32> tile_job;
+  std::vector<size_t> out_off(njobs + 1, 0);     // in the device / staging buffer, 8-byte aligned
+  for (size_t j = 0; j < njobs; ++j) {
+    const zmx_enc_job& q = jobs[j];
+    if (q.block >= t->nb || (q.slot != 0 && q.slot != 1)) return FailMsg("zmx_encode_blocks: bad block or slot");
+    if (t->store_begin[q.slot][q.block] + q.nsym > t->bsize[q.block]) return FailMsg("zmx_encode_blocks: nsym exceeds the store");
+    out_off[j + 1] = out_off[j] + (((q.bit_start + q.nbits + 7) / 8 + 8 + 7) & ~static_cast<size_t>(7));
+    EncJob& e = ej[j];
+    e.sym_off = t->blocks[q.block].pos_off + t->store_begin[q.slot][q.block];
+    e.out_word = out_off[j] / 4;
+    e.nbits = q.nbits;
+    e.nsym = q.nsym;
+    e.slot = static_cast<u32>(q.slot);
+    e.bit_start = q.bit_start;
+    e.tile0 = static_cast<u32>(tile_job.size());
+    e.code = static_cast<u32>(j);
+    e.pad = 0;
+    const u32 ntiles = q.nsym / ENC_TILE + 1;
+    for (u32 k = 0; k < ntiles; ++k) tile_job.push_back(static_cast<u32>(j));
+  }
+  DeviceGuard dev_guard(c->device);
+  HIPCHK(dev_guard.err);
+  const size_t ntile = tile_job.size(), out_words = out_off[njobs] / 4;
+  EncJob* d_jobs = nullptr;
+  u32 *d_tile_job = nullptr, *d_codes = nullptr, *d_tile_bits = nullptr, *d_out = nullptr, *d_flag = nullptr;
+  u64* d_tile_off = nullptr;
+  HIPCHK(PoolAlloc(c, &d_jobs, njobs));
+  HIPCHK(PoolAlloc(c, &d_tile_job, ntile));
+  HIPCHK(PoolAlloc(c, &d_codes, njobs * 320));
+  HIPCHK(PoolAlloc(c, &d_tile_bits, ntile));
+  HIPCHK(PoolAlloc(c, &d_tile_off, ntile));
+  HIPCHK(PoolAlloc(c, &d_out, out_words + 2));
+  HIPCHK(PoolAlloc(c, &d_flag, 4));
+  HIPCHK(hipMemcpyAsync(d_jobs, ej.data(), njobs * sizeof(EncJob), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_tile_job, tile_job.data(), ntile * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(d_codes, codes, njobs * 320 * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(d_out, 0, (out_words + 2) * sizeof(u32), c->stream));
+  HIPCHK(hipMemsetAsync(d_flag, 0, 4 * sizeof(u32), c->stream));
+  EncParams P;
+  P.jobs = d_jobs;
+  P.tile_job = d_tile_job;
+  P.codes = d_codes;
+  P.store[0] = t->d_store[0];
+  P.store[1] = t->d_store[1];
+  P.tile_bits = d_tile_bits;
+  P.tile_off = d_tile_off;
+  P.out = d_out;
+  P.flags = d_flag;
+  P.njobs = static_cast<u32>(njobs);
+  hipLaunchKernelGGL(k_enc_len, dim3(static_cast<unsigned>(ntile)), dim3(ENC_THREADS), 0, c->stream, P);
+  hipLaunchKernelGGL(k_enc_scan, dim3(static_cast<unsigned>(njobs)), dim3(64), 0, c->stream, P);
+  hipLaunchKernelGGL(k_enc_emit, dim3(static_cast<unsigned>(ntile)), dim3(ENC_THREADS), 0, c->stream, P);
+  HIPCHK(hipGetLastError());
+  // down through the pinned staging buffer, then into the caller's memory on the host workers
+  if (out_words + 1 > c->stage_cap) {
+    if (c->h_stage) HIPCHK(hipHostFree(c->h_stage));
+    c->h_stage = nullptr;
+    c->stage_cap = 0;
+    const size_t cap = out_words + out_words / 4 + 16;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), cap * sizeof(u32), hipHostMallocDefault));
+    c->stage_cap = cap;
+  }
+  u32 flag = 0;
+  HIPCHK(hipMemcpyAsync(c->h_stage, d_out, out_words * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(&flag, d_flag, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  PoolFree(c, d_jobs); PoolFree(c, d_tile_job); PoolFree(c, d_codes); PoolFree(c, d_tile_bits);
+  PoolFree(c, d_tile_off); PoolFree(c, d_out); PoolFree(c, d_flag);
+  if (flag) return FailMsg("zmx_encode_blocks: the symbols of a block take a different number of bits than the histogram says");
+  const unsigned char* stage = reinterpret_cast<const unsigned char*>(c->h_stage);
+  zamd::ParallelFor(njobs, [&](size_t j) {
+    const size_t nby = static_cast<size_t>((jobs[j].bit_start + jobs[j].nbits + 7) / 8);
+    std::memcpy(out[j], stage + out_off[j], nby);
   });
   return 0;
 }

@@ -304,4 +304,40 @@ void EncodeBlock(const Lz77Store& lz77, size_t lstart, size_t lend, int btype, b
   out->AddHuffmanBits(ll_codes[256], ll_lengths[256]);
 }
 
+size_t EncodeBlockHeader(const Histogram& h, int btype, bool final_block, BitWriter* out, size_t* tree_bits,
+                         uint32_t* codes320) {
+  unsigned ll_lengths[kNumLL], d_lengths[kNumD];
+  unsigned ll_codes[kNumLL], d_codes[kNumD];
+  out->AddBits(final_block ? 1 : 0, 1);
+  out->AddBits(static_cast<uint32_t>(btype), 2);
+  if (btype == 1) {
+    FixedTree(ll_lengths, d_lengths);
+  } else {
+    DynamicLengths(h, ll_lengths, d_lengths);
+    size_t unused;
+    const int enc = BestCodeLengthEncoding(ll_lengths, d_lengths, &unused);
+    const size_t before = out->BitCount();
+    EncodeCodeLengths(ll_lengths, d_lengths, enc & 1, enc & 2, enc & 4, out);
+    if (tree_bits) *tree_bits = out->BitCount() - before;
+  }
+  LengthsToSymbols(ll_lengths, kNumLL, 15, ll_codes);
+  LengthsToSymbols(d_lengths, kNumD, 15, d_codes);
+  auto rev = [](unsigned v, unsigned len) {
+    unsigned r = 0;
+    for (unsigned i = 0; i < len; ++i) r |= ((v >> i) & 1u) << (len - 1 - i);
+    return r;
+  };
+  size_t bits = ll_lengths[256];
+  for (int s = 0; s < kNumLL; ++s) {
+    codes320[s] = rev(ll_codes[s], ll_lengths[s]) | (ll_lengths[s] << 16);
+    if (s == 256 || s > 285) continue;
+    bits += h.ll[s] * (ll_lengths[s] + (s > 256 ? static_cast<unsigned>(LengthSymbolExtraBits(s)) : 0u));
+  }
+  for (int s = 0; s < kNumD; ++s) {
+    codes320[kNumLL + s] = rev(d_codes[s], d_lengths[s]) | (d_lengths[s] << 16);
+    if (s < 30) bits += h.d[s] * (d_lengths[s] + static_cast<unsigned>(DistSymbolExtraBits(s)));
+  }
+  return bits;
+}
+
 }  // namespace zamd

@@ -39,4 +39,12 @@ size_t TreeSize(const unsigned* ll_lengths, const unsigned* d_lengths);
 void EncodeBlock(const Lz77Store& lz77, size_t lstart, size_t lend, int btype, bool final_block,
                  BitWriter* out, size_t* tree_bits = nullptr);
 
+// The part of EncodeBlock that does not touch the symbols: the 3 header bits and (btype 2) the tree of a block with
+// histogram `h` (without the end symbol, as above), plus what a symbol writer needs — codes[s] = bit-reversed
+// Huffman code | length << 16 for the 288 litlen symbols and, from 288 on, the 32 distance symbols — and the number
+// of bits the symbols and the end symbol will take (AddLZ77Data, deflate.c:297-333).  The device writes those
+// (zmx_encode_blocks) behind the header.
+size_t EncodeBlockHeader(const Histogram& h, int btype, bool final_block, BitWriter* out, size_t* tree_bits,
+                         uint32_t* codes320);
+
 }  // namespace zamd

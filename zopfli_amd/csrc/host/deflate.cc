@@ -26,9 +26,21 @@ struct FinalBlock {
   long fixed_request = -1;           // index into the batched re-parse
 };
 
+// A compressed block whose symbols the device writes (zmx_encode_blocks): it is a whole block of the optimal batch.
+struct DeviceEncode {
+  size_t chunk = 0;                  // index in the part's chunks
+  size_t block = 0;                  // index in the batched block list
+  std::vector<uint8_t> header;       // the 3 header bits and the tree, from bit 0
+  size_t header_bits = 0;
+  size_t data_bits = 0;              // symbols + end symbol
+  uint32_t codes[320];
+};
+
 struct PartState {
   Part part{};
   std::vector<zmx_block> blocks;     // first-pass deflate blocks (byte ranges)
+  std::vector<size_t> block_sym_end; // symbols of the part's store up to the end of each first-pass block
+  std::vector<DeviceEncode> enc;
   size_t first_block = 0;            // offset into the batched block list
   Lz77Store lz77;                    // optimal parse of the whole part
   std::vector<size_t> splitpoints;   // final split points (symbol indices)
@@ -145,8 +157,15 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
   static const bool trace_phases = std::getenv("ZOPFLI_AMD_PROF") != nullptr;
   const double tp0 = Now();
   std::vector<SymbolRun> runs;
-  rc = Lz77OptimalBatch(ctx, options, all_blocks, &runs, split_tables);
+  // (ZOPFLI_AMD_DEVICE_ENCODE=0: every block's bits on the host, as in round 1)
+  static const bool device_encode = [] { const char* e = std::getenv("ZOPFLI_AMD_DEVICE_ENCODE"); return !e || std::atoi(e) != 0; }();
+  OptimalKeep keep;
+  rc = Lz77OptimalBatch(ctx, options, all_blocks, &runs, split_tables, device_encode ? &keep : nullptr);
   if (rc) return rc;
+  struct TablesGuard {
+    zmx_ctx* ctx; zmx_tables* t;
+    ~TablesGuard() { if (t) zmx_tables_free(ctx, t); }
+  } tables_guard{ctx, keep.tables};
   const double tp1 = Now();
 
   // ---- 3. join the blocks, second split attempt, per-block type costs
@@ -162,6 +181,7 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
       Lz77Store bs = StoreFromRun(runs[s.first_block + i], s.blocks[i].instart);
       totalcost += CalculateBlockSizeAutoType(bs, 0, bs.size());
       s.lz77.Append(bs);
+      s.block_sym_end.push_back(s.lz77.size());
       if (i < npoints) s.splitpoints.push_back(s.lz77.size());
     }
     if (options.blocksplitting && npoints > 1) {  // deflate.c:872-893
@@ -238,18 +258,38 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
         continue;
       }
       size_t tree_bits = 0;
-      int used_btype = 2;
-      if (fixedcost < f.dynamic) {
-        used_btype = 1;
-        if (f.expensive_fixed) {
-          EncodeBlock(fixedstore, 0, fixedstore.size(), 1, final_block, &w);
-        } else {
-          EncodeBlock(s.lz77, f.lstart, f.lend, 1, final_block, &w);
+      const int used_btype = fixedcost < f.dynamic ? 1 : 2;
+      // the symbols of a block that is a whole block of the optimal batch are still on the device: it writes them
+      long dev_block = -1;
+      if (keep.tables && !(used_btype == 1 && f.expensive_fixed)) {
+        for (size_t k = 0; k < s.block_sym_end.size(); ++k) {
+          if (s.block_sym_end[k] == f.lend && (k == 0 ? 0 : s.block_sym_end[k - 1]) == f.lstart) dev_block = static_cast<long>(s.first_block + k);
         }
-      } else {
-        EncodeBlock(s.lz77, f.lstart, f.lend, 2, final_block, &w, &tree_bits);
       }
-      Chunk c = BitsChunk(&w);
+      Chunk c;
+      if (dev_block >= 0) {
+        DeviceEncode e;
+        Histogram h;
+        s.lz77.GetHistogram(f.lstart, f.lend, &h);
+        e.data_bits = EncodeBlockHeader(h, used_btype, final_block, &w, &tree_bits, e.codes);
+        e.header = w.Finish(&e.header_bits);
+        e.block = static_cast<size_t>(dev_block);
+        e.chunk = s.chunks.size();
+        c.kind = Chunk::kBits;
+        c.nbits = e.header_bits + e.data_bits;
+        s.enc.push_back(std::move(e));
+      } else {
+        if (used_btype == 1) {
+          if (f.expensive_fixed) {
+            EncodeBlock(fixedstore, 0, fixedstore.size(), 1, final_block, &w);
+          } else {
+            EncodeBlock(s.lz77, f.lstart, f.lend, 1, final_block, &w);
+          }
+        } else {
+          EncodeBlock(s.lz77, f.lstart, f.lend, 2, final_block, &w, &tree_bits);
+        }
+        c = BitsChunk(&w);
+      }
       c.log_block = true;
       c.log_btype = used_btype;
       c.log_tree_bits = tree_bits;
@@ -258,6 +298,39 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
     }
     if (options.verbose && !s.chunks.empty()) s.chunks.front().log_pre = std::move(s.log);
   });
+  // ---- 5b. the device writes the symbols of its blocks behind the headers
+  {
+    std::vector<zmx_enc_job> jobs;
+    std::vector<uint32_t> codes;
+    std::vector<unsigned char*> outs;
+    std::vector<std::pair<size_t, size_t>> owner;    // (part, index in its enc)
+    for (size_t p = 0; p < np; ++p) {
+      for (size_t k = 0; k < st[p].enc.size(); ++k) {
+        DeviceEncode& e = st[p].enc[k];
+        Chunk& c = st[p].chunks[e.chunk];
+        c.bits.assign((c.nbits + 7) / 8, 0);
+        zmx_enc_job j;
+        j.block = static_cast<uint32_t>(e.block);
+        j.slot = keep.slot[e.block];
+        j.nsym = keep.nsym[e.block];
+        j.bit_start = static_cast<uint32_t>(e.header_bits);
+        j.nbits = e.data_bits;
+        jobs.push_back(j);
+        codes.insert(codes.end(), e.codes, e.codes + 320);
+        outs.push_back(c.bits.data());
+        owner.push_back({p, k});
+      }
+    }
+    if (!jobs.empty()) {
+      rc = zmx_encode_blocks(ctx, keep.tables, jobs.size(), jobs.data(), codes.data(), outs.data());
+      if (rc) return rc;
+      ParallelFor(jobs.size(), [&](size_t i) {
+        const DeviceEncode& e = st[owner[i].first].enc[owner[i].second];
+        uint8_t* b = st[owner[i].first].chunks[e.chunk].bits.data();
+        for (size_t k = 0; k < e.header.size(); ++k) b[k] |= e.header[k];
+      });
+    }
+  }
   ThreadTiming().encode += Now() - t5;
 
   const double tp4 = Now();

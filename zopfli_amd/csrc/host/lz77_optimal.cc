@@ -153,7 +153,7 @@ int Lz77GreedyBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks, std::vec
 }
 
 int Lz77OptimalBatch(zmx_ctx* ctx, const ZopfliOptions& options, const std::vector<zmx_block>& blocks,
-                     std::vector<SymbolRun>* out, zmx_tables* parent) {
+                     std::vector<SymbolRun>* out, zmx_tables* parent, OptimalKeep* keep) {
   const size_t nb = blocks.size();
   out->assign(nb, SymbolRun());
   if (nb == 0) {
@@ -252,9 +252,15 @@ int Lz77OptimalBatch(zmx_ctx* ctx, const ZopfliOptions& options, const std::vect
     std::vector<uint32_t> best_nsym(nb);
     for (size_t b = 0; b < nb; ++b) { best_slot[b] = it[b].best_slot; best_nsym[b] = it[b].best_nsym; }
     if (!rc) rc = DownloadAll(ctx, t, best_slot, best_nsym, out);
+    if (keep && !rc) {
+      keep->tables = t;
+      keep->slot = best_slot;
+      keep->nsym = best_nsym;
+      t = nullptr;
+    }
   }
   ThreadTiming().download += Now() - tdl;
-  zmx_tables_free(ctx, t);
+  if (t) zmx_tables_free(ctx, t);
   return rc;
 }
 

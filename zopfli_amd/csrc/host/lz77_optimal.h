@@ -34,8 +34,15 @@ int Lz77GreedyBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks, std::vec
 // ZopfliLZ77Optimal (squeeze.c:446) for each block: best of `numiterations`
 // cost-model iterations seeded by a greedy parse.  `parent` (optional, consumed): tables of blocks
 // that contain these ones — their match records are reused (zmx_tables_build_from).
+// With `keep`, the table set stays alive (the caller frees it with zmx_tables_free) together with where each block's
+// best parse is: what zmx_encode_blocks needs to write the blocks' bits on the device.
+struct OptimalKeep {
+  zmx_tables* tables = nullptr;
+  std::vector<int32_t> slot;
+  std::vector<uint32_t> nsym;
+};
 int Lz77OptimalBatch(zmx_ctx* ctx, const ZopfliOptions& options, const std::vector<zmx_block>& blocks,
-                     std::vector<SymbolRun>* out, zmx_tables* parent = nullptr);
+                     std::vector<SymbolRun>* out, zmx_tables* parent = nullptr, OptimalKeep* keep = nullptr);
 
 // ZopfliLZ77OptimalFixed (squeeze.c:528): one DP run with the fixed-tree costs.
 int Lz77OptimalFixedBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks,

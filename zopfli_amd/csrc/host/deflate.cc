@@ -159,7 +159,11 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
   std::vector<SymbolRun> runs;
   // (ZOPFLI_AMD_DEVICE_ENCODE=0: every block's bits on the host, as in round 1)
   static const bool device_encode = [] { const char* e = std::getenv("ZOPFLI_AMD_DEVICE_ENCODE"); return !e || std::atoi(e) != 0; }();
+  // Without block splitting a part is one block and nothing below needs its symbols on the host: sizes and trees
+  // come from the histogram of the best parse, the bits from the device.
+  const bool no_symbols = device_encode && !options.blocksplitting && all_blocks.size() == np;
   OptimalKeep keep;
+  keep.skip_download = no_symbols;
   rc = Lz77OptimalBatch(ctx, options, all_blocks, &runs, split_tables, device_encode ? &keep : nullptr);
   if (rc) return rc;
   struct TablesGuard {
@@ -172,6 +176,31 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
   std::vector<zmx_block> fixed_requests;
   std::vector<std::pair<size_t, size_t>> fixed_owner;  // (part, final index)
   const double t3 = Now();
+  auto block_hist = [&](size_t block) {
+    Histogram h;
+    const uint32_t* c = &keep.hist[block * ZMX_HIST];
+    for (int k = 0; k < kNumLL; ++k) h.ll[k] = c[k];
+    for (int k = 0; k < kNumD; ++k) h.d[k] = c[kNumLL + k];
+    return h;
+  };
+  if (no_symbols) {
+    ParallelForWide(np, [&](size_t p) {   // one block per part; AddLZ77BlockAutoType (deflate.c:747-762) on its histogram
+      PartState& s = st[p];
+      s.log += runs[s.first_block].log;
+      const size_t nsym = keep.nsym[s.first_block];
+      const size_t length = s.blocks[0].inend - s.blocks[0].instart;
+      const Histogram h = block_hist(s.first_block);
+      FinalBlock f;
+      f.lstart = 0;
+      f.lend = nsym;
+      f.stored = static_cast<double>((length / 65535 + (length % 65535 ? 1 : 0)) * 5 * 8 + length * 8);   // deflate.c:591-597
+      f.fixed = BlockSizeFromHistogram(h, 1);
+      f.dynamic = BlockSizeFromHistogram(h, 2);
+      f.expensive_fixed = nsym < 1000 || f.fixed <= f.dynamic * 1.1;
+      s.block_sym_end.push_back(nsym);
+      s.finals.push_back(f);
+    });
+  } else
   ParallelForWide(np, [&](size_t p) {
     PartState& s = st[p];
     const size_t npoints = s.blocks.size() - 1;
@@ -213,8 +242,8 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
     for (size_t i = 0; i < st[p].finals.size(); ++i) {
       FinalBlock& f = st[p].finals[i];
       if (f.lstart == f.lend || !f.expensive_fixed) continue;
-      const size_t instart = st[p].lz77.pos(f.lstart);
-      const size_t inend = instart + st[p].lz77.ByteRange(f.lstart, f.lend);
+      const size_t instart = no_symbols ? st[p].blocks[0].instart : st[p].lz77.pos(f.lstart);
+      const size_t inend = no_symbols ? st[p].blocks[0].inend : instart + st[p].lz77.ByteRange(f.lstart, f.lend);
       f.fixed_request = static_cast<long>(fixed_requests.size());
       fixed_requests.push_back({instart, inend});
     }
@@ -251,8 +280,8 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
       if (f.stored < fixedcost && f.stored < f.dynamic) {
         Chunk c;
         c.kind = Chunk::kStored;
-        c.start = s.lz77.pos(f.lstart);
-        c.end = c.start + s.lz77.ByteRange(f.lstart, f.lend);
+        c.start = no_symbols ? s.blocks[0].instart : s.lz77.pos(f.lstart);
+        c.end = no_symbols ? s.blocks[0].inend : c.start + s.lz77.ByteRange(f.lstart, f.lend);
         c.final_block = final_block;
         s.chunks.push_back(std::move(c));
         continue;
@@ -270,7 +299,8 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
       if (dev_block >= 0) {
         DeviceEncode e;
         Histogram h;
-        s.lz77.GetHistogram(f.lstart, f.lend, &h);
+        if (no_symbols) h = block_hist(s.first_block);
+        else s.lz77.GetHistogram(f.lstart, f.lend, &h);
         e.data_bits = EncodeBlockHeader(h, used_btype, final_block, &w, &tree_bits, e.codes);
         e.header = w.Finish(&e.header_bits);
         e.block = static_cast<size_t>(dev_block);
@@ -293,7 +323,7 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
       c.log_block = true;
       c.log_btype = used_btype;
       c.log_tree_bits = tree_bits;
-      c.log_unc = s.lz77.ByteRange(f.lstart, f.lend);
+      c.log_unc = no_symbols ? s.blocks[0].inend - s.blocks[0].instart : s.lz77.ByteRange(f.lstart, f.lend);
       s.chunks.push_back(std::move(c));
     }
     if (options.verbose && !s.chunks.empty()) s.chunks.front().log_pre = std::move(s.log);

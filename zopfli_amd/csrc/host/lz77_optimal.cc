@@ -168,7 +168,7 @@ int Lz77OptimalBatch(zmx_ctx* ctx, const ZopfliOptions& options, const std::vect
   double t1 = Now();
   ThreadTiming().tables += t1 - t0;
 
-  std::vector<uint32_t> nsym(nb), hist(nb * ZMX_HIST);
+  std::vector<uint32_t> nsym(nb), hist(nb * ZMX_HIST), best_hist(keep ? nb * ZMX_HIST : 0);
   std::vector<BlockIter> it(nb);
   std::vector<double> cost(nb * ZMX_HIST), mincost(nb);
   std::vector<int32_t> slot(nb, 0);
@@ -211,6 +211,7 @@ int Lz77OptimalBatch(zmx_ctx* ctx, const ZopfliOptions& options, const std::vect
         (*out)[b].log += line;   // (printed in the reference's order when the stream is assembled)
       }
       if (c < s.bestcost) {
+        if (keep) std::memcpy(&best_hist[b * ZMX_HIST], h, sizeof(uint32_t) * ZMX_HIST);
         s.best_slot = slot[b];
         s.best_nsym = nsym[b];
         s.beststats = s.stats;
@@ -251,11 +252,12 @@ int Lz77OptimalBatch(zmx_ctx* ctx, const ZopfliOptions& options, const std::vect
     std::vector<int32_t> best_slot(nb);
     std::vector<uint32_t> best_nsym(nb);
     for (size_t b = 0; b < nb; ++b) { best_slot[b] = it[b].best_slot; best_nsym[b] = it[b].best_nsym; }
-    if (!rc) rc = DownloadAll(ctx, t, best_slot, best_nsym, out);
+    if (!rc && !(keep && keep->skip_download)) rc = DownloadAll(ctx, t, best_slot, best_nsym, out);
     if (keep && !rc) {
       keep->tables = t;
       keep->slot = best_slot;
       keep->nsym = best_nsym;
+      keep->hist.swap(best_hist);
       t = nullptr;
     }
   }

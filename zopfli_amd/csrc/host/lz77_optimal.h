@@ -37,9 +37,11 @@ int Lz77GreedyBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks, std::vec
 // With `keep`, the table set stays alive (the caller frees it with zmx_tables_free) together with where each block's
 // best parse is: what zmx_encode_blocks needs to write the blocks' bits on the device.
 struct OptimalKeep {
+  bool skip_download = false;      // in: the caller does not need the symbols on the host (`out` only gets the logs)
   zmx_tables* tables = nullptr;
   std::vector<int32_t> slot;
   std::vector<uint32_t> nsym;
+  std::vector<uint32_t> hist;      // [blocks][ZMX_HIST] histogram of each block's best parse (no end symbol)
 };
 int Lz77OptimalBatch(zmx_ctx* ctx, const ZopfliOptions& options, const std::vector<zmx_block>& blocks,
                      std::vector<SymbolRun>* out, zmx_tables* parent = nullptr, OptimalKeep* keep = nullptr);

@@ -159,6 +159,14 @@ int zmx_store_download_batch(zmx_ctx* ctx, zmx_tables* tables, size_t n, const s
                              const int32_t* slot, const size_t* nsym, uint16_t* const* litlens,
                              uint16_t* const* dists);
 
+/* ZopfliVerifyLenDist (lz77.c:270-295) over whole stores, on the device: every literal is the input byte at its
+ * position, every (length, distance) is in range and copies equal bytes, and the symbols cover the block exactly.
+ * The reference asserts this for each symbol it stores (lz77.c:115, debug builds); here it is a separate pass,
+ * run by the Zopfli* entry points on every parse they keep when ZOPFLI_AMD_VERIFY is set.  Returns 0 or fails
+ * with the first offending block and symbol in zmx_last_error. */
+int zmx_verify_stores(zmx_ctx* ctx, zmx_tables* tables, size_t n, const size_t* block, const int32_t* slot,
+                      const size_t* nsym);
+
 /* The deflate bit writer on the device: AddLZ77Data + the end symbol (deflate.c:297-333, :735-737) of a compressed
  * block whose LZ77 symbols are a whole store of `tables` — only the bits come down, not the symbols.
  * codes[j * 320 + s] = (Huffman code of symbol s, bit-reversed as the stream wants it) | (code length << 16) for

@@ -135,6 +135,29 @@ int zmx_store_download_batch(zmx_ctx* c, zmx_tables* t, size_t n, const size_t* 
   return 0;
 }
 
+// (CPU stand-in for the device's verify pass)
+int zmx_verify_stores(zmx_ctx* c, zmx_tables* t, size_t n, const size_t* block, const int32_t* slot, const size_t* nsym) {
+  for (size_t i = 0; i < n; ++i) {
+    const BlockData& d = t->blocks[block[i]];
+    size_t pos = d.blk.instart;
+    for (size_t k = 0; k < nsym[i]; ++k) {
+      const unsigned litlen = d.litlens[slot[i]][k], dist = d.dists[slot[i]][k];
+      if (dist == 0) {
+        if (pos >= d.blk.inend || c->input[pos] != litlen) { g_err = "zmx_verify_stores: literal"; return -1; }
+        pos += 1;
+      } else {
+        if (litlen < 3 || litlen > 258 || dist > pos || pos + litlen > d.blk.inend) { g_err = "zmx_verify_stores: range"; return -1; }
+        for (unsigned q = 0; q < litlen; ++q) {
+          if (c->input[pos + q] != c->input[pos + q - dist]) { g_err = "zmx_verify_stores: bytes"; return -1; }
+        }
+        pos += litlen;
+      }
+    }
+    if (pos != d.blk.inend) { g_err = "zmx_verify_stores: coverage"; return -1; }
+  }
+  return 0;
+}
+
 // (CPU stand-in for the device bit writer: the same contract, symbol by symbol)
 int zmx_encode_blocks(zmx_ctx*, zmx_tables* t, size_t njobs, const zmx_enc_job* jobs, const uint32_t* codes,
                       unsigned char* const* out) {

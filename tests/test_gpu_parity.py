@@ -401,6 +401,40 @@ def test_device_bit_writer(gpu_ctx, cls):
     t.free()
 
 
+def test_verify_pass(gpu_ctx):
+    """ZopfliVerifyLenDist on the device (lz77.c:270-295): a greedy and an optimal parse pass; the same symbols read
+    against another input, or one symbol short, do not."""
+    data = generate("M", 200000)
+    gpu_ctx.set_input(data)
+    blocks = [(0, 70000), (70000, 200000)]
+    t = gpu_ctx.build_tables(blocks)
+    nsym, hist = t.greedy(0)
+    t.verify_stores([0, 1], [0, 0], nsym)
+    with pytest.raises(RuntimeError, match="add up"):
+        t.verify_stores([1], [0], [int(nsym[1]) - 1])
+    cost = np.zeros((2, 320))
+    mincost = np.zeros(2)
+    for b in range(2):
+        ll, d = ol.entropy_costs(hist[b])
+        cost[b, :288], cost[b, 288:] = ll, d
+        mincost[b] = ol.model_min_cost(ll, d)
+    nsym2, _ = t.squeeze_run(cost, mincost, np.ones(2, dtype=np.int32))
+    t.verify_stores([0, 1], [1, 1], nsym2)
+    t.free()
+    # the library's own use of it: same bytes with the pass switched on
+    import subprocess
+    import sys
+    code = ("import sys, hashlib\nsys.path.insert(0, %r)\nfrom zopfli_amd import ZopfliOptions, api, generate\n"
+            "print(hashlib.sha256(api.compress(generate('M', 1200000), 0, ZopfliOptions(3))).hexdigest())\n"
+            % os.path.dirname(os.path.dirname(__file__)))
+    outs = []
+    for v in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZOPFLI_AMD_VERIFY=v), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip())
+    assert outs[0] == outs[1]
+
+
 def _part_cases():
     path = os.path.join(os.path.dirname(GOLDEN), "vectors_part.json")
     if not os.path.exists(path):

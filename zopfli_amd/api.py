@@ -346,6 +346,18 @@ class Tables:
                         "zmx_store_download")
         return ll[:int(nsym)], dd[:int(nsym)]
 
+    def verify_stores(self, blocks, slots, nsyms):
+        """zmx_verify_stores: raises RuntimeError naming the first symbol that does not stand for the input's bytes."""
+        n = len(blocks)
+        fn = self.ctx.lib.zmx_verify_stores
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        b = (ctypes.c_size_t * n)(*map(int, blocks))
+        s = (ctypes.c_int32 * n)(*map(int, slots))
+        k = (ctypes.c_size_t * n)(*map(int, nsyms))
+        self.ctx._check(fn(self.ctx.handle, self.handle, n, ctypes.cast(b, ctypes.c_void_p), ctypes.cast(s, ctypes.c_void_p),
+                           ctypes.cast(k, ctypes.c_void_p)), "zmx_verify_stores")
+
     def encode_blocks(self, jobs, codes):
         """zmx_encode_blocks: jobs = [(block, slot, nsym, bit_start, nbits)], codes = uint32 [njobs, 320]
         (reversed code | length << 16).  Returns one bytes object per job (header bits zero)."""

@@ -176,3 +176,65 @@ __global__ __launch_bounds__(ENC_THREADS) void k_enc_emit(EncParams P) {
     else out[w] = x;
   }
 }
+
+// ---------------------------------------------------------------------------------------------
+// ZopfliVerifyLenDist (lz77.c:270-295; the reference asserts it for every symbol it stores, lz77.c:115) as a
+// debug pass over whole stores (ZOPFLI_AMD_VERIFY): one workgroup per job walks its store 256 symbols at a
+// time, a scan of the symbols' lengths gives their positions, every thread compares its match byte by byte.
+// ---------------------------------------------------------------------------------------------
+struct VerifyJob {
+  u64 sym_off;      // first symbol in store[slot]
+  u64 instart;      // first byte of the block
+  u64 inend;
+  u32 nsym;
+  u32 slot;
+};
+struct VerifyParams {
+  const VerifyJob* jobs;
+  const u8* in;
+  const u32* store[2];
+  u32* bad;         // [jobs][2]: 1 + index of a symbol that fails, and what was wrong (1: length / distance out of
+                    // range, 2: bytes differ, 3: the symbols do not add up to the block)
+};
+
+__global__ __launch_bounds__(256) void k_verify(VerifyParams P) {
+  __shared__ u32 s_sum[4];
+  const VerifyJob J = P.jobs[blockIdx.x];
+  const u32* st = P.store[J.slot] + J.sym_off;
+  u64 base = J.instart;
+  for (u32 i0 = 0; i0 < J.nsym; i0 += 256) {
+    const u32 i = i0 + threadIdx.x;
+    u32 litlen = 0, dist = 0, len = 0;
+    if (i < J.nsym) {
+      const u32 s = st[i];
+      litlen = s & 0xffffu;
+      dist = s >> 16;
+      len = dist ? litlen : 1u;
+    }
+    const u32 incl = wave_scan_add(len);
+    if ((threadIdx.x & 63) == 63) s_sum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    u64 pos = base + incl - len;
+    u32 tot = 0;
+    for (u32 w = 0; w < 4; ++w) {
+      if (w < (threadIdx.x >> 6)) pos += s_sum[w];
+      tot += s_sum[w];
+    }
+    if (i < J.nsym) {
+      u32 why = 0;
+      if (dist == 0) {
+        if (litlen > 255 || pos >= J.inend || P.in[pos] != litlen) why = litlen > 255 ? 1u : 2u;
+      } else if (litlen < 3 || litlen > 258 || dist > 32768 || dist > pos || pos + litlen > J.inend) {
+        why = 1;
+      } else {
+        for (u32 k = 0; k < litlen; ++k) {
+          if (P.in[pos + k] != P.in[pos + k - dist]) { why = 2; break; }
+        }
+      }
+      if (why) { atomicMax(&P.bad[2 * blockIdx.x], i + 1); P.bad[2 * blockIdx.x + 1] = why; }
+    }
+    base += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && base != J.inend) { atomicMax(&P.bad[2 * blockIdx.x], J.nsym + 1); P.bad[2 * blockIdx.x + 1] = 3; }
+}

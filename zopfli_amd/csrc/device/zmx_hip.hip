@@ -1092,6 +1092,50 @@ int zmx_store_download_batch(zmx_ctx* c, zmx_tables* t, size_t n, const size_t* 
   return 0;
 }
 
+int zmx_verify_stores(zmx_ctx* c, zmx_tables* t, size_t n, const size_t* block, const int32_t* slot, const size_t* nsym) {
+  if (n == 0) return 0;
+  std::vector<VerifyJob> vj(n);
+  for (size_t i = 0; i < n; ++i) {
+    if (block[i] >= t->nb || (slot[i] != 0 && slot[i] != 1)) return FailMsg("zmx_verify_stores: bad block or slot");
+    if (t->store_begin[slot[i]][block[i]] + nsym[i] > t->bsize[block[i]]) return FailMsg("zmx_verify_stores: nsym exceeds the store");
+    vj[i].sym_off = t->blocks[block[i]].pos_off + t->store_begin[slot[i]][block[i]];
+    vj[i].instart = t->blocks[block[i]].instart;
+    vj[i].inend = t->blocks[block[i]].inend;
+    vj[i].nsym = static_cast<u32>(nsym[i]);
+    vj[i].slot = static_cast<u32>(slot[i]);
+  }
+  DeviceGuard dev_guard(c->device);
+  HIPCHK(dev_guard.err);
+  VerifyJob* d_jobs = nullptr;
+  u32* d_bad = nullptr;
+  HIPCHK(PoolAlloc(c, &d_jobs, n));
+  HIPCHK(PoolAlloc(c, &d_bad, 2 * n));
+  HIPCHK(hipMemcpyAsync(d_jobs, vj.data(), n * sizeof(VerifyJob), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(d_bad, 0, 2 * n * sizeof(u32), c->stream));
+  VerifyParams P;
+  P.jobs = d_jobs;
+  P.in = c->d_in;
+  P.store[0] = t->d_store[0];
+  P.store[1] = t->d_store[1];
+  P.bad = d_bad;
+  hipLaunchKernelGGL(k_verify, dim3(static_cast<unsigned>(n)), dim3(256), 0, c->stream, P);
+  HIPCHK(hipGetLastError());
+  std::vector<u32> bad(2 * n);
+  HIPCHK(hipMemcpyAsync(bad.data(), d_bad, 2 * n * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  PoolFree(c, d_jobs);
+  PoolFree(c, d_bad);
+  for (size_t i = 0; i < n; ++i) {
+    if (bad[2 * i] == 0) continue;
+    static const char* why[4] = {"", "length or distance out of range", "the bytes it stands for are not the input's", "the symbols do not add up to the block"};
+    char msg[200];
+    std::snprintf(msg, sizeof(msg), "zmx_verify_stores: block %zu, symbol %u: %s", block[i], bad[2 * i] - 1, why[bad[2 * i + 1] & 3]);
+    g_err = msg;
+    return -1;
+  }
+  return 0;
+}
+
 int zmx_encode_blocks(zmx_ctx* c, zmx_tables* t, size_t njobs, const zmx_enc_job* jobs, const uint32_t* codes,
                       unsigned char* const* out) {
   if (njobs == 0) return 0;

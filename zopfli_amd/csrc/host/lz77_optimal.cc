@@ -2,6 +2,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "block_cost.h"
@@ -126,6 +127,17 @@ int DownloadAll(zmx_ctx* ctx, zmx_tables* t, const std::vector<int32_t>& slot, c
 
 }  // namespace
 
+// ZOPFLI_AMD_VERIFY: ZopfliVerifyLenDist (lz77.c:270-295) on the device for every parse that is kept
+static bool VerifyWanted() {
+  static const bool v = [] { const char* e = std::getenv("ZOPFLI_AMD_VERIFY"); return e && std::atoi(e) != 0; }();
+  return v;
+}
+static int VerifyAll(zmx_ctx* ctx, zmx_tables* t, const std::vector<int32_t>& slot, const std::vector<uint32_t>& nsym) {
+  std::vector<size_t> block(slot.size()), n(nsym.begin(), nsym.end());
+  for (size_t b = 0; b < block.size(); ++b) block[b] = b;
+  return zmx_verify_stores(ctx, t, block.size(), block.data(), slot.data(), n.data());
+}
+
 Timing& ThreadTiming() {
   static thread_local Timing t;
   return t;
@@ -145,6 +157,7 @@ int Lz77GreedyBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks, std::vec
   ThreadTiming().tables += t1 - t0;
   std::vector<uint32_t> nsym(nb), hist(nb * ZMX_HIST);
   rc = zmx_lz77_greedy(ctx, t, 0, nsym.data(), hist.data());
+  if (!rc && VerifyWanted()) rc = VerifyAll(ctx, t, std::vector<int32_t>(nb, 0), nsym);
   if (!rc) rc = DownloadAll(ctx, t, std::vector<int32_t>(nb, 0), nsym, out);
   ThreadTiming().greedy += Now() - t1;
   if (keep && !rc) *keep = t;
@@ -252,6 +265,7 @@ int Lz77OptimalBatch(zmx_ctx* ctx, const ZopfliOptions& options, const std::vect
     std::vector<int32_t> best_slot(nb);
     std::vector<uint32_t> best_nsym(nb);
     for (size_t b = 0; b < nb; ++b) { best_slot[b] = it[b].best_slot; best_nsym[b] = it[b].best_nsym; }
+    if (!rc && VerifyWanted()) rc = VerifyAll(ctx, t, best_slot, best_nsym);
     if (!rc && !(keep && keep->skip_download)) rc = DownloadAll(ctx, t, best_slot, best_nsym, out);
     if (keep && !rc) {
       keep->tables = t;
@@ -291,6 +305,7 @@ int Lz77OptimalFixedBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks, st
     mincost[b] = mc;
   }
   rc = zmx_squeeze_run(ctx, t, cost.data(), mincost.data(), slot.data(), nsym.data(), hist.data());
+  if (!rc && VerifyWanted()) rc = VerifyAll(ctx, t, std::vector<int32_t>(nb, 0), nsym);
   if (!rc) rc = DownloadAll(ctx, t, std::vector<int32_t>(nb, 0), nsym, out);
   ThreadTiming().squeeze += Now() - t1;
   zmx_tables_free(ctx, t);

@@ -176,14 +176,30 @@ __global__ __launch_bounds__(64) void k_chain(const u8* __restrict__ in, const B
 
   for (u64 t0 = w0; t0 < e1; t0 += CH_TILE) {
     const u32 tn = (u32)((e1 - t0 < CH_TILE) ? e1 - t0 : CH_TILE);
-    for (u32 i = lane; i < tn; i += 64) {
-      const u64 k = t0 + i;
-      const u32 b0 = base[k];
-      const u32 b1 = k + 1 < L ? base[k + 1] : 0;
-      const u32 b2 = k + 2 < L ? base[k + 2] : 0;
-      u32 v = ((b0 << 10) ^ (b1 << 5) ^ b2) & 32767u;  // hash.c:96-98, three rolling updates
-      if (chain) v ^= ((u32)same[k] - 3u) & 255u;      // hash.c:129
-      keys[i] = (u16)v;
+    {
+      // The tile's keys: lane l takes positions 16 l .. 16 l + 15 with all its loads in flight at once (18 bytes,
+      // 16 run lengths).  One position per lane and round was 16 rounds of dependent loads per tile, and with the
+      // two waves a CU holds (64 KB head table each) nothing hid them: most of the kernel's time.
+      const u32 i0 = 16u * lane;
+      u32 by[18];
+      u32 sm[16];
+#pragma unroll
+      for (u32 q = 0; q < 18; ++q) {
+        const u64 k = t0 + i0 + q;
+        by[q] = (i0 < tn && k < L) ? (u32)base[k] : 0u;          // (zero past the block end: hash.c:100-104's caller)
+      }
+      if (chain) {
+#pragma unroll
+        for (u32 q = 0; q < 16; ++q) sm[q] = (i0 + q < tn) ? (u32)same[t0 + i0 + q] : 0u;
+      }
+#pragma unroll
+      for (u32 q = 0; q < 16; ++q) {
+        if (i0 + q < tn) {
+          u32 v = ((by[q] << 10) ^ (by[q + 1] << 5) ^ by[q + 2]) & 32767u;   // hash.c:96-98, three rolling updates
+          if (chain) v ^= (sm[q] - 3u) & 255u;                                // hash.c:129
+          keys[i0 + q] = (u16)v;
+        }
+      }
     }
     __syncthreads();
     const u32 cur0 = (u32)(t0 - w0);

@@ -630,6 +630,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
 // One workgroup = four waves = up to four tasks of ONE block (P.wg_tasks), sharing the run's weight
 // table in LDS; after the table is in place the waves go their own ways.
 #define D5_WG 4u
+#define FIX_CH 256u       // tasks whose summaries k_dp4_fix holds in LDS at a time
 template <bool PROF, int WAVES>
 __global__ __launch_bounds__(64 * D5_WG, WAVES) void k_dp5_spec(Dp4Params P) {
   __shared__ __align__(16) double s_wtab[ZMX_WTAB];
@@ -733,17 +734,37 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
   const u32* winflag = P.winflag + P.win_off[b];
   const u64 cyc0 = __builtin_readcyclecounter();
   u64 cyc_run = 0;
-  for (u32 t = t0 + 1; t < t1; ++t) {
+  // The walk reads a few words per task and almost always just accepts it: with a dependent global load or two
+  // per task, 240 tasks a block, the walk — not the re-runs — was most of this kernel's 0.75 ms.  So: the tasks'
+  // summaries come into LDS FIX_CH at a time in one sweep, and what an accepted task leaves to do (its overshoot
+  // cells into length_array, its level for the next run) is done for the whole chunk afterwards, all threads at once.
+  __shared__ double s_ck_d[FIX_CH], s_dl[FIX_CH];
+  __shared__ float s_ck_vmin[FIX_CH], s_vmax[FIX_CH];
+  __shared__ u32 s_ck_match[FIX_CH], s_xbase[FIX_CH], s_pend[FIX_CH], s_acc[FIX_CH];
+  for (u32 c0 = t0 + 1; c0 < t1; c0 += FIX_CH) {
+  const u32 cn = t1 - c0 < FIX_CH ? t1 - c0 : FIX_CH;
+  for (u32 i = threadIdx.x; i < cn; i += blockDim.x) {
+    const SegCheck k = P.chk[c0 + i];
+    s_ck_d[i] = k.d; s_ck_vmin[i] = k.vmin; s_ck_match[i] = k.match;
+    s_vmax[i] = P.exit[c0 + i].vmax;
+    s_xbase[i] = P.exit[c0 + i].base;
+    s_pend[i] = P.tasks[c0 + i].pend;
+    s_acc[i] = 0;
+    s_dl[i] = 0.0;
+  }
+  __syncthreads();
+  for (u32 t = c0; t < c0 + cn; ++t) {
+    const u32 ti = t - c0;
     SegCheck ck;
     if (rerun_prev) ck = d4_check(&P.exit[t - 1], &P.entry[t], lane);   // every wave computes the same
-    else ck = P.chk[t];
+    else { ck.d = s_ck_d[ti]; ck.vmin = s_ck_vmin[ti]; ck.match = s_ck_match[ti]; }
     const double delta = delta_prev + ck.d;
     // the guess to start the next run of this task from
-    if (lead) P.lvl[t] = (float)((double)P.lvl[t] + delta);
+    if (lead) s_dl[ti] = delta;
     bool ok = ck.match == 1;
     u32 why = 0;
     if (ok) {
-      why = d4_accept(ck.vmin, (double)P.exit[t].vmax, delta, wmax, tiemask);
+      why = d4_accept(ck.vmin, (double)s_vmax[ti], delta, wmax, tiemask);
       ok = why == 0;
     }
     if (P.debug == 1 && lead) {
@@ -752,7 +773,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
              P.entry[t].base, P.exit[t - 1].base);
     }
     if (ok) {
-      d4_copy_over(P, t, B, la_block);
+      if (lead) s_acc[ti] = 1;
       delta_prev = delta;
       rerun_prev = false;
       ++n_ok;
@@ -799,6 +820,19 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
     cyc_run += __builtin_readcyclecounter() - cr0;
     delta_prev = 0.0;
     rerun_prev = true;
+  }
+  __syncthreads();
+  // the chunk's accepted tasks: their cells beyond pend (d4_copy_over), one task per wave at a time; and every
+  // task's level for the next run
+  for (u32 i = threadIdx.x >> 6; i < cn; i += blockDim.x >> 6) {
+    if (!s_acc[i]) continue;
+    const u32 pend = s_pend[i], stop = s_xbase[i];
+    if (pend > B) continue;                   // the last task of the block runs to the end
+    const u16* over = P.over + (u64)(c0 + i) * SEG_OVER;
+    for (u32 k = lane; pend + k < stop && pend + k <= B; k += 64) la_block[pend + k] = over[k];
+  }
+  for (u32 i = threadIdx.x; i < cn; i += blockDim.x) P.lvl[c0 + i] = (float)((double)P.lvl[c0 + i] + s_dl[i]);
+  __syncthreads();
   }
   if (P.debug >= 2 && lead) {
     printf("fix b %u: %u tasks ok %u state %u values %u level %u tie %u lean %u, %u positions re-run, %llu cycles in all, %llu in re-runs\n", b,

@@ -365,7 +365,7 @@ static unsigned EnvU32(const char* name, unsigned dflt, unsigned lo, unsigned hi
 static unsigned SegL() { static const unsigned v = EnvU32("ZOPFLI_AMD_SEG_L", 4096, 0, 1u << 24) & ~63u; return v; }
 // The first task of a block is exact by construction and runs beside the others: let it cover the
 // stretch where the costs double every few thousand positions and no guess would stay in its binade.
-static unsigned SegHead() { static const unsigned v = EnvU32("ZOPFLI_AMD_SEG_HEAD", 16384, 0, 1u << 24) & ~63u; return v; }
+static unsigned SegHead() { static const unsigned v = EnvU32("ZOPFLI_AMD_SEG_HEAD", 4096, 0, 1u << 24) & ~63u; return v; }
 static unsigned SegWarm() { static const unsigned v = (EnvU32("ZOPFLI_AMD_SEG_WARM", 512, 64, 1u << 20) + 63u) & ~63u; return v; }
 
 static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_tables* t, zmx_tables* parent = nullptr) {

@@ -192,6 +192,20 @@ hipError_t PoolAlloc(zmx_ctx* c, T** p, size_t n) {
   return PoolAllocBytes(c, reinterpret_cast<void**>(p), (n ? n : 1) * sizeof(T));
 }
 
+// Temporary arrays of one call: back to the pool when the call returns, whichever way (HIPCHK returns early).
+struct PoolScope {
+  zmx_ctx* c;
+  std::vector<void*> held;
+  explicit PoolScope(zmx_ctx* ctx) : c(ctx) {}
+  ~PoolScope();
+  template <typename T>
+  hipError_t Alloc(T** p, size_t n) {
+    const hipError_t e = PoolAlloc(c, p, n);
+    if (e == hipSuccess) held.push_back(*p);
+    return e;
+  }
+};
+
 void PoolFree(zmx_ctx* c, void* p) {
   if (!p) return;
   if (c) {
@@ -207,6 +221,10 @@ void PoolFree(zmx_ctx* c, void* p) {
     }
   }
   (void)hipFree(p);
+}
+
+PoolScope::~PoolScope() {
+  for (void* p : held) PoolFree(c, p);
 }
 
 }  // namespace
@@ -477,8 +495,9 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     // recompute the listed tiles; on pool overflow fall through to the full build
     u64* d_src_pos = nullptr;
     u32* d_tile_list = nullptr;
-    HIPCHK(PoolAlloc(c, &d_src_pos, nb));
-    HIPCHK(PoolAlloc(c, &d_tile_list, tile_list.size()));
+    PoolScope tmp(c);
+    HIPCHK(tmp.Alloc(&d_src_pos, nb));
+    HIPCHK(tmp.Alloc(&d_tile_list, tile_list.size()));
     HIPCHK(hipMemcpyAsync(d_src_pos, src_pos.data(), nb * sizeof(u64), hipMemcpyHostToDevice, c->stream));
     if (!tile_list.empty()) {
       HIPCHK(hipMemcpyAsync(d_tile_list, tile_list.data(), tile_list.size() * sizeof(u32), hipMemcpyHostToDevice, c->stream));
@@ -516,8 +535,6 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     u32 counters[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(counters, t->d_counters, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    PoolFree(c, d_src_pos);
-    PoolFree(c, d_tile_list);
     if ((counters[1] & 1u) == 0) {
       t->d_pool = parent->d_pool;          // ownership moves: the parent must not be used for records again
       t->pool_cap = parent->pool_cap;
@@ -1119,10 +1136,11 @@ int zmx_verify_stores(zmx_ctx* c, zmx_tables* t, size_t n, const size_t* block, 
   }
   DeviceGuard dev_guard(c->device);
   HIPCHK(dev_guard.err);
+  PoolScope tmp(c);
   VerifyJob* d_jobs = nullptr;
   u32* d_bad = nullptr;
-  HIPCHK(PoolAlloc(c, &d_jobs, n));
-  HIPCHK(PoolAlloc(c, &d_bad, 2 * n));
+  HIPCHK(tmp.Alloc(&d_jobs, n));
+  HIPCHK(tmp.Alloc(&d_bad, 2 * n));
   HIPCHK(hipMemcpyAsync(d_jobs, vj.data(), n * sizeof(VerifyJob), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemsetAsync(d_bad, 0, 2 * n * sizeof(u32), c->stream));
   VerifyParams P;
@@ -1136,8 +1154,6 @@ int zmx_verify_stores(zmx_ctx* c, zmx_tables* t, size_t n, const size_t* block, 
   std::vector<u32> bad(2 * n);
   HIPCHK(hipMemcpyAsync(bad.data(), d_bad, 2 * n * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  PoolFree(c, d_jobs);
-  PoolFree(c, d_bad);
   for (size_t i = 0; i < n; ++i) {
     if (bad[2 * i] == 0) continue;
     static const char* why[4] = {"", "length or distance out of range", "the bytes it stands for are not the input's", "the symbols do not add up to the block"};
@@ -1179,13 +1195,14 @@ int zmx_encode_blocks(zmx_ctx* c, zmx_tables* t, size_t njobs, const zmx_enc_job
   EncJob* d_jobs = nullptr;
   u32 *d_tile_job = nullptr, *d_codes = nullptr, *d_tile_bits = nullptr, *d_out = nullptr, *d_flag = nullptr;
   u64* d_tile_off = nullptr;
-  HIPCHK(PoolAlloc(c, &d_jobs, njobs));
-  HIPCHK(PoolAlloc(c, &d_tile_job, ntile));
-  HIPCHK(PoolAlloc(c, &d_codes, njobs * 320));
-  HIPCHK(PoolAlloc(c, &d_tile_bits, ntile));
-  HIPCHK(PoolAlloc(c, &d_tile_off, ntile));
-  HIPCHK(PoolAlloc(c, &d_out, out_words + 2));
-  HIPCHK(PoolAlloc(c, &d_flag, 4));
+  PoolScope tmp(c);
+  HIPCHK(tmp.Alloc(&d_jobs, njobs));
+  HIPCHK(tmp.Alloc(&d_tile_job, ntile));
+  HIPCHK(tmp.Alloc(&d_codes, njobs * 320));
+  HIPCHK(tmp.Alloc(&d_tile_bits, ntile));
+  HIPCHK(tmp.Alloc(&d_tile_off, ntile));
+  HIPCHK(tmp.Alloc(&d_out, out_words + 2));
+  HIPCHK(tmp.Alloc(&d_flag, 4));
   HIPCHK(hipMemcpyAsync(d_jobs, ej.data(), njobs * sizeof(EncJob), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(d_tile_job, tile_job.data(), ntile * sizeof(u32), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(d_codes, codes, njobs * 320 * sizeof(u32), hipMemcpyHostToDevice, c->stream));
@@ -1219,8 +1236,6 @@ int zmx_encode_blocks(zmx_ctx* c, zmx_tables* t, size_t njobs, const zmx_enc_job
   HIPCHK(hipMemcpyAsync(c->h_stage, d_out, out_words * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemcpyAsync(&flag, d_flag, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  PoolFree(c, d_jobs); PoolFree(c, d_tile_job); PoolFree(c, d_codes); PoolFree(c, d_tile_bits);
-  PoolFree(c, d_tile_off); PoolFree(c, d_out); PoolFree(c, d_flag);
   if (flag) return FailMsg("zmx_encode_blocks: the symbols of a block take a different number of bits than the histogram says");
   const unsigned char* stage = reinterpret_cast<const unsigned char*>(c->h_stage);
   zamd::ParallelFor(njobs, [&](size_t j) {

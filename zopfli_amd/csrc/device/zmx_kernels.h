@@ -280,7 +280,8 @@ struct MatchParams {
   const u32* tile_list;  // optional: the tiles to do (total_tiles entries); null = all of them
 };
 
-__device__ __forceinline__ u32 lds_byte(const u32* w, u32 a) { return (w[a >> 2] >> ((a & 3) * 8)) & 255u; }
+// (ds_read_u8: the byte itself, no shifting around a 32-bit read)
+__device__ __forceinline__ u32 lds_byte(const u32* w, u32 a) { return reinterpret_cast<const u8*>(w)[a]; }
 __device__ __forceinline__ u32 lds_u32_unaligned(const u32* w, u32 a) {
   const u32 lo = w[a >> 2], hi = w[(a >> 2) + 1];
   return __builtin_amdgcn_alignbyte(hi, lo, a & 3);

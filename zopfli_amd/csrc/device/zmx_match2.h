@@ -60,7 +60,14 @@ __global__ __launch_bounds__(M2_THREADS, 8) void k_match2(MatchParams P) {
     }
     __syncthreads();
 
-    const uint2* lk = reinterpret_cast<const uint2*>(P.links + bd.reg_off);  // index: abs - ws; {prev1 | prev2 << 16, same | ..}
+    // index: abs - ws; {prev1 | prev2 << 16, same | ..}.  The base is the same for the whole workgroup: as a scalar
+    // pair the walk's one dependent load takes a 32-bit lane offset instead of 64-bit address arithmetic per step.
+    const uint2* lk;
+    {
+      const u64 a = reinterpret_cast<u64>(reinterpret_cast<const uint2*>(P.links + bd.reg_off));
+      const u32 alo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)a), ahi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(a >> 32));
+      lk = reinterpret_cast<const uint2*>(((u64)ahi << 32) | alo);
+    }
     const u32 li0 = (u32)(p0 - bd.ws);            // link index of the tile's first position
     const u32 lp0 = (u32)((long long)p0 - wb);    // its LDS byte offset
     const u32 rem0 = (u32)((bd.inend - p0 < 70000) ? bd.inend - p0 : 70000);   // bytes to the block end, saturated

@@ -148,13 +148,14 @@ __global__ __launch_bounds__(256) void k_same(const u8* __restrict__ in, const B
 // ----------------------------------------------------------------------------
 #define CH_EMIT 32768u
 #define CH_TILE 1024u
-#define CH_LDS_BYTES (65536 + CH_TILE * 2)
+#define CH_LDS_BYTES (65536 + CH_TILE * 4)     // the head table, a tile's keys, a tile's run lengths
 
 __global__ __launch_bounds__(64) void k_chain(const u8* __restrict__ in, const BlockDesc* __restrict__ blocks,
                                               const u16* __restrict__ same16, ushort4* __restrict__ links) {
   extern __shared__ __align__(16) u8 dyn_lds[];
   u16* head = reinterpret_cast<u16*>(dyn_lds);   // last position (relative to w0) of every key, 0xffff = none
   u16* keys = head + 32768;
+  u16* sames = keys + CH_TILE;     // same[] of the tile's positions (chain 0 writes them into the link records)
 
   const BlockDesc bd = blocks[blockIdx.y];
   const u32 chain = blockIdx.z;
@@ -188,16 +189,15 @@ __global__ __launch_bounds__(64) void k_chain(const u8* __restrict__ in, const B
         const u64 k = t0 + i0 + q;
         by[q] = (i0 < tn && k < L) ? (u32)base[k] : 0u;          // (zero past the block end: hash.c:100-104's caller)
       }
-      if (chain) {
 #pragma unroll
-        for (u32 q = 0; q < 16; ++q) sm[q] = (i0 + q < tn) ? (u32)same[t0 + i0 + q] : 0u;
-      }
+      for (u32 q = 0; q < 16; ++q) sm[q] = (i0 + q < tn) ? (u32)same[t0 + i0 + q] : 0u;
 #pragma unroll
       for (u32 q = 0; q < 16; ++q) {
         if (i0 + q < tn) {
           u32 v = ((by[q] << 10) ^ (by[q + 1] << 5) ^ by[q + 2]) & 32767u;   // hash.c:96-98, three rolling updates
           if (chain) v ^= (sm[q] - 3u) & 255u;                                // hash.c:129
           keys[i0 + q] = (u16)v;
+          sames[i0 + q] = (u16)sm[q];
         }
       }
     }
@@ -243,7 +243,8 @@ __global__ __launch_bounds__(64) void k_chain(const u8* __restrict__ in, const B
       if (act && k >= e0) {
         if (chain == 0) {
           lk[k].x = (u16)d;
-          lk[k].z = same[k];
+          lk[k].z = sames[i];      // (from the staged tile: a global load here stalled every step of a wave that
+                                   //  shares its CU with one other wave)
         } else {
           lk[k].y = (u16)d;
         }

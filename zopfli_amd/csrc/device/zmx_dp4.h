@@ -941,23 +941,39 @@ __device__ __forceinline__ u32 d4_accept(float vmin, double vmax, double delta, 
 __global__ __launch_bounds__(64) void k_dpscan(Dp4Params P) {
   const u32 b = P.block0 + blockIdx.x;
   const u32 t0 = P.task_off[b], t1 = P.task_off[b + 1];
-  if (threadIdx.x != 0) return;
+  const u32 lane = threadIdx.x;
   const double wmax = (double)P.wmax[b] + 1.0;
   const u32 tiemask = P.tiemask[b];
-  double delta_prev = 0.0;
-  for (u32 t = t0 + 1; t < t1; ++t) {
-    const SegCheck ck = P.chk[t];
-    const double delta = delta_prev + ck.d;
-    bool ok = ck.match == 1 && d4_accept(ck.vmin, (double)P.exit[t].vmax, delta, wmax, tiemask) == 0;
-    if (!ok && ck.match != 0) {          // same structure, wrong level: again from the level the chain implies
-      const u32 slot = atomicAdd(P.redo_count, 1u);
-      u32* wg = P.redo_wg + (u64)slot * 4;
-      wg[0] = t; wg[1] = SEG_NONE; wg[2] = SEG_NONE; wg[3] = SEG_NONE;
-      P.lvl[t] = (float)((double)P.lvl[t] + delta);
+  // The shift of task t is the sum of the differences up to t — sums of multiples of float ulps, exact in any
+  // order — so the walk is a prefix sum: 64 tasks at a time, a lane each (one lane walking 240 tasks with two
+  // dependent loads per task was 0.12 ms a run).
+  double carry = 0.0;
+  for (u32 c0 = t0 + 1; c0 < t1; c0 += 64) {
+    const u32 t = c0 + lane;
+    const bool act = t < t1;
+    SegCheck ck;
+    ck.d = 0.0; ck.vmin = 0.0f; ck.match = 0;
+    float vmax = 0.0f;
+    if (act) { ck = P.chk[t]; vmax = P.exit[t].vmax; }
+    double incl = act ? ck.d : 0.0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const double up = __shfl_up(incl, o, 64);
+      if ((int)lane >= o) incl += up;
     }
-    // (the exit snapshots at hand are those of the first run: whatever becomes of this task, its exit
-    //  there plus `delta` is the best estimate of the true state the next task starts from)
-    delta_prev = delta;
+    const double delta = carry + incl;
+    if (act) {
+      const bool ok = ck.match == 1 && d4_accept(ck.vmin, (double)vmax, delta, wmax, tiemask) == 0;
+      if (!ok && ck.match != 0) {          // same structure, wrong level: again from the level the chain implies
+        const u32 slot = atomicAdd(P.redo_count, 1u);
+        u32* wg = P.redo_wg + (u64)slot * 4;
+        wg[0] = t; wg[1] = SEG_NONE; wg[2] = SEG_NONE; wg[3] = SEG_NONE;
+        P.lvl[t] = (float)((double)P.lvl[t] + delta);
+      }
+    }
+    // (the exit snapshots at hand are those of the first run: whatever becomes of a task, its exit there plus
+    //  its shift is the best estimate of the true state the next task starts from)
+    carry += __shfl(incl, 63, 64);
   }
 }
 

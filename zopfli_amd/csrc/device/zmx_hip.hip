@@ -383,7 +383,14 @@ static unsigned EnvU32(const char* name, unsigned dflt, unsigned lo, unsigned hi
 static unsigned SegL() { static const unsigned v = EnvU32("ZOPFLI_AMD_SEG_L", 4096, 0, 1u << 24) & ~63u; return v; }
 // The first task of a block is exact by construction and runs beside the others: let it cover the
 // stretch where the costs double every few thousand positions and no guess would stay in its binade.
-static unsigned SegHead() { static const unsigned v = EnvU32("ZOPFLI_AMD_SEG_HEAD", 4096, 0, 1u << 24) & ~63u; return v; }
+// The exact head of a block (positions run from the true initial state; the values double every few hundred
+// positions there and speculative tasks would not stay inside a binade).  It is one serial wave: with few blocks in
+// the batch the whole run waits for it (short: 4096), with many it hides behind the other tasks and a long head
+// saves the serial re-runs of the early tasks (16384).  ZOPFLI_AMD_SEG_HEAD overrides.
+static unsigned SegHead(size_t nb) {
+  static const unsigned v = EnvU32("ZOPFLI_AMD_SEG_HEAD", 0, 0, 1u << 24) & ~63u;
+  return v ? v : (nb >= 48 ? 16384u : 4096u);
+}
 static unsigned SegWarm() { static const unsigned v = (EnvU32("ZOPFLI_AMD_SEG_WARM", 512, 64, 1u << 20) + 63u) & ~63u; return v; }
 
 static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_tables* t, zmx_tables* parent = nullptr) {
@@ -665,7 +672,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   // the chain's tasks (zmx_dp4.h): SEG_L positions each, the last one of a block takes the remainder
   {
     const u32 L = SegL(), warm = SegWarm();
-    const u32 head = std::max(SegHead(), L);
+    const u32 head = std::max(SegHead(nb), L);
     t->task_off.assign(nb + 1, 0);
     t->tasks.clear();
     for (size_t b = 0; b < nb; ++b) {

@@ -126,6 +126,14 @@ struct zmx_tables {
   std::vector<u32> tile_off;
   u32* d_counters = nullptr;  // 16 words, see MatchParams
   u32* d_flags = nullptr;     // 4 words
+  // what a squeeze run takes and gives, each side ONE array on the device and one pinned mirror on the host, so
+  // that a run has one copy down and one up (eight small copies a run were 3 ms of copy kernels per 15 runs):
+  // d_runin = cost | mincost | runinfo | slot, d_runout = hist | nsym | segstats | flags (the d_* above point into them)
+  unsigned char* d_runin = nullptr;
+  unsigned char* d_runout = nullptr;
+  unsigned char* h_runin = nullptr;
+  unsigned char* h_runout = nullptr;
+  size_t runin_bytes = 0, runout_bytes = 0;
   u64* d_prof = nullptr;      // nb * ZMX_PROF_N counters when ZOPFLI_AMD_PROF is set
   // the chain's tasks (zmx_dp4.h)
   std::vector<SegTask> tasks;
@@ -330,11 +338,6 @@ void zmx_tables_free(zmx_ctx* c, zmx_tables* t) {
   PoolFree(c, t->d_la);
   PoolFree(c, t->d_store[0]);
   PoolFree(c, t->d_store[1]);
-  PoolFree(c, t->d_hist);
-  PoolFree(c, t->d_nsym);
-  PoolFree(c, t->d_cost);
-  PoolFree(c, t->d_mincost);
-  PoolFree(c, t->d_slot);
   PoolFree(c, t->d_dph);
   PoolFree(c, t->d_block_edges);
   PoolFree(c, t->d_badpos);
@@ -346,12 +349,15 @@ void zmx_tables_free(zmx_ctx* c, zmx_tables* t) {
   PoolFree(c, t->d_extab);
   PoolFree(c, t->d_seginfo);
   PoolFree(c, t->d_counters);
-  PoolFree(c, t->d_flags);
   PoolFree(c, t->d_prof);
   PoolFree(c, t->d_tasks);
   PoolFree(c, t->d_task_off);
   PoolFree(c, t->d_wg_tasks);
   PoolFree(c, t->d_wmeta);
+  PoolFree(c, t->d_runin);
+  PoolFree(c, t->d_runout);
+  if (t->h_runin) (void)hipHostFree(t->h_runin);
+  if (t->h_runout) (void)hipHostFree(t->h_runout);
   PoolFree(c, t->d_winroff);
   PoolFree(c, t->d_winflag);
   PoolFree(c, t->d_win_off);
@@ -361,8 +367,6 @@ void zmx_tables_free(zmx_ctx* c, zmx_tables* t) {
   PoolFree(c, t->d_chk);
   PoolFree(c, t->d_over);
   PoolFree(c, t->d_redo);
-  PoolFree(c, t->d_runinfo);
-  PoolFree(c, t->d_segstats);
   delete t;
 }
 
@@ -465,11 +469,27 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   HIPCHK(PoolAlloc(c, &t->d_la, la_off));
   HIPCHK(PoolAlloc(c, &t->d_store[0], pos_off));
   HIPCHK(PoolAlloc(c, &t->d_store[1], pos_off));
-  HIPCHK(PoolAlloc(c, &t->d_hist, nb * ZMX_HIST));
-  HIPCHK(PoolAlloc(c, &t->d_nsym, nb));
-  HIPCHK(PoolAlloc(c, &t->d_cost, nb * ZMX_HIST));
-  HIPCHK(PoolAlloc(c, &t->d_mincost, nb));
-  HIPCHK(PoolAlloc(c, &t->d_slot, nb));
+  {
+    const size_t in_cost = 0, in_min = in_cost + nb * ZMX_HIST * sizeof(double), in_info = in_min + nb * sizeof(double),
+                 in_slot = in_info + 3 * nb * sizeof(float);
+    t->runin_bytes = in_slot + nb * sizeof(int);
+    const size_t out_hist = 0, out_nsym = out_hist + nb * ZMX_HIST * sizeof(u32), out_stats = out_nsym + nb * sizeof(u32),
+                 out_flags = out_stats + 8 * sizeof(u32);
+    t->runout_bytes = out_flags + 4 * sizeof(u32);
+    HIPCHK(PoolAlloc(c, &t->d_runin, t->runin_bytes));
+    HIPCHK(PoolAlloc(c, &t->d_runout, t->runout_bytes));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&t->h_runin), t->runin_bytes, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&t->h_runout), t->runout_bytes, hipHostMallocDefault));
+    t->d_cost = reinterpret_cast<double*>(t->d_runin + in_cost);
+    t->d_mincost = reinterpret_cast<double*>(t->d_runin + in_min);
+    t->d_runinfo = reinterpret_cast<float*>(t->d_runin + in_info);
+    t->d_slot = reinterpret_cast<int*>(t->d_runin + in_slot);
+    t->d_hist = reinterpret_cast<u32*>(t->d_runout + out_hist);
+    t->d_nsym = reinterpret_cast<u32*>(t->d_runout + out_nsym);
+    t->d_segstats = reinterpret_cast<u32*>(t->d_runout + out_stats);
+    t->d_flags = reinterpret_cast<u32*>(t->d_runout + out_flags);
+    HIPCHK(hipMemsetAsync(t->d_segstats, 0, 12 * sizeof(u32), c->stream));
+  }
   HIPCHK(PoolAlloc(c, &t->d_dph, pos_off));
   HIPCHK(PoolAlloc(c, &t->d_block_edges, nb));
   t->badpos_words = pos_off / 32 + 4;
@@ -478,7 +498,6 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   HIPCHK(PoolAlloc(c, &t->d_wtab, nb * ZMX_WTAB));
   HIPCHK(PoolAlloc(c, &t->d_badcodes, nb * 40));
   HIPCHK(PoolAlloc(c, &t->d_counters, 16));
-  HIPCHK(PoolAlloc(c, &t->d_flags, 4));
   HIPCHK(hipMemcpyAsync(t->d_blocks, t->blocks.data(), nb * sizeof(BlockDesc), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(t->d_tile_off, tile_off.data(), (nb + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemsetAsync(t->d_flags, 0, 4 * sizeof(u32), c->stream));
@@ -698,8 +717,6 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     HIPCHK(PoolAlloc(c, &t->d_chk, nt));
     HIPCHK(PoolAlloc(c, &t->d_over, nt * SEG_OVER));
     HIPCHK(PoolAlloc(c, &t->d_redo, 4 + nt * 4));
-    HIPCHK(PoolAlloc(c, &t->d_runinfo, 3 * nb));
-    HIPCHK(PoolAlloc(c, &t->d_segstats, 8));
     HIPCHK(hipMemcpyAsync(t->d_tasks, t->tasks.data(), nt * sizeof(SegTask), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(t->d_task_off, t->task_off.data(), (nb + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(t->d_segstats, 0, 8 * sizeof(u32), c->stream));
@@ -746,18 +763,6 @@ int zmx_tables_build_from(zmx_ctx* c, zmx_tables* parent, const zmx_block* block
     return rc;
   }
   *out = t;
-  return 0;
-}
-
-static int CheckFlags(zmx_ctx* c, zmx_tables* t, const char* where) {
-  u32 flags[4];
-  HIPCHK(hipMemcpyAsync(flags, t->d_flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  if (flags[1]) {
-    char buf[128];
-    std::snprintf(buf, sizeof(buf), "%s: device consistency flags 0x%x", where, flags[1]);
-    return FailMsg(buf);
-  }
   return 0;
 }
 
@@ -872,21 +877,24 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     if (slot[b] != 0 && slot[b] != 1) return FailMsg("zmx_squeeze_run: slot must be 0 or 1");
   }
   const size_t nb = t->nb;
-  // per-block facts about this run's cost model for the chain's acceptance test
-  std::vector<float> runinfo(3 * nb);
+  // the run's input in the pinned mirror: costs, mincosts, slots, and per block what the chain's acceptance test has
+  // to know about this cost model (RunInfo)
   {
+    double* h_cost = reinterpret_cast<double*>(t->h_runin);
+    double* h_min = h_cost + nb * ZMX_HIST;
+    float* wmax = reinterpret_cast<float*>(h_min + nb);
+    u32* tiemask = reinterpret_cast<u32*>(wmax + nb);
+    float* est = wmax + 2 * nb;
+    int* h_slot = reinterpret_cast<int*>(wmax + 3 * nb);
+    std::memcpy(h_cost, cost, nb * ZMX_HIST * sizeof(double));
+    std::memcpy(h_min, mincost, nb * sizeof(double));
+    std::memcpy(h_slot, slot, nb * sizeof(int));
     const u32* hh = t->have_hist ? t->h_hist.data() : nullptr;
-    float* wmax = runinfo.data();
-    u32* tiemask = reinterpret_cast<u32*>(runinfo.data() + nb);
-    float* est = runinfo.data() + 2 * nb;
     zamd::ParallelFor(nb, [&](size_t b) {
       RunInfo(cost + b * ZMX_HIST, hh ? hh + b * ZMX_HIST : nullptr, t->bsize[b], &wmax[b], &tiemask[b], &est[b]);
     });
   }
-  HIPCHK(hipMemcpyAsync(t->d_cost, cost, nb * ZMX_HIST * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(t->d_mincost, mincost, nb * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(t->d_slot, slot, nb * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipMemcpyAsync(t->d_runinfo, runinfo.data(), 3 * nb * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(t->d_runin, t->h_runin, t->runin_bytes, hipMemcpyHostToDevice, c->stream));
   static const bool want_prof = std::getenv("ZOPFLI_AMD_PROF") != nullptr;
   if (want_prof && !t->d_prof) HIPCHK(PoolAlloc(c, &t->d_prof, nb * ZMX_PROF_N));
   if (t->d_prof) HIPCHK(hipMemsetAsync(t->d_prof, 0, nb * ZMX_PROF_N * sizeof(u64), c->stream));
@@ -1019,12 +1027,23 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     }
   }
   u32 segstats[8];
-  HIPCHK(hipMemcpyAsync(nsym, t->d_nsym, nb * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(hist, t->d_hist, nb * ZMX_HIST * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemcpyAsync(segstats, t->d_segstats, sizeof(segstats), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(t->h_runout, t->d_runout, t->runout_bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipMemsetAsync(t->d_segstats, 0, sizeof(segstats), c->stream));
-  const int rc = CheckFlags(c, t, "zmx_squeeze_run");
-  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  {
+    const u32* o_hist = reinterpret_cast<const u32*>(t->h_runout);
+    const u32* o_nsym = o_hist + nb * ZMX_HIST;
+    const u32* o_stats = o_nsym + nb;
+    const u32* o_flags = o_stats + 8;
+    std::memcpy(hist, o_hist, nb * ZMX_HIST * sizeof(u32));
+    std::memcpy(nsym, o_nsym, nb * sizeof(u32));
+    std::memcpy(segstats, o_stats, sizeof(segstats));
+    if (o_flags[1]) {
+      char buf[128];
+      std::snprintf(buf, sizeof(buf), "zmx_squeeze_run: device consistency flags 0x%x", o_flags[1]);
+      return FailMsg(buf);
+    }
+  }
   t->h_hist.assign(hist, hist + nb * ZMX_HIST);
   t->have_hist = true;
   ++t->squeeze_runs;

@@ -180,15 +180,19 @@ __global__ __launch_bounds__(M2_THREADS, 8) void k_match2(MatchParams P) {
         st = M2_CMP;
       }
       bool fin = false;
-      if (st == M2_CMP) {  // GetMatch (lz77.c:297), 4 bytes per step
+      if (st == M2_CMP) {  // GetMatch (lz77.c:297), 8 bytes per step (markup and source code: matches of 50+ bytes)
         const u32 rem = limit - cur;
         bool end = rem == 0;
         if (!end) {
-          const u32 x = lds_u32_unaligned(win, lp + cur) ^ lds_u32_unaligned(win, lc + cur);
-          u32 m = x ? (u32)(__ffs((int)x) - 1) >> 3 : 4u;
+          const u32 a0 = (lp + cur) >> 2, b0 = (lc + cur) >> 2, as = (lp + cur) & 3u, bs = (lc + cur) & 3u;
+          const u32 a_lo = win[a0], a_mi = win[a0 + 1], a_hi = win[a0 + 2];
+          const u32 b_lo = win[b0], b_mi = win[b0 + 1], b_hi = win[b0 + 2];
+          const u32 x0 = __builtin_amdgcn_alignbyte(a_mi, a_lo, as) ^ __builtin_amdgcn_alignbyte(b_mi, b_lo, bs);
+          const u32 x1 = __builtin_amdgcn_alignbyte(a_hi, a_mi, as) ^ __builtin_amdgcn_alignbyte(b_hi, b_mi, bs);
+          u32 m = x0 ? (u32)(__ffs((int)x0) - 1) >> 3 : x1 ? 4u + ((u32)(__ffs((int)x1) - 1) >> 3) : 8u;
           if (m > rem) m = rem;
           cur += m;
-          end = m < 4 || cur >= limit;
+          end = m < 8 || cur >= limit;
         }
         if (end) {
           ev = true;

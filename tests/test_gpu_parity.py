@@ -229,6 +229,9 @@ CHAIN_ENVS = [
     ({"ZOPFLI_AMD_SEG_WARM": "64", "ZOPFLI_AMD_SEG_HEAD": "0"}, lambda st: st["rerun_state"] > 0),                           # warm-up too short: states differ
     ({"ZOPFLI_AMD_SEG_SCALE": "1.9"}, lambda st: st["rerun_level"] + st["rerun_values"] > 0),                         # wrong binade guessed
     ({"ZOPFLI_AMD_SEG_L": "1024", "ZOPFLI_AMD_SEG_WARM": "256", "ZOPFLI_AMD_SEG_HEAD": "4096"}, lambda st: st["tasks"] > 400),
+    ({"ZOPFLI_AMD_INT_PATH": "0"}, lambda st: st["accepted"] > 0),                              # every window in the reference's doubles
+    ({"ZOPFLI_AMD_FIX_LEAN": "0"}, lambda st: st["rerun_state"] > 0),                           # serial re-runs by the lean one-wave job
+    ({"ZOPFLI_AMD_SEG_REDO": "0"}, lambda st: st["rerun_level"] > 0),                           # no second speculative pass
 ]
 
 

@@ -555,7 +555,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     mp.scratch = c->d_scratch;
     mp.tile_list = d_tile_list;
     if (mp.total_tiles > 0) {
-      hipLaunchKernelGGL(k_match2, dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
+      hipLaunchKernelGGL(k_match2<false>, dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
       HIPCHK(hipGetLastError());
     }
     u32 counters[2] = {0, 0};
@@ -600,7 +600,9 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     mp.scratch = c->d_scratch;
     mp.tile_list = nullptr;
     if (mp.total_tiles > 0) {
-      hipLaunchKernelGGL(k_match2, dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
+      static const bool match_prof = std::getenv("ZOPFLI_AMD_PROF") != nullptr;
+      if (match_prof) hipLaunchKernelGGL(k_match2<true>, dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
+      else hipLaunchKernelGGL(k_match2<false>, dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
       HIPCHK(hipGetLastError());
     }
     u32 counters[2] = {0, 0};
@@ -622,6 +624,15 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     g_match_stats[1] += ms_hash * 1e-3;
     g_match_stats[2] += 1;
     g_match_stats[3] += reuse ? static_cast<double>(tile_list.size()) * MT : match_positions;
+    if (std::getenv("ZOPFLI_AMD_PROF") && !reuse) {
+      unsigned long long hc[2] = {0, 0};
+      HIPCHK(hipMemcpy(hc, t->d_counters + 4, sizeof(hc), hipMemcpyDeviceToHost));
+      const double pos = static_cast<double>(pos_off);
+      std::fprintf(stderr, "k_match2: %.2f ms for %.0f positions: %.1f chain hits per "
+                   "position, %.1f of 64 lanes with a hit per wave-loop iteration; %.1f SIMD cycles per hit (2.4 GHz, 1024 SIMDs)\n", ms_match, pos,
+                   static_cast<double>(hc[0]) / pos, static_cast<double>(hc[0]) / static_cast<double>(hc[1] ? hc[1] : 1),
+                   ms_match * 1e-3 * 2.4e9 * 1024 / static_cast<double>(hc[0] ? hc[0] : 1));
+    }
   }
 
   // DP row layout (k_rowscan), then the edges as weight codes (k_codes) and a buffer descriptor per row

@@ -17,6 +17,9 @@
 #define M2_PEND 3u      // walk ended, record not written yet
 #define M2_DONE 4u      // the tile has no more positions
 
+// PROF: counts the chain hits (candidates visited, lz77.c:464-530) and the iterations of the wave loop into
+// P.counters[4..7] (two 64-bit sums) — ZOPFLI_AMD_PROF prints hits per position and cycles per hit.
+template <bool PROF>
 __global__ __launch_bounds__(M2_THREADS, 8) void k_match2(MatchParams P) {
   __shared__ __align__(16) u32 win[MWIN_BYTES / 4 + 4];
   __shared__ u32 s_next, s_tile;
@@ -82,6 +85,7 @@ __global__ __launch_bounds__(M2_THREADS, 8) void k_match2(MatchParams P) {
     u32 hits_left = 0, chain = 1;
     uint2 L = make_uint2(0, 0);    // link record of the candidate
     u32* rec = rec0;
+    u32 n_hits = 0, n_iter = 0;
     // the first 8 change points of sublen (3 bytes each: length - 3, distance) as they will lie in the record:
     // built in registers, written with the record in two 16-byte stores (byte stores into HBM as they were
     // found cost 9.2 GB of write traffic for 3.2 GB of records)
@@ -219,6 +223,7 @@ __global__ __launch_bounds__(M2_THREADS, 8) void k_match2(MatchParams P) {
           }
         }
       }
+      if (PROF) { n_hits += ev ? 1u : 0u; ++n_iter; }
       if (ev) {
         if (!fin) {
           // lz77.c:509-519: switch to the run-length hash; on chain 1 the 3-byte
@@ -235,6 +240,10 @@ __global__ __launch_bounds__(M2_THREADS, 8) void k_match2(MatchParams P) {
         }
         if (fin) st = M2_PEND;
       }
+    }
+    if (PROF) {
+      atomicAdd(reinterpret_cast<unsigned long long*>(P.counters + 4), (unsigned long long)n_hits);
+      if ((tid & 63) == 0) atomicAdd(reinterpret_cast<unsigned long long*>(P.counters + 6), (unsigned long long)n_iter);
     }
   }
 }

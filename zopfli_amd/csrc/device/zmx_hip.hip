@@ -384,7 +384,17 @@ static unsigned EnvU32(const char* name, unsigned dflt, unsigned lo, unsigned hi
 }
 // Task geometry of the chain (zmx_dp4.h): positions per task and warm-up positions before it.
 // ZOPFLI_AMD_SEG_L = 0 turns the cut off (one task per block: the serial chain).
-static unsigned SegL() { static const unsigned v = EnvU32("ZOPFLI_AMD_SEG_L", 4096, 0, 1u << 24) & ~63u; return v; }
+// Task length of the chain.  A task is one serial wave, and a run is at least a task, a second-pass task and the
+// serial re-runs long: with little to do (small calls: zopflipng's IDATs, files of a MB or less) short tasks cut
+// that latency (1 MB: 53 -> 47 ms, 64 KiB: 32 -> 24 ms) although every task pays its 512-position warm-up; with
+// a full batch 2048 and 4096 run alike and the longer tasks walk fewer positions.  ZOPFLI_AMD_SEG_L overrides
+// (0 = no tasks: the serial chain).
+static unsigned SegL(u64 total_positions) {
+  static const bool set = std::getenv("ZOPFLI_AMD_SEG_L") != nullptr;
+  static const unsigned v = EnvU32("ZOPFLI_AMD_SEG_L", 4096, 0, 1u << 24) & ~63u;
+  if (set) return v;
+  return total_positions < (2u << 20) ? 1024u : total_positions < (32u << 20) ? 2048u : 4096u;
+}
 // The first task of a block is exact by construction and runs beside the others: let it cover the
 // stretch where the costs double every few thousand positions and no guess would stay in its binade.
 // The exact head of a block (positions run from the true initial state; the values double every few hundred
@@ -393,7 +403,7 @@ static unsigned SegL() { static const unsigned v = EnvU32("ZOPFLI_AMD_SEG_L", 40
 // saves the serial re-runs of the early tasks (16384).  ZOPFLI_AMD_SEG_HEAD overrides.
 static unsigned SegHead(size_t nb) {
   static const unsigned v = EnvU32("ZOPFLI_AMD_SEG_HEAD", 0, 0, 1u << 24) & ~63u;
-  return v ? v : (nb >= 48 ? 16384u : 4096u);
+  return v ? v : (nb >= 48 ? 16384u : 0u);      // (0: as long as a task)
 }
 static unsigned SegWarm() { static const unsigned v = (EnvU32("ZOPFLI_AMD_SEG_WARM", 512, 64, 1u << 20) + 63u) & ~63u; return v; }
 
@@ -701,7 +711,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   }
   // the chain's tasks (zmx_dp4.h): SEG_L positions each, the last one of a block takes the remainder
   {
-    const u32 L = SegL(), warm = SegWarm();
+    const u32 L = SegL(t->total_b), warm = SegWarm();
     const u32 head = std::max(SegHead(nb), L);
     t->task_off.assign(nb + 1, 0);
     t->tasks.clear();

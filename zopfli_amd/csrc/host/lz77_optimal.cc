@@ -198,15 +198,22 @@ int Lz77OptimalBatch(zmx_ctx* ctx, const ZopfliOptions& options, const std::vect
   });
   ThreadTiming().cost_model += Now() - t2;
 
+  // the cost model of a block's next run, from its statistics (done at the end of the loop below for every run but
+  // the first: one wake-up of the workers per run instead of two)
+  auto next_model = [&](size_t b) {
+    std::memcpy(&cost[b * ZMX_HIST], it[b].stats.ll_symbols, sizeof(double) * kNumLL);
+    std::memcpy(&cost[b * ZMX_HIST + kNumLL], it[b].stats.d_symbols, sizeof(double) * kNumD);
+    mincost[b] = ModelMinCost(it[b].stats.ll_symbols, it[b].stats.d_symbols);
+    slot[b] = it[b].best_slot == 0 ? 1 : 0;  // never overwrite the best parse
+  };
+  {
+    const double ta = Now();
+    ParallelFor(nb, next_model);
+    ThreadTiming().cost_model += Now() - ta;
+  }
   for (int i = 0; i < options.numiterations; ++i) {
     double ta = Now();
-    ParallelFor(nb, [&](size_t b) {
-      std::memcpy(&cost[b * ZMX_HIST], it[b].stats.ll_symbols, sizeof(double) * kNumLL);
-      std::memcpy(&cost[b * ZMX_HIST + kNumLL], it[b].stats.d_symbols, sizeof(double) * kNumD);
-      mincost[b] = ModelMinCost(it[b].stats.ll_symbols, it[b].stats.d_symbols);
-      slot[b] = it[b].best_slot == 0 ? 1 : 0;  // never overwrite the best parse
-    });
-    double tb = Now();
+    double tb = ta;
     rc = zmx_squeeze_run(ctx, t, cost.data(), mincost.data(), slot.data(), nsym.data(), hist.data());
     if (rc) { zmx_tables_free(ctx, t); return rc; }
     double tc = Now();
@@ -254,6 +261,7 @@ int Lz77OptimalBatch(zmx_ctx* ctx, const ZopfliOptions& options, const std::vect
         s.lastrandomstep = i;
       }
       s.lastcost = c;
+      next_model(b);
     });
     double td = Now();
     ThreadTiming().squeeze += tc - tb;

@@ -29,7 +29,8 @@ struct FinalBlock {
 // A compressed block whose symbols the device writes (zmx_encode_blocks): it is a whole block of the optimal batch.
 struct DeviceEncode {
   size_t chunk = 0;                  // index in the part's chunks
-  size_t block = 0;                  // index in the batched block list
+  size_t block = 0;                  // index in the batched block list (or in the fixed-tree re-parse batch)
+  bool from_fixed = false;           // its symbols are the fixed-tree re-parse's
   std::vector<uint8_t> header;       // the 3 header bits and the tree, from bit 0
   size_t header_bits = 0;
   size_t data_bits = 0;              // symbols + end symbol
@@ -251,9 +252,15 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
 
   // ---- 4. fixed-tree re-parse where it may win (deflate.c:770-781)
   const double tp2 = Now();
+  // (with the device bit writer the re-parses stay on the device as well: their cost comes from their histograms,
+  //  their bits — where the fixed tree wins — from zmx_encode_blocks.  Incompressible input asks for a re-parse of
+  //  every block: downloading those stores and indexing them on the host was most of what such input cost.)
   std::vector<SymbolRun> fixed_runs;
-  rc = Lz77OptimalFixedBatch(ctx, fixed_requests, &fixed_runs);
+  OptimalKeep fkeep;
+  fkeep.skip_download = device_encode;
+  rc = Lz77OptimalFixedBatch(ctx, fixed_requests, &fixed_runs, device_encode ? &fkeep : nullptr);
   if (rc) return rc;
+  TablesGuard fixed_guard{ctx, fkeep.tables};
   const double tp3 = Now();
 
   // ---- 5. pick the block type and encode
@@ -273,9 +280,17 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
       }
       double fixedcost = f.fixed;
       Lz77Store fixedstore;
+      Histogram fixedhist;
       if (f.expensive_fixed) {
-        fixedstore = StoreFromRun(fixed_runs[f.fixed_request], fixed_requests[f.fixed_request].instart);
-        fixedcost = CalculateBlockSize(fixedstore, 0, fixedstore.size(), 1);
+        if (fkeep.tables) {
+          const uint32_t* c = &fkeep.hist[static_cast<size_t>(f.fixed_request) * ZMX_HIST];
+          for (int k = 0; k < kNumLL; ++k) fixedhist.ll[k] = c[k];
+          for (int k = 0; k < kNumD; ++k) fixedhist.d[k] = c[kNumLL + k];
+          fixedcost = BlockSizeFromHistogram(fixedhist, 1);
+        } else {
+          fixedstore = StoreFromRun(fixed_runs[f.fixed_request], fixed_requests[f.fixed_request].instart);
+          fixedcost = CalculateBlockSize(fixedstore, 0, fixedstore.size(), 1);
+        }
       }
       if (f.stored < fixedcost && f.stored < f.dynamic) {
         Chunk c;
@@ -290,6 +305,8 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
       const int used_btype = fixedcost < f.dynamic ? 1 : 2;
       // the symbols of a block that is a whole block of the optimal batch are still on the device: it writes them
       long dev_block = -1;
+      const bool fixed_on_device = used_btype == 1 && f.expensive_fixed && fkeep.tables != nullptr;
+      if (fixed_on_device) dev_block = f.fixed_request;
       if (keep.tables && !(used_btype == 1 && f.expensive_fixed)) {
         for (size_t k = 0; k < s.block_sym_end.size(); ++k) {
           if (s.block_sym_end[k] == f.lend && (k == 0 ? 0 : s.block_sym_end[k - 1]) == f.lstart) dev_block = static_cast<long>(s.first_block + k);
@@ -298,8 +315,10 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
       Chunk c;
       if (dev_block >= 0) {
         DeviceEncode e;
+        e.from_fixed = fixed_on_device;
         Histogram h;
-        if (no_symbols) h = block_hist(s.first_block);
+        if (fixed_on_device) h = fixedhist;          // (not read for btype 1)
+        else if (no_symbols) h = block_hist(s.first_block);
         else s.lz77.GetHistogram(f.lstart, f.lend, &h);
         e.data_bits = EncodeBlockHeader(h, used_btype, final_block, &w, &tree_bits, e.codes);
         e.header = w.Finish(&e.header_bits);
@@ -328,8 +347,11 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
     }
     if (options.verbose && !s.chunks.empty()) s.chunks.front().log_pre = std::move(s.log);
   });
-  // ---- 5b. the device writes the symbols of its blocks behind the headers
-  {
+  // ---- 5b. the device writes the symbols of its blocks behind the headers (the blocks of the optimal batch, then
+  //          those of the fixed-tree re-parses)
+  for (int pass = 0; pass < 2; ++pass) {
+    const OptimalKeep& kp = pass == 0 ? keep : fkeep;
+    if (!kp.tables) continue;
     std::vector<zmx_enc_job> jobs;
     std::vector<uint32_t> codes;
     std::vector<unsigned char*> outs;
@@ -337,11 +359,11 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
     for (size_t p = 0; p < np; ++p) {
       for (size_t k = 0; k < st[p].enc.size(); ++k) {
         DeviceEncode& e = st[p].enc[k];
-        Chunk& c = st[p].chunks[e.chunk];
+        if (e.from_fixed != (pass == 1)) continue;
         zmx_enc_job j;
         j.block = static_cast<uint32_t>(e.block);
-        j.slot = keep.slot[e.block];
-        j.nsym = keep.nsym[e.block];
+        j.slot = kp.slot[e.block];
+        j.nsym = kp.nsym[e.block];
         j.bit_start = static_cast<uint32_t>(e.header_bits);
         j.nbits = e.data_bits;
         jobs.push_back(j);
@@ -349,6 +371,7 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
         owner.push_back({p, k});
       }
     }
+    if (jobs.empty()) continue;
     // (the chunks' memory — a third of the input's size in all — is allocated and touched by the workers, not by
     //  this thread: first-touch page faults of 30 MB were most of what this phase took)
     outs.resize(jobs.size());
@@ -357,15 +380,13 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
       c.bits.assign((c.nbits + 7) / 8, 0);
       outs[i] = c.bits.data();
     });
-    if (!jobs.empty()) {
-      rc = zmx_encode_blocks(ctx, keep.tables, jobs.size(), jobs.data(), codes.data(), outs.data());
-      if (rc) return rc;
-      ParallelFor(jobs.size(), [&](size_t i) {
-        const DeviceEncode& e = st[owner[i].first].enc[owner[i].second];
-        uint8_t* b = st[owner[i].first].chunks[e.chunk].bits.data();
-        for (size_t k = 0; k < e.header.size(); ++k) b[k] |= e.header[k];
-      });
-    }
+    rc = zmx_encode_blocks(ctx, kp.tables, jobs.size(), jobs.data(), codes.data(), outs.data());
+    if (rc) return rc;
+    ParallelFor(jobs.size(), [&](size_t i) {
+      const DeviceEncode& e = st[owner[i].first].enc[owner[i].second];
+      uint8_t* b = st[owner[i].first].chunks[e.chunk].bits.data();
+      for (size_t k = 0; k < e.header.size(); ++k) b[k] |= e.header[k];
+    });
   }
   ThreadTiming().encode += Now() - t5;
 

@@ -288,7 +288,8 @@ int Lz77OptimalBatch(zmx_ctx* ctx, const ZopfliOptions& options, const std::vect
   return rc;
 }
 
-int Lz77OptimalFixedBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks, std::vector<SymbolRun>* out) {
+int Lz77OptimalFixedBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks, std::vector<SymbolRun>* out,
+                          OptimalKeep* keep) {
   const size_t nb = blocks.size();
   out->assign(nb, SymbolRun());
   if (nb == 0) return 0;
@@ -314,9 +315,16 @@ int Lz77OptimalFixedBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks, st
   }
   rc = zmx_squeeze_run(ctx, t, cost.data(), mincost.data(), slot.data(), nsym.data(), hist.data());
   if (!rc && VerifyWanted()) rc = VerifyAll(ctx, t, std::vector<int32_t>(nb, 0), nsym);
-  if (!rc) rc = DownloadAll(ctx, t, std::vector<int32_t>(nb, 0), nsym, out);
+  if (!rc && !(keep && keep->skip_download)) rc = DownloadAll(ctx, t, std::vector<int32_t>(nb, 0), nsym, out);
   ThreadTiming().squeeze += Now() - t1;
-  zmx_tables_free(ctx, t);
+  if (keep && !rc) {
+    keep->tables = t;
+    keep->slot.assign(nb, 0);
+    keep->nsym = nsym;
+    keep->hist.swap(hist);
+    t = nullptr;
+  }
+  if (t) zmx_tables_free(ctx, t);
   return rc;
 }
 

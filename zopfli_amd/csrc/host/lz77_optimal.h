@@ -47,7 +47,8 @@ int Lz77OptimalBatch(zmx_ctx* ctx, const ZopfliOptions& options, const std::vect
                      std::vector<SymbolRun>* out, zmx_tables* parent = nullptr, OptimalKeep* keep = nullptr);
 
 // ZopfliLZ77OptimalFixed (squeeze.c:528): one DP run with the fixed-tree costs.
+// With `keep` as for Lz77OptimalBatch (the parse is in slot 0 of every block).
 int Lz77OptimalFixedBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks,
-                          std::vector<SymbolRun>* out);
+                          std::vector<SymbolRun>* out, OptimalKeep* keep = nullptr);
 
 }  // namespace zamd

@@ -3,6 +3,7 @@
 // plus the resident-input stream entry points used by bench.py and by the
 // multi-GPU gather.
 #include <chrono>
+#include <malloc.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -43,7 +44,26 @@ std::vector<zmx_ctx*> g_ctx;   // one per device the Zopfli* entry points use
 // the multi-device path is exercised on a one-GPU box); else ZOPFLI_AMD_DEVICE or LOCAL_RANK (one
 // process per GPU under torchrun) name the single device; else every visible device: master blocks
 // are independent (deflate.c:916-923), so a request with several of them is dealt across the devices.
+// ZOPFLI_AMD_KEEP_HEAP=1: freed host memory stays with the process (glibc: no mmap for large blocks, no trimming).
+// With block splitting the symbols of every block pass through host vectors (hundreds of MB per 100 MB of input),
+// and every munmap of a process with a few hundred worker threads is a TLB shootdown on all their CPUs: on
+// incompressible input (one symbol per byte) returning that memory took as long as the compression.  Opt-in: it
+// changes the allocator of the whole process.
+void MaybeKeepHeap() {
+  static const bool once = [] {
+    const char* e = std::getenv("ZOPFLI_AMD_KEEP_HEAP");
+    if (e && std::atoi(e) != 0) {
+      mallopt(M_MMAP_THRESHOLD, 1 << 30);
+      mallopt(M_TRIM_THRESHOLD, 1 << 30);
+      mallopt(M_TOP_PAD, 256 << 20);
+    }
+    return true;
+  }();
+  (void)once;
+}
+
 const std::vector<zmx_ctx*>& SharedContexts() {
+  MaybeKeepHeap();
   if (!g_ctx.empty()) return g_ctx;
   std::vector<int> devices;
   const int visible = zmx_device_count();
@@ -346,6 +366,7 @@ void ZopfliCompress(const ZopfliOptions* options, ZopfliFormat output_type, cons
 
 int zmx_deflate_range(zmx_ctx* ctx, const ZopfliOptions* options, size_t instart, size_t inend, int final,
                       unsigned char** blob, size_t* blobsize) {
+  MaybeKeepHeap();
   ResetTiming();
   if (inend < instart || inend > zmx_internal_input_size(ctx)) return -1;
   // deflate.c:916-923 on [instart, inend)

@@ -206,6 +206,11 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
     PartState& s = st[p];
     const size_t npoints = s.blocks.size() - 1;
     double totalcost = 0;
+    {
+      size_t total = 0;      // (one allocation for the part's store: appending block by block re-allocated it every time)
+      for (size_t i = 0; i <= npoints; ++i) total += runs[s.first_block + i].litlens.size();
+      s.lz77.Reserve(total);
+    }
     for (size_t i = 0; i <= npoints; ++i) {
       s.log += runs[s.first_block + i].log;       // "Iteration i: n bit" (squeeze.c:493), block after block
       Lz77Store bs = StoreFromRun(runs[s.first_block + i], s.blocks[i].instart);

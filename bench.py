@@ -20,7 +20,6 @@ import hashlib
 import json
 import os
 import sys
-import threading
 import time
 import zlib
 
@@ -153,7 +152,6 @@ def main():
     import torch.distributed as dist
 
     from zopfli_amd import Context, ZopfliOptions, api, generate, sharding
-    from zopfli_amd.sharding import crc32_combine
 
     dev_index = local_rank if args.device_index is None else args.device_index
     torch.cuda.set_device(dev_index)
@@ -252,10 +250,8 @@ def main():
     seg_acc = {}
 
     def step():
-        crc_box = [0]
-        th = threading.Thread(target=lambda: crc_box.__setitem__(0, zlib.crc32(shard)))
-        th.start()  # the checksum does not depend on the device work
         ta = time.perf_counter()
+        shard_crc = ctx.checksum(api.CRC32, instart, inend)   # k_checksum over the resident shard
         if inend > instart or total_bytes == 0:
             blob = ctx.deflate_range(options, instart, inend, final, as_array=True)   # the library's buffer, no copy
         else:
@@ -265,9 +261,8 @@ def main():
             timing_acc[k] = timing_acc.get(k, 0.0) + v
         for k, v in api.last_seg_stats(lib).items():
             seg_acc[k] = seg_acc.get(k, 0.0) + v
-        th.join()
         blobs = gather_blobs(blob)
-        crcs = gather_crc(crc_box[0])
+        crcs = gather_crc(shard_crc)
         tc = time.perf_counter()
         timing_acc["deflate_range_call"] = timing_acc.get("deflate_range_call", 0.0) + (tb - ta)
         timing_acc["gather"] = timing_acc.get("gather", 0.0) + (tc - tb)
@@ -275,7 +270,7 @@ def main():
             return None
         crc = crcs[0][0]
         for c, n in crcs[1:]:
-            crc = crc32_combine(crc, c, n)
+            crc = lib.zmx_checksum_combine(api.CRC32, crc, c, n)
         trailer = crc.to_bytes(4, "little") + (total_bytes & 0xffffffff).to_bytes(4, "little")
         # the gzip stream in one malloc'ed buffer, as a C caller of zmx_chunks_merge gets it
         out = ctx.merge([b for b in blobs if len(b)], header, trailer, as_array=True)

@@ -184,6 +184,17 @@ typedef struct zmx_enc_job {
 int zmx_encode_blocks(zmx_ctx* ctx, zmx_tables* tables, size_t njobs, const zmx_enc_job* jobs,
                       const uint32_t* codes, unsigned char* const* out);
 
+/* CRC-32 (gzip_container.c:75, the value ZopfliGzipCompress writes at :107-110) or Adler-32
+ * (zlib_container.c:29, written at :71-74) of bytes [begin, end) of the resident input
+ * (zmx_set_input), computed on the device; f-2 of SURVEY 8.  `value` is the finished checksum of
+ * the range on its own.  Ranges that lie on different devices or ranks are put together with
+ * zmx_checksum_combine(kind, checksum of A, checksum of B, bytes in B) = checksum of A followed
+ * by B (host arithmetic only, no context needed). */
+#define ZMX_CRC32 0
+#define ZMX_ADLER32 1
+int zmx_checksum(zmx_ctx* ctx, int kind, size_t begin, size_t end, uint32_t* value);
+uint32_t zmx_checksum_combine(int kind, uint32_t a, uint32_t b, uint64_t len_b);
+
 /* Parity probe: the ZopfliFindLongestMatch result for one position of one
  * block, expanded to the reference's sublen[259] convention. */
 int zmx_find_longest_match(zmx_ctx* ctx, zmx_tables* tables, size_t block, size_t pos,

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "zopfli_amd.h"
+#include "checksum.h"
 extern "C" {
 #include "zopfli_oracle.h"
 }
@@ -155,6 +156,46 @@ int zmx_verify_stores(zmx_ctx* c, zmx_tables* t, size_t n, const size_t* block, 
     }
     if (pos != d.blk.inend) { g_err = "zmx_verify_stores: coverage"; return -1; }
   }
+  return 0;
+}
+
+// (CPU stand-in for k_checksum: the same pieces, lanes and tree, walked one after the other, so that the
+// CPU suite exercises the arithmetic of host/checksum.cc the way the device feeds it)
+int zmx_checksum(zmx_ctx* c, int kind, size_t begin, size_t end, uint32_t* value) {
+  using namespace zamd;
+  if (kind != ZMX_CRC32 && kind != ZMX_ADLER32) { g_err = "zmx_checksum: unknown kind"; return -1; }
+  if (begin > end || end > c->input.size()) { g_err = "zmx_checksum: range outside the resident input"; return -1; }
+  const size_t n = end - begin, npieces = (n + kChecksumPieceBytes - 1) / kChecksumPieceBytes;
+  uint32_t xpow[8];
+  ChecksumTreePowers(xpow);
+  std::vector<ChecksumPiece> pieces(npieces);
+  for (size_t w = 0; w < npieces; ++w) {
+    const long long wg_end = static_cast<long long>(end) - static_cast<long long>(w) * kChecksumPieceBytes;
+    uint32_t cr[256], sa[256], sb[256];
+    for (int t = 0; t < 256; ++t) {
+      const long long hi = wg_end - static_cast<long long>(255 - t) * kChecksumLaneBytes;
+      long long p = hi - kChecksumLaneBytes;
+      if (p < static_cast<long long>(begin)) p = static_cast<long long>(begin);
+      uint32_t crc = 0, sum = 0, wsum = 0;
+      for (; p < hi; ++p) {
+        const uint32_t d = c->input[static_cast<size_t>(p)];
+        crc ^= d;
+        for (int k = 0; k < 8; ++k) crc = (crc & 1) ? (crc >> 1) ^ kCrcPoly : crc >> 1;
+        sum += d;
+        wsum += static_cast<uint32_t>(hi - p) * d;
+      }
+      cr[t] = crc; sa[t] = sum % kAdlerBase; sb[t] = wsum % kAdlerBase;
+    }
+    for (uint32_t s = 1, k = 0; s < 256; s <<= 1, ++k) {
+      for (uint32_t t = 0; t < 256; t += 2 * s) {
+        cr[t] = Gf2MulMod(cr[t], xpow[k]) ^ cr[t + s];
+        sb[t] = static_cast<uint32_t>((sb[t] + static_cast<uint64_t>((s * kChecksumLaneBytes) % kAdlerBase) * sa[t] + sb[t + s]) % kAdlerBase);
+        sa[t] = (sa[t] + sa[t + s]) % kAdlerBase;
+      }
+    }
+    pieces[w] = ChecksumPiece{cr[0], sa[0], sb[0]};
+  }
+  *value = kind == ZMX_CRC32 ? FinishCrc32(pieces.data(), npieces, n) : FinishAdler32(pieces.data(), npieces, n);
   return 0;
 }
 

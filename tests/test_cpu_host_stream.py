@@ -262,3 +262,38 @@ def test_verbose_text_equals_the_references(more):
         texts.append(r.stderr)
     assert "block split points" in texts[1] and "treesize" in texts[1] and "Iteration" in texts[1]
     assert texts[0] == texts[1]
+
+
+def _checksum_cases(n):
+    """(begin, end) ranges around every boundary of k_checksum's geometry (1 KiB lanes, 256 KiB pieces,
+    4-byte body loads), for an input of n bytes"""
+    import random
+    rng = random.Random(7)
+    marks = [0, 1, 2, 3, 4, 5, 1023, 1024, 1025, 2048, 262143, 262144, 262145, 524288, n - 262144, n - 1025, n - 3, n - 1, n]
+    marks = sorted({m for m in marks if 0 <= m <= n})
+    cases = [(a, b) for a in marks for b in marks if a <= b]
+    cases += [tuple(sorted((rng.randrange(n + 1), rng.randrange(n + 1)))) for _ in range(40)]
+    return cases
+
+
+def test_checksum_pieces_and_combine(host):
+    """zmx_checksum's piece arithmetic (host/checksum.cc, fed by the CPU stand-in of k_checksum with the
+    device's geometry) against zlib's crc32 / adler32: gzip_container.c:75, zlib_container.c:29."""
+    from zopfli_amd import Context
+    data = generate("X", 300000) + generate("R", 300000) + bytes(200000) + b"\xff" * 70000
+    ctx = Context(0, host)
+    try:
+        ctx.set_input(data)
+        for a, b in _checksum_cases(len(data)):
+            assert ctx.checksum(api.CRC32, a, b) == zlib.crc32(data[a:b]), (a, b)
+            assert ctx.checksum(api.ADLER32, a, b) == zlib.adler32(data[a:b]), (a, b)
+        with pytest.raises(RuntimeError):
+            ctx.checksum(api.CRC32, 5, len(data) + 1)
+        with pytest.raises(RuntimeError):
+            ctx.checksum(7, 0, 1)
+    finally:
+        ctx.close()
+    for cut in (0, 1, 1000, 262144, 600001, len(data)):
+        left, right = data[:cut], data[cut:]
+        assert host.zmx_checksum_combine(api.CRC32, zlib.crc32(left), zlib.crc32(right), len(right)) == zlib.crc32(data)
+        assert host.zmx_checksum_combine(api.ADLER32, zlib.adler32(left), zlib.adler32(right), len(right)) == zlib.adler32(data)

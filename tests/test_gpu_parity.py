@@ -404,6 +404,33 @@ def test_device_bit_writer(gpu_ctx, cls):
     t.free()
 
 
+def test_device_checksums(gpu_ctx, gpu_lib):
+    """k_checksum: CRC-32 and Adler-32 of ranges of the resident input against zlib's, around
+    every boundary of the kernel's geometry (4-byte body loads, 1 KiB lanes, 256 KiB pieces), at the bench's
+    size, and through the containers (gzip_container.c:75,107-110; zlib_container.c:29,71-74)."""
+    from test_cpu_host_stream import _checksum_cases
+    data = generate("X", 300000) + generate("R", 300000) + bytes(200000) + b"\xff" * 70000
+    gpu_ctx.set_input(data)
+    for a, b in _checksum_cases(len(data)):
+        assert gpu_ctx.checksum(api.CRC32, a, b) == zlib.crc32(data[a:b]), (a, b)
+        assert gpu_ctx.checksum(api.ADLER32, a, b) == zlib.adler32(data[a:b]), (a, b)
+    with pytest.raises(RuntimeError):
+        gpu_ctx.checksum(api.CRC32, 0, len(data) + 1)
+    big = generate("T", 100000000)
+    gpu_ctx.set_input(big)
+    assert gpu_ctx.checksum(api.CRC32, 0, len(big)) == zlib.crc32(big)
+    assert gpu_ctx.checksum(api.ADLER32, 0, len(big)) == zlib.adler32(big)
+    assert gpu_ctx.checksum(api.CRC32, 32768, len(big) - 5) == zlib.crc32(big[32768:-5])
+    small = generate("M", 70001)
+    z = api.compress(small, 1, ZopfliOptions(1), lib=gpu_lib)
+    assert z[-4:] == zlib.adler32(small).to_bytes(4, "big") and zlib.decompress(z) == small
+    g = api.compress(small, 0, ZopfliOptions(1), lib=gpu_lib)
+    assert g[-8:-4] == zlib.crc32(small).to_bytes(4, "little") and gzip.decompress(g) == small
+    for empty_fmt, tail in ((0, bytes(8)), (1, (1).to_bytes(4, "big"))):
+        e = api.compress(b"", empty_fmt, ZopfliOptions(1), lib=gpu_lib)
+        assert e.endswith(tail)
+
+
 def test_verify_pass(gpu_ctx):
     """ZopfliVerifyLenDist on the device (lz77.c:270-295): a greedy and an optimal parse pass; the same symbols read
     against another input, or one symbol short, do not."""

@@ -5,6 +5,7 @@ import os
 from ._build import LIB
 
 FORMAT_GZIP, FORMAT_ZLIB, FORMAT_DEFLATE = 0, 1, 2  # zopfli.h:70-74
+CRC32, ADLER32 = 0, 1  # ZMX_CRC32, ZMX_ADLER32
 ZMX_HIST = 320
 
 
@@ -89,6 +90,9 @@ def bind(lib):
     lib.zmx_length_array_download.argtypes = [vp, vp, sz, P(ctypes.c_uint16)]
     lib.zmx_hash_links_download.argtypes = [vp, vp, sz, P(ctypes.c_uint16), P(ctypes.c_uint16), P(ctypes.c_uint16)]
     lib.zmx_deflate_range.argtypes = [vp, opt, sz, sz, ctypes.c_int, P(_u8p), P(sz)]
+    lib.zmx_checksum.argtypes = [vp, ctypes.c_int, sz, sz, P(ctypes.c_uint32)]
+    lib.zmx_checksum_combine.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64]
+    lib.zmx_checksum_combine.restype = ctypes.c_uint32
     lib.zmx_chunks_merge.argtypes = [P(vp), P(sz), sz, P(ctypes.c_ubyte), P(_u8p), P(sz)]
     lib.zmx_last_timing.argtypes = [P(ctypes.c_double)]
     lib.zmx_last_kernel_timing.argtypes = [P(ctypes.c_double)]
@@ -214,6 +218,12 @@ class Context:
             self._check(self.lib.zmx_tables_build_from(self.handle, parent.handle, arr, len(blocks), ctypes.byref(t)),
                         "zmx_tables_build_from")
         return Tables(self, t, list(blocks))
+
+    def checksum(self, kind, begin, end):
+        """zmx_checksum: CRC-32 (kind CRC32) or Adler-32 (ADLER32) of resident bytes [begin, end), on the device."""
+        v = ctypes.c_uint32(0)
+        self._check(self.lib.zmx_checksum(self.handle, kind, begin, end, ctypes.byref(v)), "zmx_checksum")
+        return v.value
 
     def deflate_range(self, options, instart, inend, final=1, as_array=False):
         """zmx_deflate_range: serialised chunks of ZopfliDeflate over resident bytes [instart, inend).

@@ -19,6 +19,7 @@
 #include "zmx_dp4.h"
 #include "zmx_dp5.h"
 #include "zmx_encode.h"
+#include "zmx_checksum.h"
 #include "zmx_trace.h"
 #include "zmx_greedy.h"
 #include "zopfli_amd.h"
@@ -1209,6 +1210,34 @@ int zmx_verify_stores(zmx_ctx* c, zmx_tables* t, size_t n, const size_t* block, 
     g_err = msg;
     return -1;
   }
+  return 0;
+}
+
+int zmx_checksum(zmx_ctx* c, int kind, size_t begin, size_t end, uint32_t* value) {
+  if (kind != ZMX_CRC32 && kind != ZMX_ADLER32) return FailMsg("zmx_checksum: unknown kind");
+  if (begin > end || end > c->insize) return FailMsg("zmx_checksum: range outside the resident input");
+  const size_t n = end - begin;
+  const size_t npieces = (n + zamd::kChecksumPieceBytes - 1) / zamd::kChecksumPieceBytes;
+  std::vector<zamd::ChecksumPiece> pieces(npieces);
+  if (npieces) {
+    DeviceGuard dev_guard(c->device);
+    HIPCHK(dev_guard.err);
+    PoolScope tmp(c);
+    u32* d_out = nullptr;
+    HIPCHK(tmp.Alloc(&d_out, 3 * npieces));
+    ChecksumParams P;
+    P.in = c->d_in;
+    P.begin = static_cast<long long>(begin);
+    P.end = static_cast<long long>(end);
+    P.out = d_out;
+    zamd::ChecksumTreePowers(P.xpow);
+    hipLaunchKernelGGL(k_checksum, dim3(static_cast<unsigned>(npieces)), dim3(256), 0, c->stream, P);
+    HIPCHK(hipGetLastError());
+    static_assert(sizeof(zamd::ChecksumPiece) == 12, "three words per piece");
+    HIPCHK(hipMemcpyAsync(pieces.data(), d_out, npieces * sizeof(zamd::ChecksumPiece), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  *value = kind == ZMX_CRC32 ? zamd::FinishCrc32(pieces.data(), npieces, n) : zamd::FinishAdler32(pieces.data(), npieces, n);
   return 0;
 }
 

@@ -145,8 +145,18 @@ int RunParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const std::v
 // runs, one host thread per device; each device gets its parts' bytes plus the 32 KiB before them
 // (all a part reads: lz77.c:551-552).  Chunks come back in stream order, stored chunks carrying
 // positions relative to `in`.
+//
+// `sum` (optional): the container's checksum over in[0, sum->limit), taken on the devices from the bytes
+// they hold anyway — each device its own parts' bytes, put together in stream order.
+struct ChecksumRequest {
+  int kind;         // ZMX_CRC32 / ZMX_ADLER32
+  size_t limit;     // bytes covered (the parts must start at 0 and cover them)
+  uint32_t value;
+};
+
 int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char* in,
-                    const std::vector<zamd::Part>& parts, std::vector<zamd::Chunk>* chunks) {
+                    const std::vector<zamd::Part>& parts, std::vector<zamd::Chunk>* chunks,
+                    ChecksumRequest* sum = nullptr) {
   const std::vector<zmx_ctx*>& ctxs = SharedContexts();
   const size_t ndev = std::min(ctxs.size(), parts.size());
   struct Shard {
@@ -155,6 +165,8 @@ int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char
     int rc = 0;
     std::string err;
     zamd::Timing timing;
+    uint32_t sum = 0;
+    size_t sum_bytes = 0;
   };
   std::vector<Shard> shards(ndev);
   for (size_t d = 0; d < ndev; ++d) {
@@ -169,6 +181,14 @@ int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char
       sh.rc = -1;
       sh.err = zmx_last_error();
       return;
+    }
+    if (sum && start < sum->limit) {
+      sh.sum_bytes = std::min(end, sum->limit) - start;
+      if (zmx_checksum(ctxs[d], sum->kind, start - sh.base, start - sh.base + sh.sum_bytes, &sh.sum) != 0) {
+        sh.rc = -1;
+        sh.err = zmx_last_error();
+        return;
+      }
     }
     std::vector<zamd::Part> mine(parts.begin() + static_cast<long>(sh.first), parts.begin() + static_cast<long>(sh.last));
     for (auto& p : mine) { p.instart -= sh.base; p.inend -= sh.base; }
@@ -201,6 +221,12 @@ int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char
     }
     for (auto& c : sh.chunks) chunks->push_back(std::move(c));
   }
+  if (sum) {
+    sum->value = sum->kind == ZMX_ADLER32 ? 1u : 0u;   // of no bytes
+    for (auto& sh : shards) {
+      if (sh.sum_bytes) sum->value = zmx_checksum_combine(sum->kind, sum->value, sh.sum, sh.sum_bytes);
+    }
+  }
   return 0;
 }
 
@@ -221,51 +247,6 @@ void ResetTiming() {
 void PushByte(unsigned v, unsigned char** out, size_t* outsize) {
   const uint8_t b = static_cast<uint8_t>(v);
   zamd::AppendToOutput(&b, 1, out, outsize);
-}
-
-// CRC-32 (poly 0xedb88320), slicing-by-8; same value as gzip_container.c:75.
-uint32_t Crc32(const unsigned char* data, size_t size) {
-  static uint32_t table[8][256];
-  static std::once_flag once;
-  std::call_once(once, [] {
-    for (uint32_t i = 0; i < 256; ++i) {
-      uint32_t c = i;
-      for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1;
-      table[0][i] = c;
-    }
-    for (uint32_t i = 0; i < 256; ++i) {
-      for (int t = 1; t < 8; ++t) table[t][i] = table[0][table[t - 1][i] & 255] ^ (table[t - 1][i] >> 8);
-    }
-  });
-  uint32_t c = 0xffffffffu;
-  while (size >= 8) {
-    uint32_t lo, hi;
-    std::memcpy(&lo, data, 4);
-    std::memcpy(&hi, data + 4, 4);
-    lo ^= c;
-    c = table[7][lo & 255] ^ table[6][(lo >> 8) & 255] ^ table[5][(lo >> 16) & 255] ^ table[4][lo >> 24] ^
-        table[3][hi & 255] ^ table[2][(hi >> 8) & 255] ^ table[1][(hi >> 16) & 255] ^ table[0][hi >> 24];
-    data += 8;
-    size -= 8;
-  }
-  for (; size; --size) c = table[0][(c ^ *data++) & 255] ^ (c >> 8);
-  return c ^ 0xffffffffu;
-}
-
-// Adler-32 (zlib_container.c:29)
-uint32_t Adler32(const unsigned char* data, size_t size) {
-  uint32_t s1 = 1, s2 = 0;
-  while (size > 0) {
-    size_t n = size > 5550 ? 5550 : size;
-    size -= n;
-    for (; n; --n) {
-      s1 += *data++;
-      s2 += s1;
-    }
-    s1 %= 65521;
-    s2 %= 65521;
-  }
-  return (s2 << 16) | s1;
 }
 
 }  // namespace
@@ -293,15 +274,17 @@ void ZopfliDeflatePart(const ZopfliOptions* options, int btype, int final, const
   EmitChunks(chunks, in, bp, out, outsize, options->verbose != 0);
 }
 
-void ZopfliDeflate(const ZopfliOptions* options, int btype, int final, const unsigned char* in,
-                   size_t insize, unsigned char* bp, unsigned char** out, size_t* outsize) {
+namespace {
+// ZopfliDeflate (deflate.c:908-931); `sum`: see RunPartsSharded
+void DeflateWhole(const ZopfliOptions* options, int btype, int final, const unsigned char* in, size_t insize,
+                  unsigned char* bp, unsigned char** out, size_t* outsize, ChecksumRequest* sum) {
   const size_t offset = *outsize;
   {
     std::lock_guard<std::mutex> lock(g_mutex);
     ResetTiming();
     const std::vector<zamd::Part> parts = MasterBlocks(insize, final != 0);
     std::vector<zamd::Chunk> chunks;
-    if (RunPartsSharded(*options, btype, in, parts, &chunks) != 0) Die("device error");
+    if (RunPartsSharded(*options, btype, in, parts, &chunks, sum) != 0) Die("device error");
     EmitChunks(chunks, in, bp, out, outsize, options->verbose != 0);
   }
   if (options->verbose) {
@@ -310,17 +293,22 @@ void ZopfliDeflate(const ZopfliOptions* options, int btype, int final, const uns
                  100.0 * static_cast<double>(insize - (*outsize - offset)) / static_cast<double>(insize));
   }
 }
+}  // namespace
+
+void ZopfliDeflate(const ZopfliOptions* options, int btype, int final, const unsigned char* in,
+                   size_t insize, unsigned char* bp, unsigned char** out, size_t* outsize) {
+  DeflateWhole(options, btype, final, in, insize, bp, out, outsize, nullptr);
+}
 
 void ZopfliGzipCompress(const ZopfliOptions* options, const unsigned char* in, size_t insize,
                         unsigned char** out, size_t* outsize) {
-  // the checksum does not depend on the device work: overlap it
-  uint32_t crc = 0;
-  std::thread crc_thread([&] { crc = Crc32(in, insize); });
+  // the CRC is taken on the device(s) from the resident input (zmx_checksum)
+  ChecksumRequest sum{ZMX_CRC32, insize, 0};
   unsigned char bp = 0;
   static const unsigned char header[10] = {31, 139, 8, 0, 0, 0, 0, 0, 2, 3};  // gzip_container.c:90-101
   zamd::AppendToOutput(header, 10, out, outsize);
-  ZopfliDeflate(options, 2, 1, in, insize, &bp, out, outsize);
-  crc_thread.join();
+  DeflateWhole(options, 2, 1, in, insize, &bp, out, outsize, &sum);
+  const uint32_t crc = sum.value;
   for (int i = 0; i < 4; ++i) PushByte((crc >> (8 * i)) & 255, out, outsize);
   for (int i = 0; i < 4; ++i) PushByte((insize >> (8 * i)) & 255, out, outsize);
   if (options->verbose) {
@@ -331,17 +319,16 @@ void ZopfliGzipCompress(const ZopfliOptions* options, const unsigned char* in, s
 
 void ZopfliZlibCompress(const ZopfliOptions* options, const unsigned char* in, size_t insize,
                         unsigned char** out, size_t* outsize) {
-  uint32_t checksum = 0;
   // the reference truncates the size to unsigned here (zlib_container.c:54)
-  std::thread sum_thread([&] { checksum = Adler32(in, static_cast<unsigned>(insize)); });
+  ChecksumRequest sum{ZMX_ADLER32, static_cast<unsigned>(insize), 0};
   unsigned char bp = 0;
   const unsigned cmf = 120, flevel = 3, fdict = 0;  // CM 8, CINFO 7
   unsigned cmfflg = 256 * cmf + fdict * 32 + flevel * 64;
   cmfflg += 31 - cmfflg % 31;
   PushByte(cmfflg / 256, out, outsize);
   PushByte(cmfflg % 256, out, outsize);
-  ZopfliDeflate(options, 2, 1, in, insize, &bp, out, outsize);
-  sum_thread.join();
+  DeflateWhole(options, 2, 1, in, insize, &bp, out, outsize, &sum);
+  const uint32_t checksum = sum.value;
   for (int i = 3; i >= 0; --i) PushByte((checksum >> (8 * i)) & 255, out, outsize);
   if (options->verbose) {
     std::fprintf(stderr, "Original Size: %d, Zlib: %d, Compression: %f%% Removed\n", static_cast<int>(insize),

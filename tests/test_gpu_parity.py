@@ -232,6 +232,7 @@ CHAIN_ENVS = [
     ({"ZOPFLI_AMD_INT_PATH": "0"}, lambda st: st["accepted"] > 0),                              # every window in the reference's doubles
     ({"ZOPFLI_AMD_FIX_LEAN": "0"}, lambda st: st["rerun_state"] > 0),                           # serial re-runs by the lean one-wave job
     ({"ZOPFLI_AMD_SEG_REDO": "0"}, lambda st: st["rerun_level"] > 0),                           # no second speculative pass
+    ({"ZOPFLI_AMD_MATCH_FILTER": "0"}, lambda st: st["accepted"] > 0),                          # k_match2 with the one-byte candidate test
 ]
 
 

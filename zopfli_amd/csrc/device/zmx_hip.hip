@@ -202,6 +202,12 @@ hipError_t PoolAlloc(zmx_ctx* c, T** p, size_t n) {
 }
 
 // Temporary arrays of one call: back to the pool when the call returns, whichever way (HIPCHK returns early).
+// k_match2's four-byte candidate filter (zmx_match2.h, FILT); ZOPFLI_AMD_MATCH_FILTER=0 keeps the one-byte test
+bool MatchFilter() {
+  static const bool on = [] { const char* e = std::getenv("ZOPFLI_AMD_MATCH_FILTER"); return e ? std::atoi(e) != 0 : true; }();
+  return on;
+}
+
 struct PoolScope {
   zmx_ctx* c;
   std::vector<void*> held;
@@ -566,7 +572,8 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     mp.scratch = c->d_scratch;
     mp.tile_list = d_tile_list;
     if (mp.total_tiles > 0) {
-      hipLaunchKernelGGL(k_match2<false>, dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
+      if (MatchFilter()) hipLaunchKernelGGL((k_match2<false, true>), dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
+      else hipLaunchKernelGGL((k_match2<false, false>), dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
       HIPCHK(hipGetLastError());
     }
     u32 counters[2] = {0, 0};
@@ -612,8 +619,11 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     mp.tile_list = nullptr;
     if (mp.total_tiles > 0) {
       static const bool match_prof = std::getenv("ZOPFLI_AMD_PROF") != nullptr;
-      if (match_prof) hipLaunchKernelGGL(k_match2<true>, dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
-      else hipLaunchKernelGGL(k_match2<false>, dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
+      const bool filt = MatchFilter();
+      if (match_prof && filt) hipLaunchKernelGGL((k_match2<true, true>), dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
+      else if (match_prof) hipLaunchKernelGGL((k_match2<true, false>), dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
+      else if (filt) hipLaunchKernelGGL((k_match2<false, true>), dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
+      else hipLaunchKernelGGL((k_match2<false, false>), dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
       HIPCHK(hipGetLastError());
     }
     u32 counters[2] = {0, 0};

@@ -19,7 +19,23 @@
 
 // PROF: counts the chain hits (candidates visited, lz77.c:464-530) and the iterations of the wave loop into
 // P.counters[4..7] (two 64-bit sums) — ZOPFLI_AMD_PROF prints hits per position and cycles per hit.
-template <bool PROF>
+//
+// FILT: the one-byte test reads the four bytes that END at offset bestlength instead (the candidate cannot beat
+// bestlength unless all of them match — a candidate the reference compares and then drops because it is not
+// longer, lz77.c:494, is dropped here without the compare: same results, and the byte-compare side block runs in
+// fewer of the wave's steps), and the compare reads 8 bytes per side with one unaligned LDS load each.
+__device__ __forceinline__ u32 m2_lds_u32(const u32* win, u32 byte_off) {
+  u32 x;
+  __builtin_memcpy(&x, reinterpret_cast<const char*>(win) + byte_off, 4);
+  return x;
+}
+__device__ __forceinline__ u64 m2_lds_u64(const u32* win, u32 byte_off) {
+  u64 x;
+  __builtin_memcpy(&x, reinterpret_cast<const char*>(win) + byte_off, 8);
+  return x;
+}
+
+template <bool PROF, bool FILT>
 __global__ __launch_bounds__(M2_THREADS, 8) void k_match2(MatchParams P) {
   __shared__ __align__(16) u32 win[MWIN_BYTES / 4 + 4];
   __shared__ u32 s_next, s_tile;
@@ -81,10 +97,10 @@ __global__ __launch_bounds__(M2_THREADS, 8) void k_match2(MatchParams P) {
     u32 lp = 0, lc = 0;            // LDS byte offsets of the position and of the candidate
     u32 li = 0;                    // link index of the position
     u32 limit = 0, bestlen = 0, bestdist = 0, dist = 0, ncp = 0, same_pos = 0, cur = 0, size_rem = 0;
-    u32 byte0 = 0, pbyte = 0;      // in[pos], in[pos + bestlen]
+    u32 byte0 = 0, pbyte = 0;      // in[pos], in[pos + bestlen] (FILT: the four bytes in[pos + foff ..], of which fmask count)
+    u32 foff = 0, fmask = 0;
     u32 hits_left = 0, chain = 1;
     uint2 L = make_uint2(0, 0);    // link record of the candidate
-    u32* rec = rec0;
     u32 n_hits = 0, n_iter = 0;
     // the first 8 change points of sublen (3 bytes each: length - 3, distance) as they will lie in the record:
     // built in registers, written with the record in two 16-byte stores (byte stores into HBM as they were
@@ -125,6 +141,7 @@ __global__ __launch_bounds__(M2_THREADS, 8) void k_match2(MatchParams P) {
               r0.w = 0;
             }
           }
+          u32* const rec = rec0 + (u64)(lp - lp0) * 8;
           reinterpret_cast<uint4*>(rec)[0] = r0;
           reinterpret_cast<uint4*>(rec)[1] = r1;
         }
@@ -136,7 +153,7 @@ __global__ __launch_bounds__(M2_THREADS, 8) void k_match2(MatchParams P) {
             lp = lp0 + idx;
             li = li0 + idx;
             size_rem = rem0 - idx;               // saturated: only compared with 3 and 258
-            rec = rec0 + (u64)idx * 8;
+            u32* const rec = rec0 + (u64)idx * 8;
             const uint2 Lp = lk[li];
             same_pos = Lp.y & 0xffffu;
             byte0 = lds_byte(win, lp);
@@ -155,7 +172,8 @@ __global__ __launch_bounds__(M2_THREADS, 8) void k_match2(MatchParams P) {
               } else {
                 lc = lp - dist;
                 L = lk[li - dist];
-                pbyte = lds_byte(win, lp + 1);
+                if (FILT) { pbyte = m2_lds_u32(win, lp); foff = 0; fmask = 0xffffu; }   // bestlength 1: bytes 0 and 1
+                else pbyte = lds_byte(win, lp + 1);
                 st = M2_WALK;
               }
             }
@@ -170,8 +188,16 @@ __global__ __launch_bounds__(M2_THREADS, 8) void k_match2(MatchParams P) {
 
       // ---- the candidate's one-byte test (lz77.c:478-479)
       const bool walk = st == M2_WALK;
-      const u32 cb = lds_byte(win, walk ? lc + bestlen : 0u);
-      const bool pass = walk && (bestlen >= size_rem || cb == pbyte);
+      bool pass;
+      if (FILT) {
+        const u32 cw = m2_lds_u32(win, walk ? lc + foff : 0u);
+        // (bestlength >= size - pos, the other half of lz77.c:478, cannot hold here: bestlength <= limit <= size - pos,
+        // and the walk ends when bestlength reaches limit)
+        pass = walk && ((cw ^ pbyte) & fmask) == 0;
+      } else {
+        const u32 cb = lds_byte(win, walk ? lc + bestlen : 0u);
+        pass = walk && (bestlen >= size_rem || cb == pbyte);
+      }
       bool ev = walk && !pass;                       // rejected: nothing to record, move on
       if (pass) {
         // lz77.c:481-490: skip the common run (pure acceleration)
@@ -187,7 +213,13 @@ __global__ __launch_bounds__(M2_THREADS, 8) void k_match2(MatchParams P) {
       if (st == M2_CMP) {  // GetMatch (lz77.c:297), 8 bytes per step (markup and source code: matches of 50+ bytes)
         const u32 rem = limit - cur;
         bool end = rem == 0;
-        if (!end) {
+        if (!end && FILT) {
+          const u64 x = m2_lds_u64(win, lp + cur) ^ m2_lds_u64(win, lc + cur);
+          u32 m = x ? (u32)(__ffsll((unsigned long long)x) - 1) >> 3 : 8u;
+          if (m > rem) m = rem;
+          cur += m;
+          end = m < 8 || cur >= limit;
+        } else if (!end) {
           const u32 a0 = (lp + cur) >> 2, b0 = (lc + cur) >> 2, as = (lp + cur) & 3u, bs = (lc + cur) & 3u;
           const u32 a_lo = win[a0], a_mi = win[a0 + 1], a_hi = win[a0 + 2];
           const u32 b_lo = win[b0], b_mi = win[b0 + 1], b_hi = win[b0 + 2];
@@ -219,7 +251,13 @@ __global__ __launch_bounds__(M2_THREADS, 8) void k_match2(MatchParams P) {
             bestlen = cur;
             bestdist = dist;
             fin = cur >= limit;
-            if (cur < size_rem) pbyte = lds_byte(win, lp + cur);
+            if (FILT) {
+              foff = cur >= 3 ? cur - 3u : 0u;
+              fmask = cur >= 3 ? 0xffffffffu : 0xffffffu;    // (cur = 2: bytes 0..2)
+              pbyte = m2_lds_u32(win, lp + foff);
+            } else if (cur < size_rem) {
+              pbyte = lds_byte(win, lp + cur);
+            }
           }
         }
       }

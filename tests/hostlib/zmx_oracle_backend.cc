@@ -12,7 +12,11 @@
 #include <vector>
 
 #include "zopfli_amd.h"
+#include "block_cost.h"
+#include "block_split.h"
 #include "checksum.h"
+#include "huffman.h"
+#include "lz77_store.h"
 extern "C" {
 #include "zopfli_oracle.h"
 }
@@ -247,6 +251,29 @@ int zmx_length_array_download(zmx_ctx*, zmx_tables* t, size_t block, uint16_t* o
   const auto& la = t->blocks[block].length_array;
   std::memcpy(out, la.data(), la.size() * 2);
   return 0;
+}
+
+// ---- hooks for unit tests of the product's host arithmetic against the real reference
+// (tests/test_cpu_oracle_vs_reference.py)
+__attribute__((visibility("default"))) int zamd_test_code_lengths(const size_t* freq, int n, int maxbits, unsigned* lengths) {
+  return zamd::LengthLimitedCodeLengths(freq, n, maxbits, lengths) ? 0 : 1;
+}
+
+__attribute__((visibility("default"))) double zamd_test_block_size_auto(const uint16_t* litlens, const uint16_t* dists, size_t n,
+                                                                          size_t lstart, size_t lend) {
+  zamd::Lz77Store s(nullptr);
+  s.Append(litlens, dists, n, 0);
+  return zamd::CalculateBlockSizeAutoType(s, lstart, lend);
+}
+
+__attribute__((visibility("default"))) size_t zamd_test_block_split(const uint16_t* litlens, const uint16_t* dists, size_t n,
+                                                                      size_t maxblocks, size_t* points, size_t cap) {
+  zamd::Lz77Store s(nullptr);
+  s.Append(litlens, dists, n, 0);
+  std::vector<size_t> pts;
+  zamd::BlockSplitLz77(s, maxblocks, &pts);
+  for (size_t i = 0; i < pts.size() && i < cap; ++i) points[i] = pts[i];
+  return pts.size();
 }
 
 }  // extern "C"

@@ -240,6 +240,15 @@ def ref():
                                          ctypes.POINTER(RefStore), ctypes.POINTER(RefHash)]
         lib.ZopfliLZ77OptimalFixed.argtypes = [ctypes.POINTER(RefBlockState), ctypes.c_char_p, sz, sz,
                                                ctypes.POINTER(RefStore)]
+        lib.ZopfliStoreLitLenDist.argtypes = [ctypes.c_ushort, ctypes.c_ushort, sz, ctypes.POINTER(RefStore)]
+        lib.ZopfliStoreLitLenDist.restype = None
+        lib.ZopfliLengthLimitedCodeLengths.argtypes = [ctypes.POINTER(sz), ctypes.c_int, ctypes.c_int,
+                                                       ctypes.POINTER(ctypes.c_uint)]
+        lib.ZopfliCalculateBlockSizeAutoType.argtypes = [ctypes.POINTER(RefStore), sz, sz]
+        lib.ZopfliCalculateBlockSizeAutoType.restype = ctypes.c_double
+        lib.ZopfliBlockSplitLZ77.argtypes = [ctypes.POINTER(RefOptions), ctypes.POINTER(RefStore), sz,
+                                             ctypes.POINTER(ctypes.POINTER(sz)), ctypes.POINTER(sz)]
+        lib.ZopfliBlockSplitLZ77.restype = None
         for n in ("ZopfliAllocHash", "ZopfliResetHash", "ZopfliCleanHash", "ZopfliWarmupHash", "ZopfliUpdateHash",
                   "ZopfliInitLZ77Store", "ZopfliCleanLZ77Store", "ZopfliInitBlockState", "ZopfliCleanBlockState",
                   "ZopfliLZ77Greedy", "ZopfliLZ77OptimalFixed"):
@@ -314,6 +323,41 @@ def ref_greedy(data, instart, inend):
     lib.ZopfliCleanBlockState(ctypes.byref(s))
     lib.ZopfliCleanHash(ctypes.byref(h))
     return ll, dd
+
+
+class RefSymbols:
+    """A ZopfliLZ77Store of the real reference filled from (litlen, dist) arrays (lz77.c:98)."""
+
+    def __init__(self, litlens, dists):
+        self.lib = ref()
+        self.store = RefStore()
+        self.lib.ZopfliInitLZ77Store(b"", ctypes.byref(self.store))
+        pos = 0
+        for l, d in zip(litlens.tolist(), dists.tolist()):
+            self.lib.ZopfliStoreLitLenDist(l, d, pos, ctypes.byref(self.store))
+            pos += 1 if d == 0 else l
+
+    def block_size_auto(self, lstart, lend):
+        return self.lib.ZopfliCalculateBlockSizeAutoType(ctypes.byref(self.store), lstart, lend)
+
+    def block_split(self, maxblocks):
+        o = RefOptions(0, 0, 15, 1, 0, 15)
+        pts, n = ctypes.POINTER(ctypes.c_size_t)(), ctypes.c_size_t(0)
+        self.lib.ZopfliBlockSplitLZ77(ctypes.byref(o), ctypes.byref(self.store), maxblocks, ctypes.byref(pts), ctypes.byref(n))
+        out = [pts[i] for i in range(n.value)]
+        _libc.free(ctypes.cast(pts, ctypes.c_void_p))
+        return out
+
+    def close(self):
+        self.lib.ZopfliCleanLZ77Store(ctypes.byref(self.store))
+
+
+def ref_code_lengths(freq, maxbits):
+    n = len(freq)
+    f = (ctypes.c_size_t * n)(*[int(x) for x in freq])
+    out = (ctypes.c_uint * n)()
+    rc = ref().ZopfliLengthLimitedCodeLengths(f, n, maxbits, out)
+    return rc, list(out)
 
 
 def ref_optimal_fixed(data, instart, inend):

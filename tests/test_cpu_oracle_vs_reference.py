@@ -41,3 +41,70 @@ def test_greedy_and_fixed(cls, n, instart):
     _, sl, sd = t.squeeze_run(fll, fd, ol.model_min_cost(fll, fd))
     rl, rd = ol.ref_optimal_fixed(data, instart, n)
     assert np.array_equal(sl, rl) and np.array_equal(sd, rd)
+
+
+def test_host_code_lengths_vs_reference():
+    """The product's length-limited code lengths (host/huffman.cc) == ZopfliLengthLimitedCodeLengths
+    (katajainen.c:172) on random histograms of the three alphabets: ties, long tails that hit the length
+    limit, sparse and dense counts."""
+    import ctypes
+    host = ol.hosttest_library()
+    host.zamd_test_code_lengths.argtypes = [ctypes.POINTER(ctypes.c_size_t), ctypes.c_int, ctypes.c_int,
+                                            ctypes.POINTER(ctypes.c_uint)]
+    rng = np.random.default_rng(5)
+    for it in range(1500):
+        n, maxbits = ((288, 15), (32, 15), (19, 7))[it % 3]
+        style = (it // 3) % 5
+        if style == 0:
+            f = rng.integers(0, 1000, n)
+        elif style == 1:
+            f = rng.integers(0, 3, n)
+        elif style == 2:
+            # (below 2^22: the reference's comparator returns a difference of keys = weight << 9 as an int,
+            # katajainen.c:146-148, so its order is only defined while counts differ by less than that —
+            # always, inside the 1 MB master blocks of ZopfliDeflate)
+            f = 1 << rng.integers(0, 22, n)
+        elif style == 3:
+            f = np.where(rng.random(n) < 0.7, 0, rng.integers(1, 100000, n))
+        else:
+            f = np.where(np.arange(n) < rng.integers(0, n + 1), rng.integers(1, 8, n), 0)
+        rc, want = ol.ref_code_lengths(f, maxbits)
+        arr = (ctypes.c_size_t * n)(*[int(x) for x in f])
+        out = (ctypes.c_uint * n)()
+        got_rc = host.zamd_test_code_lengths(arr, n, maxbits, out)
+        assert (got_rc != 0) == (rc != 0), (it, f)
+        if rc == 0:
+            assert list(out) == want, (it, list(f))
+
+
+@pytest.mark.parametrize("cls,n", [("T", 60000), ("X", 40000), ("M", 90000), ("Z", 30000), ("R", 8000), ("B", 20000)])
+def test_host_block_size_and_split_vs_reference(cls, n):
+    """CalculateBlockSizeAutoType (deflate.c:610; host/block_cost.cc) over random symbol ranges of a greedy
+    parse, and the split points of ZopfliBlockSplitLZ77 (blocksplitter.c:215; host/block_split.cc)."""
+    import ctypes
+    host = ol.hosttest_library()
+    u16p, sz = ctypes.POINTER(ctypes.c_uint16), ctypes.c_size_t
+    host.zamd_test_block_size_auto.argtypes = [u16p, u16p, sz, sz, sz]
+    host.zamd_test_block_size_auto.restype = ctypes.c_double
+    host.zamd_test_block_split.argtypes = [u16p, u16p, sz, sz, ctypes.POINTER(sz), sz]
+    host.zamd_test_block_split.restype = sz
+    data = generate(cls, n)
+    ll, dd = ol.OracleTable(data, 0, n).greedy()
+    ll, dd = np.ascontiguousarray(ll, dtype=np.uint16), np.ascontiguousarray(dd, dtype=np.uint16)
+    pl, pd = ll.ctypes.data_as(u16p), dd.ctypes.data_as(u16p)
+    r = ol.RefSymbols(ll, dd)
+    try:
+        rng = np.random.default_rng(11)
+        m = len(ll)
+        ranges = [(0, m), (0, 1), (m - 1, m), (0, min(m, 300)), (0, min(m, 700))]
+        ranges += [tuple(sorted(rng.integers(0, m + 1, 2).tolist())) for _ in range(60)]
+        for a, b in ranges:
+            if a == b:
+                continue
+            assert host.zamd_test_block_size_auto(pl, pd, m, a, b) == r.block_size_auto(a, b), (a, b)
+        for maxblocks in (15, 4, 0):
+            pts = (sz * 64)()
+            k = host.zamd_test_block_split(pl, pd, m, maxblocks, pts, 64)
+            assert [pts[i] for i in range(k)] == r.block_split(maxblocks), maxblocks
+    finally:
+        r.close()

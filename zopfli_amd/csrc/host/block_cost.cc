@@ -1,6 +1,7 @@
 #include "block_cost.h"
 
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "huffman.h"
@@ -104,16 +105,86 @@ size_t EncodeCodeLengths(const unsigned* ll_lengths, const unsigned* d_lengths, 
   return bits;
 }
 
-// Index (bit0 = use16, bit1 = use17, bit2 = use18) of the smallest header; the
-// first minimum wins as in AddDynamicTree (deflate.c:251-272).
+// Size in bits of the header EncodeCodeLengths would write, for all eight subsets of the repeat codes at
+// once: the runs of the length sequence are found once, every subset only counts its tokens (the same
+// rules as above), and subsets that come to the same token counts share one code-length computation.
+// Index (bit0 = use16, bit1 = use17, bit2 = use18) of the smallest header; the first minimum wins as in
+// AddDynamicTree (deflate.c:251-272).
 int BestCodeLengthEncoding(const unsigned* ll_lengths, const unsigned* d_lengths, size_t* best_bits) {
+  unsigned hlit = 29, hdist = 29;
+  while (hlit > 0 && ll_lengths[257 + hlit - 1] == 0) hlit--;
+  while (hdist > 0 && d_lengths[1 + hdist - 1] == 0) hdist--;
+  const unsigned nll = hlit + 257;
+  const unsigned total = nll + hdist + 1;
+  uint8_t run_symbol[kNumLL + kNumD];
+  uint16_t run_length[kNumLL + kNumD];
+  unsigned nruns = 0;
+  for (unsigned i = 0; i < total;) {
+    const unsigned symbol = i < nll ? ll_lengths[i] : d_lengths[i - nll];
+    unsigned run = 1;
+    while (i + run < total && (i + run < nll ? ll_lengths[i + run] : d_lengths[i + run - nll]) == symbol) run++;
+    run_symbol[nruns] = static_cast<uint8_t>(symbol);
+    run_length[nruns++] = static_cast<uint16_t>(run);
+    i += run;
+  }
+  size_t counts[8][19];
+  size_t sizes[8];
   int best = 0;
   size_t best_size = 0;
-  for (int i = 0; i < 8; ++i) {
-    const size_t s = EncodeCodeLengths(ll_lengths, d_lengths, i & 1, i & 2, i & 4, nullptr);
-    if (best_size == 0 || s < best_size) {
-      best_size = s;
-      best = i;
+  for (int v = 0; v < 8; ++v) {
+    const bool use16 = v & 1, use17 = v & 2, use18 = v & 4;
+    size_t* clcount = counts[v];
+    for (int i = 0; i < 19; ++i) clcount[i] = 0;
+    for (unsigned r = 0; r < nruns; ++r) {
+      const unsigned symbol = run_symbol[r];
+      unsigned run = run_length[r];
+      if (!(use16 || (symbol == 0 && (use17 || use18)))) {   // no run is looked for: one token per length
+        clcount[symbol] += run;
+        continue;
+      }
+      if (symbol == 0 && run >= 3) {
+        if (use18) {
+          while (run >= 11) {
+            run -= run > 138 ? 138 : run;
+            clcount[18]++;
+          }
+        }
+        if (use17) {
+          while (run >= 3) {
+            run -= run > 10 ? 10 : run;
+            clcount[17]++;
+          }
+        }
+      }
+      if (use16 && run >= 4) {
+        clcount[symbol]++;
+        run--;
+        while (run >= 3) {
+          run -= run > 6 ? 6 : run;
+          clcount[16]++;
+        }
+      }
+      clcount[symbol] += run;
+    }
+    int same = -1;
+    for (int w = 0; w < v && same < 0; ++w) {
+      if (std::memcmp(counts[w], clcount, sizeof(counts[w])) == 0) same = w;
+    }
+    if (same >= 0) {
+      sizes[v] = sizes[same];
+    } else {
+      unsigned clcl[19];
+      LengthLimitedCodeLengths(clcount, 19, 7, clcl);
+      unsigned hclen = 15;
+      while (hclen > 0 && clcount[kClOrder[hclen + 4 - 1]] == 0) hclen--;
+      size_t bits = 14 + (hclen + 4) * 3;
+      for (int i = 0; i < 19; ++i) bits += clcl[i] * clcount[i];
+      bits += clcount[16] * 2 + clcount[17] * 3 + clcount[18] * 7;
+      sizes[v] = bits;
+    }
+    if (best_size == 0 || sizes[v] < best_size) {
+      best_size = sizes[v];
+      best = v;
     }
   }
   *best_bits = best_size;
@@ -168,7 +239,7 @@ void OptimizeCountsForRle(int length, size_t* counts) {
 
   // Runs that already code well with the repeat codes are frozen: >=5 zeros or
   // >=7 equal non-zero counts.
-  std::vector<char> frozen(length, 0);
+  char frozen[kNumLL] = {0};
   for (int start = 0; start < length;) {
     int stop = start + 1;
     while (stop < length && counts[stop] == counts[start]) ++stop;
@@ -225,7 +296,8 @@ double DynamicLengths(const Histogram& hin, unsigned* ll_lengths, unsigned* d_le
   LengthLimitedCodeLengths(smooth.ll, kNumLL, 15, ll2);
   LengthLimitedCodeLengths(smooth.d, kNumD, 15, d2);
   EnsureTwoDistanceCodes(d2);
-  const double tree2 = static_cast<double>(TreeSize(ll2, d2));
+  const bool same_lengths = std::memcmp(ll2, ll_lengths, sizeof(ll2)) == 0 && std::memcmp(d2, d_lengths, sizeof(d2)) == 0;
+  const double tree2 = same_lengths ? tree : static_cast<double>(TreeSize(ll2, d2));
   const double data2 = static_cast<double>(SymbolBits(h, ll2, d2));
 
   if (tree2 + data2 < tree + data) {

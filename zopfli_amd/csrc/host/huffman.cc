@@ -22,115 +22,113 @@ struct Chain {
   int tail;
 };
 
-class BoundaryPackageMerge {
- public:
-  BoundaryPackageMerge(const std::vector<Leaf>& leaves, int maxbits)
-      : leaves_(leaves), nleaves_(static_cast<int>(leaves.size())), maxbits_(maxbits) {
-    pool_.reserve(static_cast<size_t>(2) * maxbits * nleaves_ + 4);
-    pool_.push_back({leaves_[0].weight, 1, -1});
-    pool_.push_back({leaves_[1].weight, 2, -1});
-    for (int i = 0; i < maxbits_; ++i) {
-      look_[i][0] = 0;
-      look_[i][1] = 1;
-    }
-  }
-
-  // Adds one chain to list `top`, replenishing the look-ahead pairs of the
-  // lower lists as packages consume them (katajainen.c:69, iteratively).
-  void Advance(int top) {
-    int pending[40];
-    int np = 0;
-    pending[np++] = top;
-    while (np > 0) {
-      const int list = pending[--np];
-      const int used = pool_[look_[list][1]].count;
-      if (list == 0 && used >= nleaves_) continue;
-      const int prev_last = look_[list][1];
-      const int fresh = static_cast<int>(pool_.size());
-      pool_.push_back({0, 0, -1});
-      look_[list][0] = prev_last;
-      look_[list][1] = fresh;
-      if (list == 0) {
-        pool_[fresh] = {leaves_[used].weight, used + 1, -1};
-        continue;
-      }
-      const size_t package = pool_[look_[list - 1][0]].weight + pool_[look_[list - 1][1]].weight;
-      if (used < nleaves_ && package > leaves_[used].weight) {
-        pool_[fresh] = {leaves_[used].weight, used + 1, pool_[prev_last].tail};
-      } else {
-        pool_[fresh] = {package, used, look_[list - 1][1]};
-        pending[np++] = list - 1;  // both look-ahead chains of the lower list
-        pending[np++] = list - 1;  // were consumed
-      }
-    }
-  }
-
-  // The last chain only needs its leaf count / tail (katajainen.c:107).
-  void Finish() {
-    const int top = maxbits_ - 1;
-    const int last = look_[top][1];
-    const int used = pool_[last].count;
-    const size_t package = pool_[look_[top - 1][0]].weight + pool_[look_[top - 1][1]].weight;
-    if (used < nleaves_ && package > leaves_[used].weight) {
-      const int fresh = static_cast<int>(pool_.size());
-      pool_.push_back({0, used + 1, pool_[last].tail});
-      look_[top][1] = fresh;
-    } else {
-      pool_[last].tail = look_[top - 1][1];
-    }
-  }
-
-  // Number of active leaves per list, read off the final chain (katajainen.c:140).
-  void Extract(unsigned* lengths) const {
-    int active[16] = {0};
-    int first = 16;
-    for (int c = look_[maxbits_ - 1][1]; c != -1; c = pool_[c].tail) active[--first] = pool_[c].count;
-    int leaf = active[15];
-    unsigned bits = 1;
-    for (int slot = 15; slot >= first; --slot, ++bits) {
-      for (; leaf > active[slot - 1]; --leaf) lengths[leaves_[leaf - 1].symbol] = bits;
-    }
-  }
-
- private:
-  const std::vector<Leaf>& leaves_;
-  const int nleaves_;
-  const int maxbits_;
-  std::vector<Chain> pool_;
-  int look_[16][2];
-};
+constexpr int kMaxLeaves = 288;   // litlen alphabet; the callers' other alphabets are smaller
+constexpr int kMaxBits = 15;
 
 }  // namespace
 
+// Boundary package-merge (katajainen.c:172-262) on flat arrays: the leaves on the stack, the chains in a
+// per-thread array that is allocated once (the block-split search calls this ~20 times per candidate split
+// point, deflate.c:569 and :277 — heap traffic was two thirds of its time).
 bool LengthLimitedCodeLengths(const size_t* freq, int n, int maxbits, unsigned* lengths) {
-  std::vector<Leaf> leaves;
-  leaves.reserve(n);
+  for (int i = 0; i < n; ++i) lengths[i] = 0;
+  if (n > kMaxLeaves || maxbits > kMaxBits) return false;
+  Leaf leaves[kMaxLeaves];
+  int used = 0;
   for (int i = 0; i < n; ++i) {
-    lengths[i] = 0;
-    if (freq[i]) leaves.push_back({freq[i], i});
+    if (freq[i]) leaves[used++] = {freq[i], i};
   }
-  const int used = static_cast<int>(leaves.size());
   if ((1 << maxbits) < used) return false;
   if (used == 0) return true;
   if (used <= 2) {
-    for (const Leaf& l : leaves) lengths[l.symbol] = 1;
+    for (int i = 0; i < used; ++i) lengths[leaves[i].symbol] = 1;
     return true;
   }
-  for (const Leaf& l : leaves) {
-    if (l.weight >= (static_cast<size_t>(1) << (sizeof(size_t) * 8 - 9))) return false;
+  for (int i = 0; i < used; ++i) {
+    if (leaves[i].weight >= (static_cast<size_t>(1) << (sizeof(size_t) * 8 - 9))) return false;
   }
-  // lightest first, symbol index breaks ties (the reference packs the index
-  // into the low 9 bits of the sort key, katajainen.c:221-229)
-  std::sort(leaves.begin(), leaves.end(), [](const Leaf& a, const Leaf& b) {
-    return a.weight != b.weight ? a.weight < b.weight : a.symbol < b.symbol;
-  });
+  // lightest first, symbol index breaks ties: the index rides in the low 9 bits of the sort key, as in
+  // katajainen.c:221-229 (weights are below 2^55, checked above)
+  {
+    uint64_t key[kMaxLeaves];
+    for (int i = 0; i < used; ++i) key[i] = (static_cast<uint64_t>(leaves[i].weight) << 9) | static_cast<uint64_t>(leaves[i].symbol);
+    if (used <= 24) {
+      for (int i = 1; i < used; ++i) {
+        const uint64_t x = key[i];
+        int j = i;
+        for (; j > 0 && key[j - 1] > x; --j) key[j] = key[j - 1];
+        key[j] = x;
+      }
+    } else {
+      std::sort(key, key + used);
+    }
+    for (int i = 0; i < used; ++i) leaves[i] = {static_cast<size_t>(key[i] >> 9), static_cast<int>(key[i] & 511)};
+  }
   if (used - 1 < maxbits) maxbits = used - 1;
 
-  BoundaryPackageMerge bpm(leaves, maxbits);
-  const int chains_needed = 2 * used - 4;  // two already exist in every list
-  for (int i = 0; i + 1 < chains_needed; ++i) bpm.Advance(maxbits - 1);
-  bpm.Finish();
-  bpm.Extract(lengths);
+  // two chains to start with, then at most one per list for each of the 2 * used - 4 steps
+  static thread_local std::vector<Chain> pool_store;
+  const size_t need = static_cast<size_t>(2) * maxbits * used + 8;
+  if (pool_store.size() < need) pool_store.resize(std::max(need, static_cast<size_t>(2) * kMaxBits * kMaxLeaves + 8));
+  Chain* const pool = pool_store.data();
+  int np = 0;
+  pool[np++] = {leaves[0].weight, 1, -1};
+  pool[np++] = {leaves[1].weight, 2, -1};
+  int look[kMaxBits][2];   // the two look-ahead chains of every list
+  for (int i = 0; i < maxbits; ++i) {
+    look[i][0] = 0;
+    look[i][1] = 1;
+  }
+  const int top = maxbits - 1;
+  // Adds one chain to the top list, replenishing the look-ahead pairs of the lower lists as packages
+  // consume them (katajainen.c:69, iteratively); the last chain only needs its leaf count / tail (:107).
+  for (int step = 0; step + 1 < 2 * used - 4; ++step) {
+    int pending[2 * kMaxBits + 2];
+    int npend = 0;
+    pending[npend++] = top;
+    while (npend > 0) {
+      const int list = pending[--npend];
+      const int prev_last = look[list][1];
+      const int cnt = pool[prev_last].count;
+      if (list == 0 && cnt >= used) continue;
+      const int fresh = np++;
+      look[list][0] = prev_last;
+      look[list][1] = fresh;
+      if (list == 0) {
+        pool[fresh] = {leaves[cnt].weight, cnt + 1, -1};
+        continue;
+      }
+      const size_t package = pool[look[list - 1][0]].weight + pool[look[list - 1][1]].weight;
+      if (cnt < used && package > leaves[cnt].weight) {
+        pool[fresh] = {leaves[cnt].weight, cnt + 1, pool[prev_last].tail};
+      } else {
+        pool[fresh] = {package, cnt, look[list - 1][1]};
+        pending[npend++] = list - 1;  // both look-ahead chains of the lower list
+        pending[npend++] = list - 1;  // were consumed
+      }
+    }
+  }
+  {
+    const int last = look[top][1];
+    const int cnt = pool[last].count;
+    const size_t package = pool[look[top - 1][0]].weight + pool[look[top - 1][1]].weight;
+    if (cnt < used && package > leaves[cnt].weight) {
+      const int fresh = np++;
+      pool[fresh] = {0, cnt + 1, pool[last].tail};
+      look[top][1] = fresh;
+    } else {
+      pool[last].tail = look[top - 1][1];
+    }
+  }
+  // number of active leaves per list, read off the final chain (katajainen.c:140)
+  int active[17] = {0};
+  int first = 16;
+  for (int c = look[top][1]; c != -1; c = pool[c].tail) active[--first] = pool[c].count;
+  int leaf = active[15];
+  unsigned bits = 1;
+  for (int slot = 15; slot >= first; --slot, ++bits) {
+    for (; leaf > active[slot - 1]; --leaf) lengths[leaves[leaf - 1].symbol] = bits;
+  }
   return true;
 }
 

@@ -202,7 +202,9 @@ int zmx_find_longest_match(zmx_ctx* ctx, zmx_tables* tables, size_t block, size_
 
 /* Parity probe: the static hash arrays of one block for positions max(0, instart - 32768) .. inend - 1
  * (inend - windowstart entries each): same[] (hash.c:116-126) and the distances to the previous
- * position of the same hash / of the same second hash (hash.c:110-114, 129-135; 0 = none). */
+ * position of the same hash / of the same second hash (hash.c:110-114, 129-135; 0 = none).
+ * Fails for tables built with zmx_tables_build_from and a parent: those hold the hash arrays only
+ * where the recomputed positions at the block ends read them. */
 int zmx_hash_links_download(zmx_ctx* ctx, zmx_tables* tables, size_t block, uint16_t* same,
                             uint16_t* prev1, uint16_t* prev2);
 

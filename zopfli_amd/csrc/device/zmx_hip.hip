@@ -101,6 +101,7 @@ struct zmx_tables {
   u32* d_tile_off = nullptr;
   u16* d_same16 = nullptr;
   ushort4* d_links = nullptr;
+  bool links_partial = false;     // built from a parent: the hash arrays exist only where k_match2 read them
   u32* d_recs = nullptr;
   u32* d_pool = nullptr;
   u32 pool_cap = 0;
@@ -449,11 +450,13 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
 
   // ---- reuse of the parent's records
   std::vector<u64> src_pos;
+  std::vector<u64> link_lo;       // per block: first links[] index the recomputed tiles read (its L: none)
   std::vector<u32> tile_list;
   bool reuse = parent != nullptr && parent->nb > 0 && c->h_in != nullptr && parent->d_recs != nullptr &&
                parent->total_b + pos_off < (3ull << 30);
   if (reuse) {
     src_pos.resize(nb);
+    link_lo.resize(nb);
     size_t pb = 0;
     for (size_t b = 0; b < nb && reuse; ++b) {
       const BlockDesc& d = t->blocks[b];
@@ -465,6 +468,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
       const BlockDesc& pd = parent->blocks[pb];
       src_pos[b] = pd.pos_off + (d.instart - pd.instart);
       const u64 B = d.inend - d.instart;
+      link_lo[b] = d.inend - d.ws;
       if (B == 0 || d.inend == pd.inend) continue;   // same end: every record is the same
       // first position whose record may differ
       u64 t0 = B > ZMX_MAX_MATCH ? d.inend - ZMX_MAX_MATCH : d.instart;
@@ -472,9 +476,13 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
       u64 r = d.inend - 1;
       while (r > d.instart && d.inend - r < 65600 && c->h_in[r - 1] == lastb) --r;
       if (r < t0) t0 = r;
-      for (u32 tile = static_cast<u32>((t0 - d.instart) / MT); tile < tile_off[b + 1] - tile_off[b]; ++tile) {
+      const u32 tile_first = static_cast<u32>((t0 - d.instart) / MT);
+      for (u32 tile = tile_first; tile < tile_off[b + 1] - tile_off[b]; ++tile) {
         tile_list.push_back(tile_off[b] + tile);
       }
+      // the walks of those tiles stay inside the 32 KiB before them (lz77.c:464)
+      const u64 first_index = d.instart + static_cast<u64>(tile_first) * MT - d.ws;
+      link_lo[b] = first_index > ZMX_WINDOW ? first_index - ZMX_WINDOW : 0;
     }
   }
 
@@ -520,13 +528,25 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   HIPCHK(hipMemsetAsync(t->d_flags, 0, 4 * sizeof(u32), c->stream));
 
   HIPCHK(hipEventRecord(c->ev[0], c->stream));
-  if (max_l > 0) {
+  PoolScope hash_tmp(c);
+  auto launch_hash = [&](const u64* d_link_lo) -> int {
+    if (max_l == 0) return 0;
     const dim3 g1(static_cast<unsigned>((max_l + 256 * SAME_CH - 1) / (256 * SAME_CH)), static_cast<unsigned>(nb));
-    hipLaunchKernelGGL(k_same, g1, dim3(256), 0, c->stream, c->d_in, t->d_blocks, t->d_same16);
+    hipLaunchKernelGGL(k_same, g1, dim3(256), 0, c->stream, c->d_in, t->d_blocks, t->d_same16, d_link_lo);
     HIPCHK(hipGetLastError());
     const dim3 g2(static_cast<unsigned>((max_l + CH_EMIT - 1) / CH_EMIT), static_cast<unsigned>(nb), 2);
-    hipLaunchKernelGGL(k_chain, g2, dim3(64), CH_LDS_BYTES, c->stream, c->d_in, t->d_blocks, t->d_same16, t->d_links);
+    hipLaunchKernelGGL(k_chain, g2, dim3(64), CH_LDS_BYTES, c->stream, c->d_in, t->d_blocks, t->d_same16, t->d_links, d_link_lo);
     HIPCHK(hipGetLastError());
+    return 0;
+  };
+  {
+    u64* d_link_lo = nullptr;
+    if (reuse) {
+      HIPCHK(hash_tmp.Alloc(&d_link_lo, nb));
+      HIPCHK(hipMemcpyAsync(d_link_lo, link_lo.data(), nb * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    }
+    if (launch_hash(d_link_lo) != 0) return -1;
+    t->links_partial = reuse;
   }
 
   if (!c->d_scratch) HIPCHK(DevAlloc(&c->d_scratch, static_cast<size_t>(kMatchGrid) * M2_THREADS * SCRATCH_CPS));
@@ -585,7 +605,9 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
       parent->d_pool = nullptr;
       parent->pool_cap = 0;
     } else {
-      reuse = false;                       // pool overflow: build everything with a pool of our own
+      reuse = false;                       // pool overflow: build everything with a pool of our own,
+      if (launch_hash(nullptr) != 0) return -1;   // which needs the hash arrays of whole blocks
+      t->links_partial = false;
     }
   }
 
@@ -1380,6 +1402,7 @@ int zmx_hash_links_download(zmx_ctx* c, zmx_tables* t, size_t block, uint16_t* s
   if (block >= t->nb) return FailMsg("zmx_hash_links_download: bad block");
   DeviceGuard dev_guard(c->device);
   HIPCHK(dev_guard.err);
+  if (t->links_partial) return FailMsg("zmx_hash_links_download: tables built from a parent hold the hash arrays only near the block ends");
   const BlockDesc& d = t->blocks[block];
   const size_t n = static_cast<size_t>(d.inend - d.ws);
   std::vector<ushort4> lk(n);

@@ -94,13 +94,22 @@ __device__ __forceinline__ void wave_lds_sync() {
 // ----------------------------------------------------------------------------
 #define SAME_CH 64
 
+// link_lo (optional, per block): only the links from this index on will be read (tables built from a parent:
+// k_match2 recomputes the tiles at the block's end only) — k_chain skips the chunks that end below it, k_same
+// what lies more than a chunk and its warm-up window below it.
 __global__ __launch_bounds__(256) void k_same(const u8* __restrict__ in, const BlockDesc* __restrict__ blocks,
-                                              u16* __restrict__ same16) {
+                                              u16* __restrict__ same16, const u64* __restrict__ link_lo) {
   const BlockDesc bd = blocks[blockIdx.y];
   const u64 L = bd.inend - bd.ws;
   const u64 c0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * SAME_CH;
   if (c0 >= L) return;
   const u64 c1 = (c0 + SAME_CH < L) ? c0 + SAME_CH : L;
+  if (link_lo) {
+    const u64 lo = link_lo[blockIdx.y];
+    if (lo >= L) return;
+    const u64 chunk0 = lo / 32768u * 32768u;                 // first chunk k_chain keeps (CH_EMIT)
+    if (c1 + 32768u <= chunk0) return;                       // below its warm-up window
+  }
   const u8* base = in + bd.ws;
   // same[c1] by scanning forward (at most 65535 bytes, 8 at a time once aligned)
   u32 next = 0;
@@ -151,7 +160,8 @@ __global__ __launch_bounds__(256) void k_same(const u8* __restrict__ in, const B
 #define CH_LDS_BYTES (65536 + CH_TILE * 4)     // the head table, a tile's keys, a tile's run lengths
 
 __global__ __launch_bounds__(64) void k_chain(const u8* __restrict__ in, const BlockDesc* __restrict__ blocks,
-                                              const u16* __restrict__ same16, ushort4* __restrict__ links) {
+                                              const u16* __restrict__ same16, ushort4* __restrict__ links,
+                                              const u64* __restrict__ link_lo) {
   extern __shared__ __align__(16) u8 dyn_lds[];
   u16* head = reinterpret_cast<u16*>(dyn_lds);   // last position (relative to w0) of every key, 0xffff = none
   u16* keys = head + 32768;
@@ -163,6 +173,7 @@ __global__ __launch_bounds__(64) void k_chain(const u8* __restrict__ in, const B
   const u64 e0 = (u64)blockIdx.x * CH_EMIT;
   if (e0 >= L) return;
   const u64 e1 = (e0 + CH_EMIT < L) ? e0 + CH_EMIT : L;
+  if (link_lo && e1 <= link_lo[blockIdx.y]) return;     // nobody reads this chunk's links (see k_same)
   const u64 w0 = e0 >= ZMX_WINDOW ? e0 - ZMX_WINDOW : 0;
   const u32 lane = threadIdx.x;
   const u64 lt_mask = (1ull << lane) - 1;          // lanes below me

@@ -226,12 +226,14 @@ def test_squeeze_runs(gpu_ctx, case):
 CHAIN_ENVS = [
     ({}, lambda st: st["tasks"] > 100 and st["accepted"] > 0),
     ({"ZOPFLI_AMD_SEG_L": "0"}, lambda st: st["tasks"] == 0),                                   # the serial chain
-    ({"ZOPFLI_AMD_SEG_WARM": "64", "ZOPFLI_AMD_SEG_HEAD": "0"}, lambda st: st["rerun_state"] > 0),                           # warm-up too short: states differ
+    ({"ZOPFLI_AMD_SEG_WARM": "64", "ZOPFLI_AMD_SEG_HEAD": "0", "ZOPFLI_AMD_SEG_CUTS": "0"}, lambda st: st["rerun_state"] > 0),                           # warm-up too short: states differ
     ({"ZOPFLI_AMD_SEG_SCALE": "1.9"}, lambda st: st["rerun_level"] + st["rerun_values"] > 0),                         # wrong binade guessed
     ({"ZOPFLI_AMD_SEG_L": "1024", "ZOPFLI_AMD_SEG_WARM": "256", "ZOPFLI_AMD_SEG_HEAD": "4096"}, lambda st: st["tasks"] > 400),
     ({"ZOPFLI_AMD_INT_PATH": "0"}, lambda st: st["accepted"] > 0),                              # every window in the reference's doubles
     ({"ZOPFLI_AMD_FIX_LEAN": "0"}, lambda st: st["rerun_state"] > 0),                           # serial re-runs by the lean one-wave job
     ({"ZOPFLI_AMD_SEG_REDO": "0"}, lambda st: st["rerun_level"] > 0),                           # no second speculative pass
+    ({"ZOPFLI_AMD_SEG_CUTS": "0"}, lambda st: st["accepted"] > 0),                              # every task warms up over 512 positions (no cut points)
+    ({"ZOPFLI_AMD_SEG_CUTS": "64", "ZOPFLI_AMD_SEG_L": "512", "ZOPFLI_AMD_SEG_HEAD": "2048"}, lambda st: st["tasks"] > 1000 and st["accepted"] > 0),   # short tasks, cut points sought close by
     ({"ZOPFLI_AMD_MATCH_FILTER": "0"}, lambda st: st["accepted"] > 0),                          # k_match2 with the one-byte candidate test
 ]
 

@@ -353,6 +353,7 @@ struct Dp4Params {
 // state recorded at the first window at or after pout).  k_dp4_fix's jobs: a task again, from the
 // true exit state of its predecessor.
 struct D4Job {
+  u32 cell = 0;            // spec, not load: the window cell that holds `level` (the task starts at start + cell)
   u32 start;               // first window / group base
   u32 noshort;             // walk state there
   u32 pout;                // spec: the entry state is recorded at the first window base >= pout

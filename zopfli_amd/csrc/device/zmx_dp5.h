@@ -232,8 +232,8 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
   } else {
 #pragma unroll
     for (int s = 0; s < 6; ++s) { c[s] = 1e30f; l[s] = 0; }
-    if (lane == 0) c[0] = J.level;
-    reach = 0;
+    if (lane == J.cell) c[0] = J.level;     // (cell > 0: a task that starts at a cut point inside its first window)
+    reach = J.cell;
   }
   u32 la_lo = J.la_lo;
   // the length of cell x: into length_array, or — from pend on, where the successor may be writing
@@ -627,6 +627,53 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// CUT POINTS.  A position q that no DP edge crosses — p + kend(p) <= q for every p < q (kend: the longest
+// match at p, or 1 for the literal: dph[p].y) — splits GetBestLengths exactly: every cell beyond q gets its
+// value through cell q alone, so a chain started at q from ONE cell is the true chain shifted by a constant,
+// with no warm-up and nothing left to chance (a long-run shortcut cannot span a cut either: the run's own
+// matches would cross it).  Text has one every ~25 positions (largest gap seen: 688), data made of long runs
+// almost none.  One wave per task looks for the last cut point at most `depth` positions before the task's
+// pout and makes it the task's start (SegTask.q, which then need not be a multiple of 32: k_dp5_spec starts
+// at the window that holds it, with the level in that window's cell); tasks without one keep the warm-up.
+// ---------------------------------------------------------------------------------------------
+struct CutParams {
+  const BlockDesc* blocks;
+  const uint2* dph;
+  SegTask* tasks;
+  u32 depth;
+  u32* found;      // [2]: tasks that got a cut point, sum of (pout - q) over them
+};
+
+__global__ __launch_bounds__(64) void k_cutpoints(CutParams P) {
+  const u32 t = blockIdx.x;
+  const SegTask K = P.tasks[t];
+  if (K.pout == 0) return;      // the head of a block starts from the block's true state
+  const BlockDesc bd = P.blocks[K.block];
+  const uint2* dph = P.dph + bd.pos_off;
+  const u32 lane = threadIdx.x;
+  const u32 lo = K.pout > P.depth + ZMX_MAX_MATCH ? K.pout - P.depth - ZMX_MAX_MATCH : 0u;
+  // the prefix maximum from lo on is the true one for q >= lo + 258 (no edge is longer), and for every q if lo = 0
+  const u32 q_min = lo == 0 ? 1u : lo + ZMX_MAX_MATCH;
+  u32 carry = 0, best = SEG_NONE;
+  for (u32 p0 = lo; p0 < K.pout; p0 += 64) {
+    const u32 p = p0 + lane;
+    const u32 r = p < K.pout ? p + (dph[p].y & 0xffffu) : 0u;
+    u32 incl = wave_scan_max(r);
+    incl = incl > carry ? incl : carry;
+    // q = p + 1 is a cut point; not pout itself: the start cell has no source, and the cells from pout on are
+    // compared with the predecessor's, sources included
+    const u64 ok = __ballot(p + 1 < K.pout && p + 1 >= q_min && incl <= p + 1);
+    if (ok) best = p0 + (63u - (u32)__builtin_clzll(ok)) + 1u;
+    carry = rdlane_u32(incl, 63);
+  }
+  if (lane == 0 && best != SEG_NONE) {
+    P.tasks[t].q = best;
+    atomicAdd(&P.found[0], 1u);
+    atomicAdd(&P.found[1], K.pout - best);
+  }
+}
+
 // One workgroup = four waves = up to four tasks of ONE block (P.wg_tasks), sharing the run's weight
 // table in LDS; after the table is in place the waves go their own ways.
 #define D5_WG 4u
@@ -678,7 +725,8 @@ __global__ __launch_bounds__(64 * D5_WG, WAVES) void k_dp5_spec(Dp4Params P) {
   const u32 B = (u32)(bd.inend - bd.instart);
   if (B == 0) return;
   D4Job J;
-  J.start = T.q;
+  J.start = T.q & ~31u;       // windows lie at multiples of 32 from the block start
+  J.cell = T.q & 31u;
   J.noshort = 0;
   J.pout = T.pout;
   J.pend = T.pend;

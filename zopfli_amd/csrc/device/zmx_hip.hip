@@ -401,17 +401,20 @@ static unsigned SegL(u64 total_positions) {
   static const bool set = std::getenv("ZOPFLI_AMD_SEG_L") != nullptr;
   static const unsigned v = EnvU32("ZOPFLI_AMD_SEG_L", 4096, 0, 1u << 24) & ~63u;
   if (set) return v;
-  return total_positions < (2u << 20) ? 1024u : total_positions < (32u << 20) ? 2048u : 4096u;
+  // (with the tasks started at cut points, below, the warm-up is ~70 positions instead of 512 and 2048 beats 4096
+  //  for a full batch too: half the positions re-run where a task crosses a binade, 4.17 -> 3.75 ms per run of 100 MB;
+  //  1024 loses to the per-task set-up again: 4.2 ms)
+  return total_positions < (2u << 20) ? 1024u : 2048u;
 }
 // The first task of a block is exact by construction and runs beside the others: let it cover the
 // stretch where the costs double every few thousand positions and no guess would stay in its binade.
 // The exact head of a block (positions run from the true initial state; the values double every few hundred
 // positions there and speculative tasks would not stay inside a binade).  It is one serial wave: with few blocks in
 // the batch the whole run waits for it (short: 4096), with many it hides behind the other tasks and a long head
-// saves the serial re-runs of the early tasks (16384).  ZOPFLI_AMD_SEG_HEAD overrides.
+// saves the serial re-runs of the early tasks (8192; 16384 and 4096 are within 1 %).  ZOPFLI_AMD_SEG_HEAD overrides.
 static unsigned SegHead(size_t nb) {
   static const unsigned v = EnvU32("ZOPFLI_AMD_SEG_HEAD", 0, 0, 1u << 24) & ~63u;
-  return v ? v : (nb >= 48 ? 16384u : 0u);      // (0: as long as a task)
+  return v ? v : (nb >= 48 ? 8192u : 0u);       // (0: as long as a task)
 }
 static unsigned SegWarm() { static const unsigned v = (EnvU32("ZOPFLI_AMD_SEG_WARM", 512, 64, 1u << 20) + 63u) & ~63u; return v; }
 
@@ -774,6 +777,31 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     HIPCHK(hipMemcpyAsync(t->d_tasks, t->tasks.data(), nt * sizeof(SegTask), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(t->d_task_off, t->task_off.data(), (nb + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(t->d_segstats, 0, 8 * sizeof(u32), c->stream));
+    // start the tasks at cut points of the DP where there is one close enough (zmx_dp5.h: k_cutpoints);
+    // ZOPFLI_AMD_SEG_CUTS = how far before a task's first owned position to look, 0 = every task warms up
+    static const u32 cut_depth = EnvU32("ZOPFLI_AMD_SEG_CUTS", 1024, 0, 1u << 16);
+    if (cut_depth && nt) {
+      PoolScope tmp(c);
+      u32* d_found = nullptr;
+      HIPCHK(tmp.Alloc(&d_found, 2));
+      HIPCHK(hipMemsetAsync(d_found, 0, 2 * sizeof(u32), c->stream));
+      CutParams cp;
+      cp.blocks = t->d_blocks;
+      cp.dph = t->d_dph;
+      cp.tasks = t->d_tasks;
+      cp.depth = cut_depth;
+      cp.found = d_found;
+      hipLaunchKernelGGL(k_cutpoints, dim3(static_cast<unsigned>(nt)), dim3(64), 0, c->stream, cp);
+      HIPCHK(hipGetLastError());
+      static const bool prof = std::getenv("ZOPFLI_AMD_PROF") != nullptr;
+      if (prof) {
+        u32 found[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(found, d_found, sizeof(found), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        std::fprintf(stderr, "k_cutpoints: %u of %zu tasks start at a cut point, %.1f positions before their first owned one on average\n",
+                     found[0], nt, found[0] ? static_cast<double>(found[1]) / found[0] : 0.0);
+      }
+    }
   }
   {
     // k_dp5_spec's workgroups: four tasks of one block each (they share the block's weight table in

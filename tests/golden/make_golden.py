@@ -1,7 +1,7 @@
 """Generates tests/golden/vectors.json from the REAL reference (oracle/_ref/libzopfli_ref.so,
 compiled from /root/reference by oracle/Makefile).  Run in the build container:
 
-    python tests/golden/make_golden.py [--big | --big2 | --extra | --part]
+    python tests/golden/make_golden.py [--big | --big2 | --big3 | --extra | --part]
 
 Each vector: synthetic class / size / seed (zopfli_amd.datagen) or a literal input, the
 ZopfliOptions used, the format, and the SHA-256 + length of the reference's output.
@@ -110,6 +110,47 @@ def big2_cases():
     return cs
 
 
+def big3_cases():
+    """Round-2 verdict item 6: every class at bench size.  The mixed corpus M at 100 MB (bs 0/1), M at 20 MB with
+    numiterations=50 (BASELINE configs[3] shape), and R / Z / B / P at 20 MB and 100 MB (class B at 100 MB only
+    without block splitting: ~4 h of one core).  Longest first, so a pool drains evenly."""
+    cs = []
+
+    def add(cls, size, n=15, split=1):
+        cs.append({"input": {"kind": "class", "cls": cls, "size": size}, "format": 0, "numiterations": n,
+                   "blocksplitting": split, "blocksplittingmax": 15})
+
+    add("B", 100000000, 15, 0)
+    add("M", 20000000, 50, 1)
+    for split in (0, 1):
+        add("B", 20000000, 15, split)
+    for split in (0, 1):
+        add("M", 100000000, 15, split)
+    for cls in "ZPR":
+        for split in (0, 1):
+            add(cls, 100000000, 15, split)
+    for cls in "ZPR":
+        for split in (0, 1):
+            add(cls, 20000000, 15, split)
+    return cs
+
+
+def run_to_file(case):
+    """run() with the result kept in its own file, so an interrupted --big3 keeps what it finished."""
+    i = case["input"]
+    name = "%s_%d_n%d_bs%d.json" % (i["cls"], i["size"], case["numiterations"], case["blocksplitting"])
+    path = os.path.join(HERE, "_big3_parts", name)
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f)
+    done = run(case)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path + ".tmp", "w") as f:
+        json.dump(done, f)
+    os.replace(path + ".tmp", path)
+    return done
+
+
 def part_cases():
     """ZopfliDeflatePart over ONE block far beyond the reference's 1 MB master blocks (blocksplitting 0: the whole
     range is one deflate block, deflate.c:811-842) — the 32-bit DP row offsets of round 1 stopped at 16 MB."""
@@ -133,6 +174,15 @@ def main():
     if "--part" in sys.argv:
         done = [run_part(c) for c in part_cases()]
         path = os.path.join(HERE, "vectors_part.json")
+        with open(path, "w") as f:
+            json.dump(done, f, indent=1)
+        print("wrote", path, len(done), "vectors")
+        return
+    if "--big3" in sys.argv:
+        nproc = int(os.environ.get("GOLDEN_PROCS", "6"))
+        with mp.Pool(nproc) as pool:
+            done = pool.map(run_to_file, big3_cases(), chunksize=1)
+        path = os.path.join(HERE, "vectors_big3.json")
         with open(path, "w") as f:
             json.dump(done, f, indent=1)
         print("wrote", path, len(done), "vectors")

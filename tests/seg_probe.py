@@ -15,6 +15,24 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 import oracle_lib as ol  # noqa: E402
 from zopfli_amd import Context, api, generate  # noqa: E402
 
+def dyadic_costs(hist):
+    """A cost model whose weights are dyadic rationals (SEG_PROBE_COSTS=dyadic): every cost is a small integer
+    plus an odd multiple of 2^-k, k = 4..11 by symbol.  w mod ulp(e) = ulp(e)/2 then holds in binade e = k + 16
+    (float ulp 2^(e-23)), so the sum of such a weight and a float of that binade lands exactly half-way between
+    two floats (squeeze.c:281-299 rounds it to even): the tie rule of the chain's acceptance test
+    (zmx_dp4.h d4_accept -> 2, the integer table refused) has to re-run every task whose values lie in a
+    masked binade, 2^13 .. 2^21 bits here — entropy costs never get there."""
+    ll = np.zeros(288)
+    d = np.zeros(32)
+    total = max(int(hist[:288].sum()), 1)
+    for i in range(288):
+        base = 3 + (int(np.log2(total / max(int(hist[i]), 1))) if hist[i] else 9)
+        ll[i] = base + 2.0 ** -(4 + i % 8)
+    for i in range(32):
+        d[i] = 2 + i % 5 + 2.0 ** -(4 + (i * 3) % 8)
+    return ll, d
+
+
 CASES = [
     ("T", 200000, [(0, 120000), (120000, 200000)]),
     ("X", 100000, [(30000, 100000)]),
@@ -26,6 +44,9 @@ CASES = [
 
 def main():
     global CASES
+    dyadic = os.environ.get("SEG_PROBE_COSTS") == "dyadic"
+    if dyadic:   # one long block: its costs pass 2^20 bits, through every binade the weights can tie in
+        CASES = [("T", 400000, [(0, 400000)]), ("X", 300000, [(10000, 300000)])]
     if os.environ.get("SEG_PROBE_CASES"):
         CASES = [c for c in CASES if c[0] in os.environ["SEG_PROBE_CASES"]]
     lib = api.library()
@@ -41,7 +62,7 @@ def main():
             cost = np.zeros((nb, 320))
             mincost = np.zeros(nb)
             for b in range(nb):
-                ll, d = ol.entropy_costs(hist[b])
+                ll, d = dyadic_costs(hist[b]) if dyadic else ol.entropy_costs(hist[b])
                 cost[b, :288], cost[b, 288:] = ll, d
                 mincost[b] = ol.model_min_cost(ll, d)
             nsym, hist = t.squeeze_run(cost, mincost, np.full(nb, it & 1, dtype=np.int32))

@@ -252,6 +252,52 @@ def test_chain_task_paths(env, expect):
     assert expect(st), st
 
 
+@pytest.mark.parametrize("int_path", ["1", "0"])
+def test_chain_tie_rule(int_path):
+    """The exactness branch entropy costs never reach: a cost model of dyadic weights (seg_probe.dyadic_costs)
+    ties in the float rounding of the binades 2^13 .. 2^21 (squeeze.c:281-299: float cells, double sums), so a
+    task there must not be accepted on a shifted entry state (zmx_dp4.h d4_accept -> 2) nor take the integer
+    chain step (zmx_dp5.h: the workgroup's table is refused when the tie mask has its binade).  length_array
+    and the stores equal the oracle's, and the statistics show tasks re-run for the tie rule."""
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(__file__), "seg_probe.py")
+    env = dict(os.environ, SEG_PROBE_COSTS="dyadic", ZOPFLI_AMD_INT_PATH=int_path)
+    r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    st = json.loads(r.stdout.strip().splitlines()[-1])
+    assert st["rerun_tie"] > 0 and st["tasks"] > 100, st
+
+
+def test_guard_mode():
+    """ZOPFLI_AMD_GUARD=1 (red zones around every device allocation, poisoned bodies, a check after every kernel
+    launch: zmx_hip.hip): the chained squeeze runs of seg_probe.py on every class and a block-split stream stay
+    bit-exact and touch no red zone; a byte broken on purpose (ZOPFLI_AMD_GUARD_SELFTEST) is reported with the
+    allocation it lies behind."""
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(__file__), "seg_probe.py")
+    env = dict(os.environ, ZOPFLI_AMD_GUARD="1")
+    r = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    code = ("import sys, gzip; sys.path.insert(0, %r)\n"
+            "from zopfli_amd import ZopfliOptions, api, generate\n"
+            "d = generate('M', 2500000)\n"
+            "o = api.compress(d, 0, ZopfliOptions(5, 1, 15))\n"
+            "assert gzip.decompress(o) == d\n"
+            "import hashlib; print(hashlib.sha256(o).hexdigest())\n" % os.path.dirname(os.path.dirname(__file__)))
+    sha = {}
+    for guard in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ZOPFLI_AMD_GUARD=guard), capture_output=True,
+                           text=True, timeout=1800)
+        assert r.returncode == 0, (guard, r.stdout[-2000:], r.stderr[-2000:])
+        sha[guard] = r.stdout.split()[-1]
+    assert sha["0"] == sha["1"]
+    r = subprocess.run([sys.executable, probe], env=dict(env, ZOPFLI_AMD_GUARD_SELFTEST="7", SEG_PROBE_CASES="X"),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "red zone" in (r.stdout + r.stderr), (r.stdout[-1000:], r.stderr[-1000:])
+
+
 def _golden(lo, hi):
     out = []
     for name in ("vectors.json", "vectors_extra.json"):

@@ -123,6 +123,55 @@ def test_change_point_pool_overflow_and_retry():
     assert res[""] == res["1000"]
 
 
+def test_match_kernels_agree():
+    """The three match-table kernels (ZOPFLI_AMD_MATCH: 2 = k_chain + k_match2 on prev links, 3 = k_bucket + k_match3,
+    a wave per position on sorted candidate slices, 4 = k_bucket + k_match4, the slices streamed by a lane per position)
+    produce the same records — (length, distance, sublen) at every position of every class, blocks with a window in
+    front, tables built from a parent, and a change-point pool that overflows — and the same hash arrays
+    (zmx_hash_links_download reads k_bucket's sorted / rank / bucket arrays back as prev links).  Kernel 2 is the one
+    test_match_table checks against the oracle position by position."""
+    import subprocess
+    import sys
+    code = (
+        "import hashlib, sys\n"
+        "import numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from zopfli_amd import Context, api, generate\n"
+        "lib = api.library()\n"
+        "ctx = Context(0, lib)\n"
+        "h = hashlib.sha256()\n"
+        "cases = [('T', 70000, None, [(0, 70000)]), ('X', 50000, None, [(0, 20000), (20000, 50000)]),\n"
+        "         ('Z', 90000, None, [(0, 45001), (45001, 90000)]), ('B', 40000, None, [(0, 40000)]),\n"
+        "         ('R', 30000, None, [(0, 30000)]), ('P', 66000, None, [(33000, 66000)]),\n"
+        "         ('M', 150000, None, [(0, 3), (3, 5), (5, 5), (5, 100000), (100000, 150000)]),\n"
+        "         ('Z', 200000, [(0, 100000), (100000, 200000)], [(0, 40001), (40001, 100000), (100000, 100300), (100300, 200000)]),\n"
+        "         ('B', 60000, [(0, 60000)], [(0, 30000), (30000, 60000)])]\n"
+        "for cls, n, parents, blocks in cases:\n"
+        "    data = generate(cls, n)\n"
+        "    ctx.set_input(data)\n"
+        "    pt = ctx.build_tables(parents) if parents else None\n"
+        "    t = ctx.build_tables(blocks, parent=pt) if pt else ctx.build_tables(blocks)\n"
+        "    if pt: pt.free()\n"
+        "    for b, (s, e) in enumerate(blocks):\n"
+        "        for pos in range(s, e):\n"
+        "            l, d, sub = t.find_longest_match(b, pos)\n"
+        "            h.update(np.array([l if l >= 3 else 0, d if l >= 3 else 0], dtype=np.uint16).tobytes() + sub[3:l + 1].tobytes())\n"
+        "        if e > s and not parents:\n"
+        "            for a in t.hash_links(b): h.update(np.ascontiguousarray(a).tobytes())\n"
+        "    t.free()\n"
+        "print(h.hexdigest())\n" % os.path.dirname(os.path.dirname(__file__)))
+    res = {}
+    for kern in ("2", "3", "4"):
+        for entries in ("", "2000"):
+            env = dict(os.environ, ZOPFLI_AMD_MATCH=kern)
+            if entries:
+                env["ZOPFLI_AMD_POOL_ENTRIES"] = entries
+            r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1200)
+            assert r.returncode == 0, (kern, entries, r.stderr[-2000:])
+            res[kern + entries] = r.stdout.split()[-1]
+    assert len(set(res.values())) == 1, res
+
+
 # (class, total size, parent blocks, sub-blocks)
 REUSE_CASES = [
     ("T", 120000, [(0, 120000)], [(0, 50000), (50000, 50100), (50100, 120000)]),
@@ -230,7 +279,7 @@ CHAIN_ENVS = [
     ({"ZOPFLI_AMD_SEG_SCALE": "1.9"}, lambda st: st["rerun_level"] + st["rerun_values"] > 0),                         # wrong binade guessed
     ({"ZOPFLI_AMD_SEG_L": "1024", "ZOPFLI_AMD_SEG_WARM": "256", "ZOPFLI_AMD_SEG_HEAD": "4096"}, lambda st: st["tasks"] > 400),
     ({"ZOPFLI_AMD_INT_PATH": "0"}, lambda st: st["accepted"] > 0),                              # every window in the reference's doubles
-    ({"ZOPFLI_AMD_FIX_LEAN": "0"}, lambda st: st["rerun_state"] > 0),                           # serial re-runs by the lean one-wave job
+    ({"ZOPFLI_AMD_FIX_LEAN": "0"}, lambda st: st["rerun_state"] + st["rerun_level"] + st["rerun_values"] > 0),   # serial re-runs by the lean one-wave job
     ({"ZOPFLI_AMD_SEG_REDO": "0"}, lambda st: st["rerun_level"] > 0),                           # no second speculative pass
     ({"ZOPFLI_AMD_SEG_CUTS": "0"}, lambda st: st["accepted"] > 0),                              # every task warms up over 512 positions (no cut points)
     ({"ZOPFLI_AMD_SEG_CUTS": "64", "ZOPFLI_AMD_SEG_L": "512", "ZOPFLI_AMD_SEG_HEAD": "2048"}, lambda st: st["tasks"] > 1000 and st["accepted"] > 0),   # short tasks, cut points sought close by

@@ -114,7 +114,7 @@ struct SegSnap {
   u32 base;              // block-relative position of the next group
   u32 noshort;           // squeeze.c:273: the shortcut is not tested at `base` (it was just taken)
   float vmax;            // exit snapshots: the largest finite cell value the task produced from its entry on
-  u32 pad;
+  u32 skip;              // the first `skip` positions of the window at `base` lie inside a long-run shortcut's span (zmx_dp5.h)
   float c[SEG_CELLS];    // cell values (1e30 = never reached)
   u32 l[SEG_CELLS];      // 1 + block-relative position the cell was reached from (0 = never)
 };
@@ -180,7 +180,7 @@ __device__ __forceinline__ void d3_load_group(D3Walk& W, D3Group& G, const uint2
   G.kend = act ? (dh.y & 0xffffu) : 0u;
   G.roff = dh.x;
   G.offend = G.roff + G.kend;
-  G.m_short = __ballot(act && (dh.y >> 16) != 0);
+  G.m_short = __ballot(act && ((dh.y >> 16) & 1u) != 0);
   // the chain wave re-bases its cell registers every 32 positions (see the consumer): a position
   // sits in lane (lane & 31) of the window, its edges reach cell register (kend + (lane & 31)) >> 6
   G.m_r1 = __ballot(G.kend + (lane & 31u) >= 64u);                    // needs cell register 1
@@ -279,7 +279,7 @@ __device__ __forceinline__ float wave_min_f32(float v) {
 
 // exit state E of a task against the entry state N of the next one, by one wave
 __device__ __forceinline__ SegCheck d4_check(const SegSnap* E, const SegSnap* N, u32 lane) {
-  bool bad = E->base != N->base || E->noshort != N->noshort;
+  bool bad = E->base != N->base || E->noshort != N->noshort || E->skip != N->skip;
   bool badv = false;
   double dl[6];
   bool fin[6];
@@ -294,11 +294,12 @@ __device__ __forceinline__ SegCheck d4_check(const SegSnap* E, const SegSnap* N,
     dl[s] = (double)ec - (double)nc;          // exact in double
     if (nf) vmin = fminf(vmin, nc);
   }
-  // cell `base` is the next position: always reached
-  const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)__double_as_longlong(dl[0]), 0);
-  const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(__double_as_longlong(dl[0]) >> 32), 0);
+  // the cell of the next position — `base`, or base + skip behind a long-run shortcut — is always reached
+  const u32 ref = (u32)__builtin_amdgcn_readfirstlane((int)(E->skip < 32u ? E->skip : 0u));
+  const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)__double_as_longlong(dl[0]), ref);
+  const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(__double_as_longlong(dl[0]) >> 32), ref);
   const double d0 = __longlong_as_double((long long)(((u64)hi << 32) | lo));
-  const bool fin0 = __builtin_amdgcn_readlane(fin[0] ? 1 : 0, 0) != 0;
+  const bool fin0 = __builtin_amdgcn_readlane(fin[0] ? 1 : 0, ref) != 0;
 #pragma unroll
   for (int s = 0; s < 6; ++s) badv |= fin[s] && dl[s] != d0;
   SegCheck r;
@@ -783,7 +784,7 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
     D3_STORE_LA()                                       // the last step
 #undef D3_STORE_LA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA in flight when the ring is reused
-    if (J.exit && lane == 0) { J.exit->base = W.base; J.exit->noshort = W.noshort ? 1u : 0u; }
+    if (J.exit && lane == 0) { J.exit->base = W.base; J.exit->noshort = W.noshort ? 1u : 0u; J.exit->skip = 0u; }
     if (PROF && P.prof && lane == 0) {
       u64* o = P.prof + (u64)b * ZMX_PROF_N + 16;
       for (int i = 0; i < 4; ++i) atomicAdd(&o[i], tq[i]);
@@ -985,7 +986,7 @@ __global__ __launch_bounds__(64) void k_dpscan(Dp4Params P) {
 __device__ __forceinline__ void d4_copy_over(const Dp4Params& P, u32 t, u32 B, u16* la) {
   const u32 pend = P.tasks[t].pend;
   if (pend > B) return;                       // the last task of the block runs to the end
-  const u32 stop = P.exit[t].base;
+  const u32 stop = P.exit[t].base + P.exit[t].skip;   // (cells of the last window that a shortcut had already consumed: zmx_dp5.h)
   const u16* over = P.over + (u64)t * SEG_OVER;
   for (u32 i = threadIdx.x; pend + i < stop && pend + i <= B; i += blockDim.x) la[pend + i] = over[i];
 }

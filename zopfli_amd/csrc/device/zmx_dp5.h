@@ -72,9 +72,11 @@ __global__ __launch_bounds__(256) void k_mkdesc(MkDescParams P) {
   uint2 dhw = make_uint2(0, 0);
   if (p < B) dhw = P.dph[bd.pos_off + p];
   // (whole waves take part in the ballots and the shuffle; a wave covers two windows)
-  const bool flagged = p >= B || (dhw.y >> 16) != 0;
+  const bool flagged = p >= B || ((dhw.y >> 16) & 1u) != 0;
   const u64 not1 = __ballot(flagged || (dhw.y & 0xffffu) + (lane & 31u) >= 64u);    // an edge beyond cell register 0
-  const u64 not2 = __ballot(flagged);                                                // flagged for the shortcut, or short
+  // flagged for the shortcut, or short — or a wide run row (k_rowscan): those go position by position, where their
+  // weights come from the run-row table instead of six scattered code loads (d5_run_job)
+  const u64 not2 = __ballot(flagged || (((dhw.y >> 17) & 1u) != 0 && (dhw.y & 0xffffu) >= 64u));
   const u32 first = (u32)__shfl((int)dhw.x, (int)(lane & 32u), 64);                  // row offset of the window's first position
   const u32 w = P.win_off[blockIdx.y] + (p >> 5);
   u32* wm = P.wmeta + (u64)w * D5_WM;
@@ -179,16 +181,41 @@ __device__ __forceinline__ void d5_build_inttab(const double (&s_wtab)[ZMX_WTAB]
   }
 }
 
+// The weights of a run row's edges, by slot of the row (slot k1 = edge k - 1): [0] the literal's place (the caller puts
+// the position's own literal there), [1] the dead slot k = 2, [k1] = weight of (length k1 + 1, distance 1) — squeeze.c:146-157
+// with dsym = 0 — for k1 = 2 .. 257, +inf beyond.  Built by the whole workgroup from its weight table.
+#define D5_W1 264u
+__device__ __forceinline__ void d5_build_w1(const double (&s_wtab)[ZMX_WTAB], double* s_w1, u8* s_sym1) {
+  for (u32 k1 = threadIdx.x; k1 < D5_W1; k1 += blockDim.x) {
+    double w = __longlong_as_double(0x7ff0000000000000ll);
+    u32 sym = 31u;                           // no edge
+    if (k1 >= 2 && k1 <= 257) {
+      sym = (u32)(dev_length_symbol(k1 + 1u) - 257);
+      w = s_wtab[257u + 30u * sym];
+    }
+    if (k1 == 0) sym = 29u;                  // the literal's entry of the wave's integer table
+    s_w1[k1] = w;
+    s_sym1[k1] = (u8)sym;
+  }
+  __syncthreads();
+}
+
 struct D5Cls {          // one window on the generic path: lane l < 32 = position wbase + l
   u32 kend, roff;
   u64 ms;               // flagged for the long-run shortcut
+  u32 fl;               // bit 0: a run row (k_rowscan), bits 1..8: the literal
+  u64 mb;               // owns an edge below mincost in this run (k_badscan)
   u32 nav;
 };
 
-template <bool PROF>
+// RUNS: the variant for tasks that walk runs of equal bytes (the run-row vector, staged codes of wide rows, window
+// headers asked for ahead): built as a kernel of its own, k_dp5_spec<.., true>, so that what it keeps in registers
+// is not the text tasks' problem (with both in one body k_dp5_spec<.., false> spilled and lost a fifth of its speed).
+template <bool PROF, bool RUNS>
 __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u32 b, const BlockDesc& bd,
                                            const double (&s_wtab)[ZMX_WTAB], float* s_xc, u16* s_xl, u16* s_stage,
-                                           const uint2 (&s_itab)[ZMX_WTAB], const D5IntTab& IT) {
+                                           const uint2 (&s_itab)[ZMX_WTAB], const D5IntTab& IT, const double* s_w1,
+                                           const u8* s_sym1, uint2* s_ri) {
   typedef __attribute__((address_space(3))) const u16* lds_u16p;
   typedef __attribute__((address_space(3))) d5_u32x4* lds_u4p;
   // (the LDS byte address of the wave's staging area, halved: it joins the scalar part of the lanes' addresses)
@@ -247,10 +274,25 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
   float vmax = 0.0f;
   u32 wbase = (u32)__builtin_amdgcn_readfirstlane((int)J.start);
   bool noshort = J.noshort != 0;
+  // After a long-run shortcut the cell registers are put back on the 32-position grid (windows at multiples of 32 from
+  // the block start: every task then takes its snapshots at the same bases, whatever shortcuts lie behind it); the
+  // first `skip` positions of that window lie inside the shortcut's span and are not walked.
+  u32 skip = J.load ? (u32)__builtin_amdgcn_readfirstlane((int)J.init->skip) : 0u;
+  // the wave's integer table of the run-row weights (29 length symbols at distance symbol 0, and one literal) for one
+  // binade: r1_lo = bit pattern of its 2^e (0 = none built), see the run-row step below
+  u32 r1_lo = 0, r1_lit = 0xffffffffu, r1_rmax = 0;
+  // the header (dph, bad-edge word) of the generic window that will follow the current one, asked for as soon as the
+  // current one's shortcut flags say where that is: behind a shortcut a window is one position and a jump, and the
+  // header's round trip was most of its time
+  u32 st_base = 0, st_n = 0;        // codes [st_base, st_base + st_n) of the block are in the staging area (generic rows)
+  u32 gpf_base = SEG_NONE, gpf_bw = 0;
+  uint2 gpf_dh = make_uint2(0, 0);
+  const u32 tiemask_b = P.tiemask[b];
   u64 n_fast = 0, n_slow = 0, n_int = 0;
   u64 kc[4] = {0, 0, 0, 0}, kn[4] = {0, 0, 0, 0};   // PROF: cycles / positions per window class: integer, class 1 in doubles, class 2, generic
   u64 pw[4] = {0, 0, 0, 0};   // PROF, integer windows: class decision, wait for the prefetched data, staging + prefetch issue, retire
   u64 pq[3] = {0, 0, 0};   // PROF: cycles of the integer windows: issuing the row fetches, waiting for them, the chain
+  u64 gq[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // PROF, generic windows: cycles / count of shortcuts, run rows (integer, doubles), other rows, window headers
   const u64 t_begin = PROF ? (u64)__builtin_readcyclecounter() : 0ull;
 
   // The codes of the rows of positions U0 .. U0 + 15 of a window whose codes are staged in LDS (below): lane l
@@ -312,7 +354,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
       // registers hold now is compared with the predecessor's exit state
 #pragma unroll
       for (int s = 0; s < 6; ++s) { J.entry->c[64u * s + lane] = c[s]; J.entry->l[64u * s + lane] = l[s]; }
-      if (lane == 0) { J.entry->base = wbase; J.entry->noshort = noshort ? 1u : 0u; }
+      if (lane == 0) { J.entry->base = wbase; J.entry->noshort = noshort ? 1u : 0u; J.entry->skip = skip; }
       la_lo = wbase;
       vmax = 0.0f;
     }
@@ -321,13 +363,16 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
     const u64 np0 = n_fast + n_slow;
     u32 pcls = 3;
     u32 kind;
-    if (pf_w == (wbase >> 5) && (wbase & 31u) == 0 && wbase + 32u <= B) {
+    if (skip) {
+      kind = 0;
+    } else if (pf_w == (wbase >> 5) && (wbase & 31u) == 0 && wbase + 32u <= B) {
       const u32 f = rdlane_u32(pf_meta, 34), g = bit_off + wbase;
       const u64 two = ((u64)rdlane_u32(pf_meta, 41) << 32) | rdlane_u32(pf_meta, 40);
       kind = f != 0 && (u32)(two >> (g & 31u)) == 0 ? f : 0u;
     } else {
       kind = win_kind(wbase);
     }
+    if (kind != 0) st_n = 0;          // (the other windows use the staging area their own way)
     if (kind == 1) {
       // ---- 32 positions, one cell register, no flags
       u32 lt_ = 0;                             // 1 + index of the last position that updated the cell
@@ -495,22 +540,42 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
       if (pf_w != SEG_NONE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pf_w = SEG_NONE; }   // (the shortcut spills cells where codes may be landing)
       D5Cls W;
       W.nav = B - wbase < 32u ? B - wbase : 32u;
+      const bool fine_ = PROF && P.debug == 7;   // (the per-position timers cost a scalar-memory round trip each)
+      const u64 th0_ = fine_ ? (u64)__builtin_readcyclecounter() : 0ull;
       {
         const u32 jj = wbase + lane;
         const bool act = lane < W.nav;
         const u32 cur = jj < B ? jj : B - 1;
-        const uint2 dh = dbase[cur];
-        const u32 bw = badpos[(bit_off + cur) >> 5];
+        uint2 dh;
+        u32 bw;
+        if (RUNS && gpf_base == wbase) { dh = gpf_dh; bw = gpf_bw; }
+        else { dh = dbase[cur]; bw = badpos[(bit_off + cur) >> 5]; }
+        if (RUNS) {
+          u64 ms_ = __ballot(act && ((dh.y >> 16) & 1u) != 0 && lane >= skip);
+          if (noshort) ms_ &= ~(1ull << skip);
+          const u32 nxt = ms_ ? ((wbase + (u32)__ffsll((long long)ms_) - 1u + ZMX_MAX_MATCH) & ~31u) : wbase + 32u;
+          gpf_base = nxt;
+          const u32 nj = nxt + lane < B ? nxt + lane : B - 1;
+          gpf_dh = dbase[nj];
+          gpf_bw = badpos[(bit_off + nj) >> 5];
+        }
         W.kend = act ? (dh.y & 0xffffu) : 0u;
         W.roff = dh.x;
-        W.ms = __ballot(act && (dh.y >> 16) != 0);
+        W.ms = __ballot(act && ((dh.y >> 16) & 1u) != 0);
+        W.fl = dh.y >> 17;
+        W.mb = __ballot(act && ((bw >> ((bit_off + cur) & 31u)) & 1u) != 0);
       }
-      if (noshort) W.ms &= ~1ull;      // squeeze.c:273: the position right after a shortcut is not tested again
-      for (u32 p = 0; p < W.nav; ++p) {
+      if (noshort) W.ms &= ~(1ull << skip);   // squeeze.c:273: the position right after a shortcut is not tested again
+      if (fine_) { gq[8] += (u64)__builtin_readcyclecounter() - th0_ + (u64)(W.kend & 0u); ++gq[9]; }
+      const u32 skip0 = skip;                 // (cells below it were given their lengths by the shortcut)
+      for (u32 p = skip; p < W.nav; ++p) {
         const u32 j = wbase + p;
+        const u64 tp0_ = fine_ ? (u64)__builtin_readcyclecounter() : 0ull;
+        u32 gk_ = 6;
         if ((W.ms >> p) & 1) {
           // long-run shortcut at position j (squeeze.c:251-271)
-          if (lane < p && wbase + lane >= la_lo) put_la(wbase + lane, (u16)(l[0] ? wbase + lane + 1 - l[0] : 0u));
+          if (lane >= skip0 && lane < p && wbase + lane >= la_lo) put_la(wbase + lane, (u16)(l[0] ? wbase + lane + 1 - l[0] : 0u));
+          st_n = 0;                               // (the cells are spilled where the staged codes lie)
           wave_lds_sync();
 #pragma unroll
           for (int s = 0; s < 6; ++s) {
@@ -522,26 +587,26 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
           wave_lds_sync();
           // costs[j+t+258] = costs[j+t] + symbolcost for t = 0..257, unconditionally; cells
           // j..j+257 are consumed with the lengths they have now
-          float nc4[5];
 #pragma unroll
           for (int r = 0; r < 5; ++r) {
             const u32 t = 64u * r + lane;
-            nc4[r] = 1e30f;
-            if (t < ZMX_MAX_MATCH) {
-              if (j + t >= la_lo) put_la(j + t, s_xl[p + t]);
-              nc4[r] = (float)((double)s_xc[p + t] + symbolcost258);
-            }
+            if (t < ZMX_MAX_MATCH && j + t >= la_lo) put_la(j + t, s_xl[p + t]);
           }
+          // the registers go to the window that holds position j + 258: cell j + 258 + t sits at index t + d
+          const u32 d = (j + ZMX_MAX_MATCH) & 31u;
 #pragma unroll
-          for (int s = 0; s < 6; ++s) { c[s] = 1e30f; l[s] = 0; }
-#pragma unroll
-          for (int r = 0; r < 5; ++r) {
-            const u32 t = 64u * r + lane;
-            if (t < ZMX_MAX_MATCH) { c[r] = nc4[r]; l[r] = j + t + 1; }
+          for (int s = 0; s < 6; ++s) {
+            const u32 t = 64u * s + lane - d;
+            const bool in = t < ZMX_MAX_MATCH;
+            const float v = s_xc[in ? p + t : 0u];
+            c[s] = in ? (float)((double)v + symbolcost258) : 1e30f;
+            l[s] = in ? j + t + 1 : 0u;
           }
           wave_lds_sync();
-          wbase = j + ZMX_MAX_MATCH;           // the registers now sit there
-          reach = ZMX_MAX_MATCH - 1;
+          if (fine_) { gq[0] += (u64)__builtin_readcyclecounter() - tp0_; ++gq[1]; }
+          wbase = j + ZMX_MAX_MATCH - d;
+          skip = d;
+          reach = ZMX_MAX_MATCH - 1 + d;
           noshort = true;
           jumped = true;
           break;
@@ -553,7 +618,122 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
         const u32 km1 = lane - p - 1;
         const u32 smax = (ke + p) >> 6;
         reach = reach > ke + p ? reach : ke + p;
-        if (smax < 2) {
+        const u32 fl = rdlane_u32(W.fl, p);
+        if (RUNS && (fl & 1u)) {
+          // a run row (k_rowscan): the literal and (k, distance 1) for k = 3 .. ke — weights from tables of those edges,
+          // nothing read from codes[]: inside runs of equal bytes, where every row is 258 wide, the six scattered code
+          // loads per position were all the time there was (2 600 - 3 500 cycles a position).
+          const u32 lit = (fl >> 1) & 255u;
+          // The integer step (see D5IntTab above; the same arithmetic on the bit patterns) needs only the SOURCE cell
+          // inside the table's binade with room for the largest weight: a target in a higher binade (or unreached,
+          // 1e30) compares greater as a bit pattern exactly when it is greater, one in a lower binade smaller.  The
+          // table is the wave's own — 29 length symbols at distance symbol 0 plus the run's literal, for one binade —
+          // and is rebuilt when the chain leaves the binade or the literal changes (a few times per task).
+          const u32 sj = rdlane_u32(__float_as_uint(c[0]), p);
+          bool ipos = P.int_path != 0 && ((W.mb >> p) & 1ull) == 0 && sj >= 0x41800000u && sj < 0x4f000000u;   // (2^4 .. 2^31)
+          if (ipos && ((sj & 0x7f800000u) != r1_lo || lit != r1_lit)) {
+            const int e = (int)(sj >> 23) - 127;
+            r1_lo = 0;
+            if (((tiemask_b >> (e & 31)) & 1u) == 0) {
+              double w = kInf;
+              if (lane < 29) w = s_wtab[257u + 30u * lane];
+              else if (lane == 29) w = s_wtab[1u + lit];
+              uint2 v = make_uint2(D5_NOEDGE, D5_NOEDGE);
+              u32 rr = 0;
+              if (w < 1e300) {
+                const u64 r = d5_rne_scaled(w, e);
+                const u64 rh = r >> 29;
+                if (rh < 0x800000ull) {
+                  rr = (u32)rh + ((r & 0x1fffffffull) > 0x10000000ull ? 1u : 0u);
+                  v.x = rr;
+                  v.y = (u32)rh;
+                } else {
+                  rr = 0x800000u;                 // (a weight of the binade's own size: the room test below keeps every position out)
+                }
+              }
+              wave_lds_sync();
+              if (lane < 32) s_ri[lane] = v;
+              wave_lds_sync();
+              r1_rmax = d5_max64(rr);
+              r1_lo = sj & 0x7f800000u;
+              r1_lit = lit;
+            }
+          }
+          ipos = ipos && r1_lo != 0 && sj + r1_rmax < r1_lo + 0x800000u;
+          if (ipos) {
+            // branch-free over the five registers a row can reach (index <= 31 + 258): the five symbol reads, then the five
+            // table reads, in flight together — one dependent pair of LDS round trips per register, register after
+            // register, was 1 700 cycles a position.  (Tried and slower: the symbols by symbols.h's closed form, 80
+            // instructions; the weights as a register vector moved one lane up per position by DPP, 1 550 cycles a
+            // position against 1 250 — a lone wave on its SIMD pays for every instruction, not for the LDS.)
+            u32 sym5[5];
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+              const u32 k1 = km1 + 64u * s;
+              sym5[s] = s_sym1[k1 < ke ? k1 : 1u];              // ([0] = 29: the literal, [1] = 31: the dead slot k = 2, no edge)
+            }
+            uint2 e5[5];
+#pragma unroll
+            for (int s = 0; s < 5; ++s) e5[s] = s_ri[sym5[s]];
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+              const u32 t_ = sj + e5[s].x, th_ = sj + e5[s].y;
+              const u32 cb = __float_as_uint(c[s]);
+              l[s] = th_ < cb ? src1 : l[s];
+              c[s] = __uint_as_float(cb < t_ ? cb : t_);
+            }
+            if (PROF) ++n_int;
+            gk_ = 2;
+          } else {
+            gk_ = 4;
+            const double wl = code_w((1u + lit) * 8u);
+            double w5[5];
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+              const u32 k1 = km1 + 64u * s;
+              w5[s] = s_w1[k1 < ke ? k1 : 1u];                  // ([1] = the dead slot k = 2: +inf)
+            }
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+              const u32 k1 = km1 + 64u * s;
+              const double w = k1 == 0 ? wl : w5[s];
+              const double mcl = k1 == 0 ? -kInf : mincost;
+              DP_RELAX(c[s], l[s], w, mcl)
+            }
+          }
+        } else if (RUNS) {
+          // any other row: its codes from the wave's staging area, where 2048 codes of the block's rows are kept from
+          // the row's first code on (the rows of consecutive positions are consecutive in codes[]: the copy serves the
+          // next rows too — eight of the widest), brought in by LDS-DMA.  One scattered 2-byte global load per register
+          // and position, a full memory round trip each time, was what these rows cost before (class Z: the last 257
+          // positions of every long run are such rows).
+          if (ro < st_base || ro + ke > st_base + st_n) {
+            st_base = ro & ~7u;
+            const u16* src_ = rows + st_base + 8u * lane;
+#pragma unroll
+            for (u32 k = 0; k < 4; ++k) dp_dma_piece(src_ + 512u * k, (stage_half << 1) + 1024u * k);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st_n = 2048u;
+          }
+          const u32 sb_ = ro - st_base;
+          u32 cd[5];
+#pragma unroll
+          for (int s = 0; s < 5; ++s) {
+            const u32 k1 = km1 + 64u * s;
+            cd[s] = s_stage[sb_ + (k1 < ke ? k1 : 0u)];
+          }
+          double wv[5];
+#pragma unroll
+          for (int s = 0; s < 5; ++s) wv[s] = code_w(cd[s] & 0x3ff8u);
+#pragma unroll
+          for (int s = 0; s < 5; ++s) {
+            const u32 k1 = km1 + 64u * s;
+            const double w = k1 < ke ? wv[s] : kInf;
+            const double mcl = k1 == 0 ? -kInf : mincost;
+            DP_RELAX(c[s], l[s], w, mcl)
+          }
+        }
+        else if (smax < 2) {
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
             if ((u32)s <= smax) {
@@ -584,6 +764,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
         }
         noshort = false;
         ++n_slow;
+        if (fine_) { gq[gk_] += (u64)__builtin_readcyclecounter() - tp0_ + (u64)(__float_as_uint(c[0]) & 0u); ++gq[gk_ + 1]; }
       }
     }
     if (PROF) { kc[pcls] += (u64)__builtin_readcyclecounter() - tw0; kn[pcls] += n_fast + n_slow - np0; }
@@ -591,7 +772,8 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
     // ---- cells wbase .. wbase + 31 are final
     {
       const u32 jj = wbase + lane;
-      if (lane < 32 && jj >= la_lo && jj <= B) put_la(jj, (u16)(l[0] ? jj + 1 - l[0] : 0u));
+      if (lane < 32 && lane >= skip && jj >= la_lo && jj <= B) put_la(jj, (u16)(l[0] ? jj + 1 - l[0] : 0u));
+      skip = 0;
       D4_TRACK_MAX()
       D3_ROT32()
       wbase += 32;
@@ -609,7 +791,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
       vmax = fmaxf(vmax, c[s] < 1e29f ? c[s] : 0.0f);
     }
     vmax = wave_max_f32(vmax);
-    if (lane == 0) { J.exit->vmax = vmax; J.exit->base = wbase; J.exit->noshort = noshort ? 1u : 0u; }
+    if (lane == 0) { J.exit->vmax = vmax; J.exit->base = wbase; J.exit->noshort = noshort ? 1u : 0u; J.exit->skip = skip; }
   }
   if (PROF && P.prof && lane == 0) {
     u64* o = P.prof + (u64)b * ZMX_PROF_N;
@@ -621,6 +803,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
     for (int i = 0; i < 3; ++i) atomicAdd(&o[20 + i], pw[i]);
     for (int i = 0; i < 4; ++i) { atomicAdd(&o[24 + i], kc[i]); atomicAdd(&o[28 + i], kn[i]); }
     atomicAdd(&o[11], pq[0]); atomicAdd(&o[12], pq[1]); atomicAdd(&o[13], pq[2]);
+    for (int i = 0; i < 10; ++i) atomicAdd(&o[32 + i], gq[i]);
     const u64 dt = (u64)__builtin_readcyclecounter() - t_begin;
     atomicMax(&o[7], dt);                               // the longest task of the block
     if (J.la_lo == 1) atomicAdd(&o[8], dt);             // the head task
@@ -642,9 +825,18 @@ struct CutParams {
   const uint2* dph;
   SegTask* tasks;
   u32 depth;
+  u32 warm;        // the warm-up a task without a cut point would get
   u32* found;      // [2]: tasks that got a cut point, sum of (pout - q) over them
+  u32* wide;       // [tasks]: 1 = no cut point, and the warm-up stretch holds long-run material (see below)
 };
 
+// A task that finds no cut point has to rely on coalescence (zmx_dp4.h) over its warm-up stretch.  Inside and
+// behind runs of equal bytes that does not happen: the long-run shortcut (squeeze.c:251-271) copies 258 cells
+// unmixed, and where every row is 258 edges of one distance the paths run side by side — measured on class Z,
+// 90 % of such tasks were re-run serially.  So a task whose warm-up stretch holds a shortcut position or a run row
+// of 64+ edges is not started at all: the host merges it into its predecessor (BuildTables), whose own start IS a
+// cut point (or the block's head) — tasks become the stretches between cut points there, every one exact by
+// construction, and the only thing left to verify is the level.
 __global__ __launch_bounds__(64) void k_cutpoints(CutParams P) {
   const u32 t = blockIdx.x;
   const SegTask K = P.tasks[t];
@@ -653,12 +845,16 @@ __global__ __launch_bounds__(64) void k_cutpoints(CutParams P) {
   const uint2* dph = P.dph + bd.pos_off;
   const u32 lane = threadIdx.x;
   const u32 lo = K.pout > P.depth + ZMX_MAX_MATCH ? K.pout - P.depth - ZMX_MAX_MATCH : 0u;
+  const u32 wlo = K.pout > P.warm ? K.pout - P.warm : 0u;
   // the prefix maximum from lo on is the true one for q >= lo + 258 (no edge is longer), and for every q if lo = 0
   const u32 q_min = lo == 0 ? 1u : lo + ZMX_MAX_MATCH;
   u32 carry = 0, best = SEG_NONE;
+  bool wide = false;
   for (u32 p0 = lo; p0 < K.pout; p0 += 64) {
     const u32 p = p0 + lane;
-    const u32 r = p < K.pout ? p + (dph[p].y & 0xffffu) : 0u;
+    const u32 y = p < K.pout ? dph[p].y : 0u;
+    const u32 r = p < K.pout ? p + (y & 0xffffu) : 0u;
+    wide |= p >= wlo && (((y >> 16) & 1u) != 0 || (((y >> 17) & 1u) != 0 && (y & 0xffffu) >= 64u));
     u32 incl = wave_scan_max(r);
     incl = incl > carry ? incl : carry;
     // q = p + 1 is a cut point; not pout itself: the start cell has no source, and the cells from pout on are
@@ -667,23 +863,52 @@ __global__ __launch_bounds__(64) void k_cutpoints(CutParams P) {
     if (ok) best = p0 + (63u - (u32)__builtin_clzll(ok)) + 1u;
     carry = rdlane_u32(incl, 63);
   }
-  if (lane == 0 && best != SEG_NONE) {
-    P.tasks[t].q = best;
-    atomicAdd(&P.found[0], 1u);
-    atomicAdd(&P.found[1], K.pout - best);
+  const bool any_wide = __any(wide);
+  if (lane == 0) {
+    P.wide[t] = best == SEG_NONE && any_wide ? 1u : 0u;
+    if (best != SEG_NONE) {
+      P.tasks[t].q = best;
+      atomicAdd(&P.found[0], 1u);
+      atomicAdd(&P.found[1], K.pout - best);
+    }
   }
+}
+
+// Which of the two k_dp5_spec variants a task is for: 1 = at least a quarter of its 32-position windows are of the
+// generic kind (shortcut positions, wide run rows: k_mkdesc), i.e. it walks runs of equal bytes.  One wave per task.
+struct TaskKindParams {
+  const SegTask* tasks;
+  const BlockDesc* blocks;
+  const u32* winflag;
+  const u32* win_off;
+  u32* kind;
+};
+__global__ __launch_bounds__(64) void k_taskkind(TaskKindParams P) {
+  const u32 t = blockIdx.x;
+  const SegTask K = P.tasks[t];
+  const BlockDesc bd = P.blocks[K.block];
+  const u32 B = (u32)(bd.inend - bd.instart);
+  const u32* wf = P.winflag + P.win_off[K.block];
+  const u32 w0 = K.q >> 5, w1 = ((K.pend < B ? K.pend : B) + 31u) >> 5;
+  u32 g = 0;
+  for (u32 w = w0 + threadIdx.x; w < w1; w += 64) g += wf[w] == 0 ? 1u : 0u;
+  g = wave_scan_add(g);
+  if (threadIdx.x == 63) P.kind[t] = 4u * g >= (w1 - w0) && g >= 4u ? 1u : 0u;
 }
 
 // One workgroup = four waves = up to four tasks of ONE block (P.wg_tasks), sharing the run's weight
 // table in LDS; after the table is in place the waves go their own ways.
 #define D5_WG 4u
 #define FIX_CH 256u       // tasks whose summaries k_dp4_fix holds in LDS at a time
-template <bool PROF, int WAVES>
+template <bool PROF, int WAVES, bool RUNS>
 __global__ __launch_bounds__(64 * D5_WG, WAVES) void k_dp5_spec(Dp4Params P) {
   __shared__ __align__(16) double s_wtab[ZMX_WTAB];
   // per wave: the staged codes of a window (4 KB + the alignment slack), or the cells of a long-run shortcut
   __shared__ __align__(16) unsigned char s_buf[D5_WG][D5_STAGE_BYTES];
   __shared__ __align__(8) uint2 s_itab[ZMX_WTAB];
+  __shared__ __align__(8) double s_w1[D5_W1];
+  __shared__ u8 s_sym1[D5_W1];
+  __shared__ __align__(8) uint2 s_ri[D5_WG][32];
   __shared__ u32 s_rmax;
   const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (P.redo_pass && blockIdx.x >= *P.redo_count) return;
@@ -693,6 +918,7 @@ __global__ __launch_bounds__(64 * D5_WG, WAVES) void k_dp5_spec(Dp4Params P) {
   for (u32 i = threadIdx.x; i < ZMX_WTAB; i += 64 * D5_WG) s_wtab[i] = P.wtab[(u64)b0 * ZMX_WTAB + i];
   if (threadIdx.x == 0) s_rmax = 0;
   __syncthreads();
+  d5_build_w1(s_wtab, s_w1, s_sym1);
   // the level a speculative task starts from
   auto task_level = [&](u32 tt) -> float {
     const SegTask K = P.tasks[tt];
@@ -747,8 +973,8 @@ __global__ __launch_bounds__(64 * D5_WG, WAVES) void k_dp5_spec(Dp4Params P) {
     J.level = task_level(t);
     if (P.est_bits && (threadIdx.x & 63) == 0) P.lvl[t] = J.level;
   }
-  d5_run_job<PROF>(P, J, T.block, bd, s_wtab, reinterpret_cast<float*>(s_buf[wave]), reinterpret_cast<u16*>(s_buf[wave] + 4u * DP_XN),
-                   reinterpret_cast<u16*>(s_buf[wave]), s_itab, IT);
+  d5_run_job<PROF, RUNS>(P, J, T.block, bd, s_wtab, reinterpret_cast<float*>(s_buf[wave]), reinterpret_cast<u16*>(s_buf[wave] + 4u * DP_XN),
+                   reinterpret_cast<u16*>(s_buf[wave]), s_itab, IT, s_w1, s_sym1, s_ri[wave]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -774,6 +1000,10 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
   const u32 tiemask = P.tiemask[b];
   for (u32 i = threadIdx.x; i < ZMX_WTAB; i += blockDim.x) s_wtab[i] = P.wtab[(u64)b * ZMX_WTAB + i];
   __syncthreads();
+  __shared__ __align__(8) double s_w1[D5_W1];
+  __shared__ u8 s_sym1[D5_W1];
+  __shared__ __align__(8) uint2 s_ri[32];
+  d5_build_w1(s_wtab, s_w1, s_sym1);
   u16* la_block = P.la + bd.la_off;
   d4_copy_over(P, t0, B, la_block);   // the head is exact
   double delta_prev = 0.0;     // what has to be added to exit[t - 1] to get the true values
@@ -795,7 +1025,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
     const SegCheck k = P.chk[c0 + i];
     s_ck_d[i] = k.d; s_ck_vmin[i] = k.vmin; s_ck_match[i] = k.match;
     s_vmax[i] = P.exit[c0 + i].vmax;
-    s_xbase[i] = P.exit[c0 + i].base;
+    s_xbase[i] = P.exit[c0 + i].base + P.exit[c0 + i].skip;   // (where the task's own cells end: d4_copy_over)
     s_pend[i] = P.tasks[c0 + i].pend;
     s_acc[i] = 0;
     s_dl[i] = 0.0;
@@ -814,6 +1044,23 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
     if (ok) {
       why = d4_accept(ck.vmin, (double)s_vmax[ti], delta, wmax, tiemask);
       ok = why == 0;
+    }
+    if (P.debug == 6 && ck.match == 0 && threadIdx.x < 64) {
+      // where the two states differ: the first cell whose reach, source or value shape is not the same
+      const SegSnap* E = &P.exit[t - 1];
+      const SegSnap* N = &P.entry[t];
+      u32 first = 0xffffffffu;
+      for (int s6 = 0; s6 < 6; ++s6) {
+        const u32 i = 64u * s6 + lane;
+        const bool ef = E->c[i] < 1e29f, nf = N->c[i] < 1e29f;
+        if ((ef != nf || E->l[i] != N->l[i]) && i < first) first = i;
+      }
+      for (int o = 32; o >= 1; o >>= 1) { const u32 v = __shfl_xor(first, o, 64); first = v < first ? v : first; }
+      if (lane == 0) {
+        const u32 i = first < SEG_CELLS ? first : 0;
+        printf("diff b %u t %u pout %u base %u/%u noshort %u/%u skip %u/%u first cell %u: exit c %.4f l %u | entry c %.4f l %u | q %u\n", b, t - t0, P.tasks[t].pout,
+               E->base, N->base, E->noshort, N->noshort, E->skip, N->skip, first, (double)E->c[i], E->l[i], (double)N->c[i], N->l[i], P.tasks[t].q);
+      }
     }
     if (P.debug == 1 && lead) {
       printf("fix b %u t %u pout %u: match %u d %.6f delta %.6f vmin %.4f vmax %.4f why %u ok %d entry base %u exit-1 base %u\n", b,
@@ -847,17 +1094,25 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
     n_pos += (T.pend < B ? T.pend : B) - (J.start < B ? J.start : B);
     // windows of the task that k_dp5_spec's fast paths cannot take (k_mkdesc)
     const u32 w0 = J.start >> 5, w1 = ((T.pend < B ? T.pend : B) + 31u) >> 5;
-    u32 generic = 0;
-    for (u32 w = w0 + threadIdx.x; w < w1; w += blockDim.x) generic += winflag[w] == 0 ? 1u : 0u;
-    // (the barrier also means: every wave has read the old exit[t] / exit[t - 1])
-    const bool lean = __syncthreads_count((int)generic) >= P.fix_lean_min ? true : false;
+    u32 generic = 0, mine = 0;
+    for (u32 w = w0 + threadIdx.x; w < w1; w += blockDim.x) { generic += winflag[w] == 0 ? 1u : 0u; ++mine; }
+    // (the barriers also mean: every wave has read the old exit[t] / exit[t - 1])
+    // (automatic, P.fix_lean_min < 0: the lean job where most of the windows are of the generic kind — runs of equal
+    //  bytes: its run-row path reads no codes, the pipeline's ring would restart at every shortcut.  Counted per
+    //  thread: a merged task has thousands of windows)
+    const int n_generic = __syncthreads_count((int)generic);
+    const int n_major = __syncthreads_count(mine > 0 && 2 * generic >= mine ? 1 : 0);
+    const int n_have = __syncthreads_count(mine > 0 ? 1 : 0);
+    // (a predecessor that stopped inside a shortcut's window — skip — can only be continued by the job that knows
+    //  about it)
+    const bool lean = P.exit[t - 1].skip != 0 || (P.fix_lean_min >= 0 ? n_generic >= P.fix_lean_min : 2 * n_major >= n_have);
     const u64 cr0 = __builtin_readcyclecounter();
     if (lean) {
       ++n_lean;
       if (threadIdx.x < 64) {
         D5IntTab IT;
         IT.on = false; IT.lo = 0; IT.span = 0;
-        d5_run_job<PROF>(P, J, b, bd, s_wtab, s_xc, s_xl, s_ring, *reinterpret_cast<const uint2 (*)[ZMX_WTAB]>(&s_t1[0][0]), IT);
+        d5_run_job<PROF, true>(P, J, b, bd, s_wtab, s_xc, s_xl, s_ring, *reinterpret_cast<const uint2 (*)[ZMX_WTAB]>(&s_t1[0][0]), IT, s_w1, s_sym1, s_ri);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __syncthreads();

@@ -16,6 +16,8 @@
 
 #include "zmx_kernels.h"
 #include "zmx_match2.h"
+#include "zmx_match3.h"
+#include "zmx_match4.h"
 #include "zmx_dp4.h"
 #include "zmx_dp5.h"
 #include "zmx_encode.h"
@@ -65,6 +67,7 @@ struct DeviceGuard {
 
 constexpr int kTooLarge = -2;   // zmx_tables_build*: the batch does not fit the code budget, try fewer blocks
 constexpr u32 kMatchGrid = 1024;  // persistent workgroups: 256 CUs x 4 (LDS-limited)
+constexpr u32 kMatchGrid3 = 768;  // k_match3: 256 CUs x 3
 constexpr size_t kInputPad = 4096;
 
 // ---------------------------------------------------------------------------------------------
@@ -109,6 +112,8 @@ struct zmx_ctx {
   std::vector<std::pair<void*, size_t>> pool_free;
   size_t pool_free_bytes = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t stream2 = nullptr;   // the run tasks' k_dp5_spec beside the others' (zmx_squeeze_run)
+  hipEvent_t ev2[2] = {nullptr, nullptr};
   u32* h_stage = nullptr;    // pinned staging for store downloads (grow-only)
   size_t stage_cap = 0;      // in u32
   // ZOPFLI_AMD_GUARD (below): the bytes the caller asked for and who asked, per live allocation (keyed like pool_live)
@@ -130,7 +135,17 @@ struct zmx_tables {
   u32* d_tile_off = nullptr;
   u16* d_same16 = nullptr;
   ushort4* d_links = nullptr;
-  bool links_partial = false;     // built from a parent: the hash arrays exist only where k_match2 read them
+  bool links_partial = false;     // built from a parent: the hash arrays exist only where the match kernel read them
+  // k_bucket's order of every 32768-position chunk by (hash value, position), per hash (zmx_match3.h)
+  u16* d_sorted_alloc = nullptr;
+  u16* d_sorted[2] = {nullptr, nullptr};   // (inside d_sorted_alloc)
+  u16* d_rank[2] = {nullptr, nullptr};
+  u32* d_bucket[2] = {nullptr, nullptr};
+  u8* d_ssame = nullptr;
+  u32* d_chunk_base = nullptr;
+  std::vector<u32> chunk_base;    // [nb + 1] first chunk of each block
+  size_t merged_tasks = 0;        // tasks merged into their predecessors (BuildTables): the set has long tasks
+  bool buckets = false;           // the hash arrays are k_bucket's (k_match3), not k_chain's links (k_match2)
   u32* d_recs = nullptr;
   u32* d_pool = nullptr;
   u32 pool_cap = 0;
@@ -173,6 +188,7 @@ struct zmx_tables {
   u32* d_task_off = nullptr;
   u32* d_wg_tasks = nullptr;       // k_dp5_spec's workgroups: four tasks of one block each
   u32 n_wg = 0;
+  u32 n_wg_runs = 0;               // ... of which the last n_wg_runs hold run tasks (k_taskkind): k_dp5_spec<.., true>
   u32* d_wmeta = nullptr;          // per 32-position window: 40 words, what k_dp5_spec needs to fetch its rows (k_mkdesc)
   u32* d_winroff = nullptr;        // per 32-position window: offset of its first row in the block's codes (k_mkdesc)
   u32* d_winflag = nullptr;        // per 32-position window: fast path possible (k_mkdesc)
@@ -261,6 +277,15 @@ hipError_t PoolAllocT(zmx_ctx* c, T** p, size_t n, const char* tag) {
 bool MatchFilter() {
   static const bool on = [] { const char* e = std::getenv("ZOPFLI_AMD_MATCH_FILTER"); return e ? std::atoi(e) != 0 : true; }();
   return on;
+}
+
+// Which match-table kernel (ZOPFLI_AMD_MATCH): 2 = k_chain + k_match2 (prev links, a lane per position; the default:
+// still the fastest on every class measured, profiles/r03_match_ab.txt), 3 = k_bucket + k_match3 (sorted candidate
+// slices, a wave per position, 64 candidates per coalesced load), 4 = k_bucket + k_match4 (the same slices streamed
+// by a lane per position, four candidates per step).  All three produce the same records (tests).
+int MatchKernel() {
+  static const int v = [] { const char* e = std::getenv("ZOPFLI_AMD_MATCH"); const int k = e ? std::atoi(e) : 2; return k == 3 || k == 4 ? k : 2; }();
+  return v;
 }
 
 struct PoolScope {
@@ -397,6 +422,8 @@ int zmx_ctx_create(int device, zmx_ctx** out) {
   c->device = device;
   HIPCHK(hipStreamCreate(&c->stream));
   for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreate(&c->ev[i]));
+  HIPCHK(hipStreamCreate(&c->stream2));
+  for (int i = 0; i < 2; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev2[i], hipEventDisableTiming));
   {
     // Budgets from what the device has, not from what an MI355X has on paper: several contexts may share one
     // device (ZOPFLI_AMD_DEVICES=0,0), other processes may hold memory already.
@@ -408,6 +435,8 @@ int zmx_ctx_create(int device, zmx_ctx** out) {
 
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
                              CH_LDS_BYTES));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             BK_LDS_BYTES));
   *out = c;
   return 0;
 }
@@ -421,6 +450,8 @@ void zmx_ctx_destroy(zmx_ctx* c) {
   for (auto& f : c->pool_live) (void)hipFree(c->guard_live.count(f.first) ? static_cast<unsigned char*>(f.first) - kGuardBytes : f.first);
   (void)hipFree(c->d_guard_tab);
   for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  for (int i = 0; i < 2; ++i) if (c->ev2[i]) (void)hipEventDestroy(c->ev2[i]);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -449,6 +480,10 @@ void zmx_tables_free(zmx_ctx* c, zmx_tables* t) {
   PoolFree(c, t->d_tile_off);
   PoolFree(c, t->d_same16);
   PoolFree(c, t->d_links);
+  PoolFree(c, t->d_sorted_alloc);
+  for (int h = 0; h < 2; ++h) { PoolFree(c, t->d_rank[h]); PoolFree(c, t->d_bucket[h]); }
+  PoolFree(c, t->d_ssame);
+  PoolFree(c, t->d_chunk_base);
   PoolFree(c, t->d_recs);
   PoolFree(c, t->d_pool);
   PoolFree(c, t->d_la);
@@ -600,7 +635,28 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   HIPCHK(PoolAlloc(c, &t->d_blocks, nb));
   HIPCHK(PoolAlloc(c, &t->d_tile_off, nb + 1));
   HIPCHK(PoolAlloc(c, &t->d_same16, reg_off));
-  HIPCHK(PoolAlloc(c, &t->d_links, reg_off));
+  t->buckets = MatchKernel() != 2;
+  t->chunk_base.assign(nb + 1, 0);
+  for (size_t b = 0; b < nb; ++b) {
+    const u64 L = t->blocks[b].inend - t->blocks[b].ws;
+    t->chunk_base[b + 1] = t->chunk_base[b] + static_cast<u32>((L + BK_CH - 1) / BK_CH);
+  }
+  if (t->buckets) {
+    // (the two orders in one allocation, M4_PAD entries in front: k_match4 reads 16 bytes at a time, from up to 15 entries
+    //  below a chunk's first one, and takes the second order as an offset from the first)
+    HIPCHK(PoolAlloc(c, &t->d_sorted_alloc, 2 * reg_off + 2 * M4_PAD));
+    t->d_sorted[0] = t->d_sorted_alloc + M4_PAD;
+    t->d_sorted[1] = t->d_sorted[0] + reg_off + M4_PAD;
+    for (int h = 0; h < 2; ++h) {
+      HIPCHK(PoolAlloc(c, &t->d_rank[h], reg_off));
+      HIPCHK(PoolAlloc(c, &t->d_bucket[h], static_cast<size_t>(t->chunk_base[nb]) * 32768u));
+    }
+    HIPCHK(PoolAlloc(c, &t->d_ssame, reg_off));
+    HIPCHK(PoolAlloc(c, &t->d_chunk_base, nb + 1));
+    HIPCHK(hipMemcpyAsync(t->d_chunk_base, t->chunk_base.data(), (nb + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+  } else {
+    HIPCHK(PoolAlloc(c, &t->d_links, reg_off));
+  }
   HIPCHK(PoolAlloc(c, &t->d_recs, pos_off * 8));
   HIPCHK(PoolAlloc(c, &t->d_la, la_off));
   HIPCHK(PoolAlloc(c, &t->d_store[0], pos_off));
@@ -647,9 +703,21 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     KCHK(c, "k_same");
     HIPCHK(hipGetLastError());
     const dim3 g2(static_cast<unsigned>((max_l + CH_EMIT - 1) / CH_EMIT), static_cast<unsigned>(nb), 2);
-    hipLaunchKernelGGL(k_chain, g2, dim3(64), CH_LDS_BYTES, c->stream, c->d_in, t->d_blocks, t->d_same16, t->d_links, d_link_lo);
-    KCHK(c, "k_chain");
-    HIPCHK(hipGetLastError());
+    if (t->buckets) {
+      BucketParams kp;
+      kp.in = c->d_in;
+      kp.blocks = t->d_blocks;
+      kp.same16 = t->d_same16;
+      kp.chunk_base = t->d_chunk_base;
+      kp.link_lo = d_link_lo;
+      for (int h = 0; h < 2; ++h) { kp.sorted[h] = t->d_sorted[h]; kp.rank[h] = t->d_rank[h]; kp.bucket[h] = t->d_bucket[h]; }
+      kp.ssame = t->d_ssame;
+      hipLaunchKernelGGL(k_bucket, g2, dim3(BK_THREADS), BK_LDS_BYTES, c->stream, kp);
+      KCHK(c, "k_bucket");
+    } else {
+      hipLaunchKernelGGL(k_chain, g2, dim3(64), CH_LDS_BYTES, c->stream, c->d_in, t->d_blocks, t->d_same16, t->d_links, d_link_lo);
+      KCHK(c, "k_chain");
+    }
     return 0;
   };
   {
@@ -662,9 +730,61 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     t->links_partial = reuse;
   }
 
-  if (!c->d_scratch) HIPCHK(PoolAllocT(c, &c->d_scratch, static_cast<size_t>(kMatchGrid) * M2_THREADS * SCRATCH_CPS, "d_scratch"));
+  if (MatchKernel() != 3 && !c->d_scratch) HIPCHK(PoolAllocT(c, &c->d_scratch, static_cast<size_t>(kMatchGrid) * M2_THREADS * SCRATCH_CPS, "d_scratch"));
   HIPCHK(hipEventRecord(c->ev[1], c->stream));
   double match_positions = 0;
+  // the match-table kernel over `total_tiles` tiles (all of them, or those of tile_list)
+  auto launch_match = [&](u32* pool, u32 pool_cap, u32 total_tiles, const u32* d_tiles, bool prof) -> int {
+    if (total_tiles == 0) return 0;
+    if (t->buckets) {
+      Match3Params mp;
+      mp.in = c->d_in;
+      mp.blocks = t->d_blocks;
+      mp.tile_off = t->d_tile_off;
+      mp.nb = static_cast<u32>(nb);
+      mp.total_tiles = total_tiles;
+      mp.same16 = t->d_same16;
+      mp.chunk_base = t->d_chunk_base;
+      for (int h = 0; h < 2; ++h) { mp.sorted[h] = t->d_sorted[h]; mp.rank[h] = t->d_rank[h]; mp.bucket[h] = t->d_bucket[h]; }
+      mp.ssame = t->d_ssame;
+      mp.recs = t->d_recs;
+      mp.pool = pool;
+      mp.pool_cap = pool_cap;
+      mp.counters = t->d_counters;
+      mp.tile_list = d_tiles;
+      mp.scratch = c->d_scratch;
+      if (MatchKernel() == 3) {
+        if (prof) hipLaunchKernelGGL((k_match3<true>), dim3(kMatchGrid3), dim3(M3_THREADS), 0, c->stream, mp);
+        else hipLaunchKernelGGL((k_match3<false>), dim3(kMatchGrid3), dim3(M3_THREADS), 0, c->stream, mp);
+        KCHK(c, "k_match3");
+      } else {
+        if (prof) hipLaunchKernelGGL((k_match4<true>), dim3(kMatchGrid3), dim3(M4_THREADS), 0, c->stream, mp);
+        else hipLaunchKernelGGL((k_match4<false>), dim3(kMatchGrid3), dim3(M4_THREADS), 0, c->stream, mp);
+        KCHK(c, "k_match4");
+      }
+      return 0;
+    }
+    MatchParams mp;
+    mp.in = c->d_in;
+    mp.blocks = t->d_blocks;
+    mp.tile_off = t->d_tile_off;
+    mp.nb = static_cast<u32>(nb);
+    mp.total_tiles = total_tiles;
+    mp.links = t->d_links;
+    mp.recs = t->d_recs;
+    mp.pool = pool;
+    mp.pool_cap = pool_cap;
+    mp.counters = t->d_counters;
+    mp.scratch = c->d_scratch;
+    mp.tile_list = d_tiles;
+    const bool filt = MatchFilter();
+    if (prof && filt) hipLaunchKernelGGL((k_match2<true, true>), dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
+    else if (prof) hipLaunchKernelGGL((k_match2<true, false>), dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
+    else if (filt) hipLaunchKernelGGL((k_match2<false, true>), dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
+    else hipLaunchKernelGGL((k_match2<false, false>), dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
+    KCHK(c, "k_match2");
+    return 0;
+  };
 
   if (reuse) {
     // copy every record, adopt the parent's change-point pool (copied records point into it) and
@@ -692,25 +812,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     // the pool cursor continues where the parent's stopped
     HIPCHK(hipMemsetAsync(t->d_counters, 0, 16 * sizeof(u32), c->stream));
     HIPCHK(hipMemcpyAsync(t->d_counters, parent->d_counters, sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
-    MatchParams mp;
-    mp.in = c->d_in;
-    mp.blocks = t->d_blocks;
-    mp.tile_off = t->d_tile_off;
-    mp.nb = static_cast<u32>(nb);
-    mp.total_tiles = static_cast<u32>(tile_list.size());
-    mp.links = t->d_links;
-    mp.recs = t->d_recs;
-    mp.pool = parent->d_pool;
-    mp.pool_cap = parent->pool_cap;
-    mp.counters = t->d_counters;
-    mp.scratch = c->d_scratch;
-    mp.tile_list = d_tile_list;
-    if (mp.total_tiles > 0) {
-      if (MatchFilter()) hipLaunchKernelGGL((k_match2<false, true>), dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
-      else hipLaunchKernelGGL((k_match2<false, false>), dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
-      KCHK(c, "k_match2");
-      HIPCHK(hipGetLastError());
-    }
+    if (launch_match(parent->d_pool, parent->pool_cap, static_cast<u32>(tile_list.size()), d_tile_list, false) != 0) return -1;
     u32 counters[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(counters, t->d_counters, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -741,29 +843,8 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     HIPCHK(PoolAlloc(c, &t->d_pool, cap));
     t->pool_cap = static_cast<u32>(cap);
     HIPCHK(hipMemsetAsync(t->d_counters, 0, 16 * sizeof(u32), c->stream));
-    MatchParams mp;
-    mp.in = c->d_in;
-    mp.blocks = t->d_blocks;
-    mp.tile_off = t->d_tile_off;
-    mp.nb = static_cast<u32>(nb);
-    mp.total_tiles = tile_off[nb];
-    mp.links = t->d_links;
-    mp.recs = t->d_recs;
-    mp.pool = t->d_pool;
-    mp.pool_cap = t->pool_cap;
-    mp.counters = t->d_counters;
-    mp.scratch = c->d_scratch;
-    mp.tile_list = nullptr;
-    if (mp.total_tiles > 0) {
-      static const bool match_prof = std::getenv("ZOPFLI_AMD_PROF") != nullptr;
-      const bool filt = MatchFilter();
-      if (match_prof && filt) hipLaunchKernelGGL((k_match2<true, true>), dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
-      else if (match_prof) hipLaunchKernelGGL((k_match2<true, false>), dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
-      else if (filt) hipLaunchKernelGGL((k_match2<false, true>), dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
-      else hipLaunchKernelGGL((k_match2<false, false>), dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
-      KCHK(c, "k_match2");
-      HIPCHK(hipGetLastError());
-    }
+    static const bool match_prof = std::getenv("ZOPFLI_AMD_PROF") != nullptr;
+    if (launch_match(t->d_pool, t->pool_cap, tile_off[nb], nullptr, match_prof) != 0) return -1;
     u32 counters[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(counters, t->d_counters, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -787,8 +868,8 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
       unsigned long long hc[2] = {0, 0};
       HIPCHK(hipMemcpy(hc, t->d_counters + 4, sizeof(hc), hipMemcpyDeviceToHost));
       const double pos = static_cast<double>(pos_off);
-      std::fprintf(stderr, "k_match2: %.2f ms for %.0f positions: %.1f chain hits per "
-                   "position, %.1f of 64 lanes with a hit per wave-loop iteration; %.1f SIMD cycles per hit (2.4 GHz, 1024 SIMDs)\n", ms_match, pos,
+      std::fprintf(stderr, "%s: %.2f ms for %.0f positions: %.1f chain hits per "
+                   "position, %.1f of 64 lanes with a hit per wave-loop iteration; %.1f SIMD cycles per hit (2.4 GHz, 1024 SIMDs)\n", MatchKernel() == 4 ? "k_match4" : MatchKernel() == 3 ? "k_match3" : "k_match2", ms_match, pos,
                    static_cast<double>(hc[0]) / pos, static_cast<double>(hc[0]) / static_cast<double>(hc[1] ? hc[1] : 1),
                    ms_match * 1e-3 * 2.4e9 * 1024 / static_cast<double>(hc[0] ? hc[0] : 1));
     }
@@ -898,45 +979,112 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     // (the search costs 1.1 ms per 100 MB at 1024, the configuration the whole GPU suite ran with; 512 would halve
     //  it and finds the same cut point for 99.8 % of the tasks of text)
     static const u32 cut_depth = EnvU32("ZOPFLI_AMD_SEG_CUTS", 1024, 0, 1u << 16);
+    // ZOPFLI_AMD_SEG_MERGE=0: never merge tasks (every task that finds no cut point warms up, as in round 2)
+    static const bool merge_on = EnvU32("ZOPFLI_AMD_SEG_MERGE", 1, 0, 1) != 0;
     if (cut_depth && nt) {
       PoolScope tmp(c);
       u32* d_found = nullptr;
+      u32* d_wide = nullptr;
       HIPCHK(tmp.AllocT(&d_found, 2, "d_found"));
+      HIPCHK(tmp.AllocT(&d_wide, nt, "d_wide"));
       HIPCHK(hipMemsetAsync(d_found, 0, 2 * sizeof(u32), c->stream));
+      HIPCHK(hipMemsetAsync(d_wide, 0, nt * sizeof(u32), c->stream));
       CutParams cp;
       cp.blocks = t->d_blocks;
       cp.dph = t->d_dph;
       cp.tasks = t->d_tasks;
       cp.depth = cut_depth;
+      cp.warm = warm;
       cp.found = d_found;
+      cp.wide = d_wide;
       hipLaunchKernelGGL(k_cutpoints, dim3(static_cast<unsigned>(nt)), dim3(64), 0, c->stream, cp);
       KCHK(c, "k_cutpoints");
-      HIPCHK(hipGetLastError());
       static const bool prof = std::getenv("ZOPFLI_AMD_PROF") != nullptr;
+      u32 found[2] = {0, 0};
+      std::vector<u32> wide(nt);
+      HIPCHK(hipMemcpyAsync(found, d_found, sizeof(found), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipMemcpyAsync(wide.data(), d_wide, nt * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipMemcpyAsync(t->tasks.data(), t->d_tasks, nt * sizeof(SegTask), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      // merge the tasks that must not speculate (k_cutpoints) into their predecessors: the predecessor walks on to
+      // the merged task's end.  (The head of a block is never merged: pout = 0.)
+      size_t merged = 0;
+      if (merge_on) {
+        std::vector<SegTask> kept;
+        kept.reserve(nt);
+        std::vector<u32> off(nb + 1, 0);
+        for (size_t b = 0; b < nb; ++b) {
+          for (u32 k = t->task_off[b]; k < t->task_off[b + 1]; ++k) {
+            if (k > t->task_off[b] && wide[k]) {
+              kept.back().pend = t->tasks[k].pend;
+              ++merged;
+            } else {
+              kept.push_back(t->tasks[k]);
+            }
+          }
+          off[b + 1] = static_cast<u32>(kept.size());
+        }
+        t->merged_tasks = merged;
+        if (merged) {
+          t->tasks.swap(kept);
+          t->task_off.swap(off);
+          HIPCHK(hipMemcpyAsync(t->d_tasks, t->tasks.data(), t->tasks.size() * sizeof(SegTask), hipMemcpyHostToDevice, c->stream));
+          HIPCHK(hipMemcpyAsync(t->d_task_off, t->task_off.data(), (nb + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+          HIPCHK(hipStreamSynchronize(c->stream));
+        }
+      }
       if (prof) {
-        u32 found[2] = {0, 0};
-        HIPCHK(hipMemcpyAsync(found, d_found, sizeof(found), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        std::fprintf(stderr, "k_cutpoints: %u of %zu tasks start at a cut point, %.1f positions before their first owned one on average\n",
-                     found[0], nt, found[0] ? static_cast<double>(found[1]) / found[0] : 0.0);
+        std::fprintf(stderr, "k_cutpoints: %u of %zu tasks start at a cut point, %.1f positions before their first owned one on average; "
+                     "%zu tasks merged into their predecessors (long-run material in the warm-up stretch), %zu tasks left\n",
+                     found[0], nt, found[0] ? static_cast<double>(found[1]) / found[0] : 0.0, merged, t->tasks.size());
       }
     }
   }
   {
     // k_dp5_spec's workgroups: four tasks of one block each (they share the block's weight table in
-    // LDS); the workgroups that hold a head (several times the length of the other tasks) go first
-    std::vector<u32> wg;
+    // LDS); the workgroups that hold a head (several times the length of the other tasks) go first.  Tasks that
+    // walk runs of equal bytes (k_taskkind) get workgroups of their own, listed after the others: they are run by the
+    // kernel's other variant, beside the rest.
+    const size_t ntk = t->tasks.size();
+    std::vector<u32> kind(ntk, 0);
+    if (ntk) {
+      PoolScope tmp(c);
+      u32* d_kind = nullptr;
+      HIPCHK(tmp.AllocT(&d_kind, ntk, "d_kind"));
+      TaskKindParams kp;
+      kp.tasks = t->d_tasks;
+      kp.blocks = t->d_blocks;
+      kp.winflag = t->d_winflag;
+      kp.win_off = t->d_win_off;
+      kp.kind = d_kind;
+      hipLaunchKernelGGL(k_taskkind, dim3(static_cast<unsigned>(ntk)), dim3(64), 0, c->stream, kp);
+      KCHK(c, "k_taskkind");
+      HIPCHK(hipMemcpyAsync(kind.data(), d_kind, ntk * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    std::vector<u32> wg, wg_runs;
     for (int pass = 0; pass < 2; ++pass) {
       for (size_t b = 0; b < nb; ++b) {
         const u32 a0 = t->task_off[b], a1 = t->task_off[b + 1];
-        for (u32 k = pass == 0 ? a0 : a0 + D5_WG; k < (pass == 0 ? std::min(a0 + D5_WG, a1) : a1); k += D5_WG) {
-          for (u32 w = 0; w < D5_WG; ++w) wg.push_back(k + w < a1 ? k + w : SEG_NONE);
+        // pass 0: the group that holds the block's head; pass 1: the others.  Inside a block the tasks of either kind
+        // are grouped four at a time in order.
+        std::vector<u32> grp[2];
+        for (u32 k = a0; k < a1; ++k) grp[kind[k] ? 1 : 0].push_back(k);
+        for (int kd = 0; kd < 2; ++kd) {
+          std::vector<u32>& dst = kd ? wg_runs : wg;
+          for (size_t i = 0; i < grp[kd].size(); i += D5_WG) {
+            const bool has_head = i == 0 && !grp[kd].empty() && grp[kd][0] == a0;
+            if ((pass == 0) != has_head) continue;
+            for (u32 w = 0; w < D5_WG; ++w) dst.push_back(i + w < grp[kd].size() ? grp[kd][i + w] : SEG_NONE);
+          }
         }
       }
     }
     t->n_wg = static_cast<u32>(wg.size() / D5_WG);
-    HIPCHK(PoolAlloc(c, &t->d_wg_tasks, wg.size()));
-    HIPCHK(hipMemcpyAsync(t->d_wg_tasks, wg.data(), wg.size() * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+    t->n_wg_runs = static_cast<u32>(wg_runs.size() / D5_WG);
+    wg.insert(wg.end(), wg_runs.begin(), wg_runs.end());
+    HIPCHK(PoolAlloc(c, &t->d_wg_tasks, wg.size() + 4));
+    if (!wg.empty()) HIPCHK(hipMemcpyAsync(t->d_wg_tasks, wg.data(), wg.size() * sizeof(u32), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));   // `wg` is a local
   }
   // trace segments (zmx_trace.h)
@@ -1146,8 +1294,8 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   cp.wg_tasks = t->d_wg_tasks;
   static const int seg_debug = [] { const char* e = std::getenv("ZOPFLI_AMD_SEG_DEBUG"); return e ? std::atoi(e) : 0; }();
   cp.debug = seg_debug;
-  // (ZOPFLI_AMD_FIX_LEAN: 0 = every serial re-run by the lean one-wave job, large = none; zmx_dp5.h)
-  static const int fix_lean = [] { const char* e = std::getenv("ZOPFLI_AMD_FIX_LEAN"); return e ? std::atoi(e) : 1000000; }();
+  // (ZOPFLI_AMD_FIX_LEAN: 0 = every serial re-run by the lean one-wave job, large = none, unset = by the task's windows; zmx_dp5.h)
+  static const int fix_lean = [] { const char* e = std::getenv("ZOPFLI_AMD_FIX_LEAN"); return e ? std::atoi(e) : -1; }();
   cp.fix_lean_min = fix_lean;
   static const int int_path = [] { const char* e = std::getenv("ZOPFLI_AMD_INT_PATH"); return e ? std::atoi(e) : 1; }();
   cp.int_path = int_path;
@@ -1193,9 +1341,25 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     // the chain: every task speculatively on all CUs (four tasks of a block per workgroup, the workgroups
     // with a head first), then the per-block walk that accepts or re-runs
     {
-      const dim3 g(t->n_wg), bdim(64 * D5_WG);
-      if (cp.prof) hipLaunchKernelGGL((k_dp5_spec<true, 4>), g, bdim, 0, c->stream, cp);
-      else hipLaunchKernelGGL((k_dp5_spec<false, 4>), g, bdim, 0, c->stream, cp);
+      const dim3 bdim(64 * D5_WG);
+      // the run tasks on a second stream, beside the others: few and long (one wave may walk 100 000 positions)
+      if (t->n_wg_runs) {
+        HIPCHK(hipEventRecord(c->ev2[0], c->stream));
+        HIPCHK(hipStreamWaitEvent(c->stream2, c->ev2[0], 0));
+        Dp4Params cr = cp;
+        cr.task0 = t->n_wg;
+        if (cp.prof) hipLaunchKernelGGL((k_dp5_spec<true, 2, true>), dim3(t->n_wg_runs), bdim, 0, c->stream2, cr);
+        else hipLaunchKernelGGL((k_dp5_spec<false, 2, true>), dim3(t->n_wg_runs), bdim, 0, c->stream2, cr);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c->ev2[1], c->stream2));
+      }
+      if (t->n_wg) {
+        if (cp.prof) hipLaunchKernelGGL((k_dp5_spec<true, 4, false>), dim3(t->n_wg), bdim, 0, c->stream, cp);
+        else hipLaunchKernelGGL((k_dp5_spec<false, 4, false>), dim3(t->n_wg), bdim, 0, c->stream, cp);
+        HIPCHK(hipGetLastError());
+      }
+      if (t->n_wg_runs) HIPCHK(hipStreamWaitEvent(c->stream, c->ev2[1], 0));
+      if (GuardOn()) HIPCHK(hipStreamSynchronize(c->stream2));
       KCHK(c, "k_dp5_spec");
     }
     if (ntask > nblk) {
@@ -1203,8 +1367,10 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
       KCHK(c, "k_dpcheck");
       // a second speculative run, from the level the chain of shifts implies, for the tasks that only
       // missed their level (ZOPFLI_AMD_SEG_REDO=0: leave them to the serial pass)
-      static const bool redo = [] { const char* e = std::getenv("ZOPFLI_AMD_SEG_REDO"); return !e || std::atoi(e) != 0; }();
-      if (redo) {
+      // (ZOPFLI_AMD_SEG_REDO = how many such passes, default 1.  More settle more tasks before the serial pass — class Z:
+      //  87 / 92 / 93 % accepted with 1 / 2 / 3 — but every pass waits for its longest task: 1 264 / 1 362 / 1 601 ms)
+      static const int redo = [] { const char* e = std::getenv("ZOPFLI_AMD_SEG_REDO"); return e ? std::atoi(e) : 1; }();
+      for (int pass = 0; pass < redo; ++pass) {
         HIPCHK(hipMemsetAsync(t->d_redo, 0, sizeof(u32), c->stream));
         hipLaunchKernelGGL(k_dpscan, dim3(nblk), dim3(64), 0, c->stream, cp);
         KCHK(c, "k_dpscan");
@@ -1213,8 +1379,14 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
         c2.est_bits = nullptr;
         // (one workgroup per listed task; the workgroups beyond the list have nothing to do)
         const unsigned cap = ntask;
-        if (cp.prof) hipLaunchKernelGGL((k_dp5_spec<true, 4>), dim3(cap), dim3(64 * D5_WG), 0, c->stream, c2);
-        else hipLaunchKernelGGL((k_dp5_spec<false, 4>), dim3(cap), dim3(64 * D5_WG), 0, c->stream, c2);
+        // (the variant for run tasks wherever the set has any: what is run again there is mostly theirs)
+        if (t->n_wg_runs) {
+          if (cp.prof) hipLaunchKernelGGL((k_dp5_spec<true, 2, true>), dim3(cap), dim3(64 * D5_WG), 0, c->stream, c2);
+          else hipLaunchKernelGGL((k_dp5_spec<false, 2, true>), dim3(cap), dim3(64 * D5_WG), 0, c->stream, c2);
+        } else {
+          if (cp.prof) hipLaunchKernelGGL((k_dp5_spec<true, 4, false>), dim3(cap), dim3(64 * D5_WG), 0, c->stream, c2);
+          else hipLaunchKernelGGL((k_dp5_spec<false, 4, false>), dim3(cap), dim3(64 * D5_WG), 0, c->stream, c2);
+        }
         KCHK(c, "k_dp5_spec");
         hipLaunchKernelGGL(k_dpcheck, dim3(ntask), dim3(64), 0, c->stream, cp);
         KCHK(c, "k_dpcheck");
@@ -1292,6 +1464,8 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     std::fprintf(stderr, "  k_dp5_spec windows: integer %.1f%% of positions at %.0f cycles each, class 1 in doubles %.1f%% at %.0f, class 2 %.1f%% at %.0f, generic %.1f%% at %.0f\n",
                  100.0 * a[28] / (a[4] + 1e-9), a[24] / (a[28] + 1e-9), 100.0 * a[29] / (a[4] + 1e-9), a[25] / (a[29] + 1e-9),
                  100.0 * a[30] / (a[4] + 1e-9), a[26] / (a[30] + 1e-9), 100.0 * a[31] / (a[4] + 1e-9), a[27] / (a[31] + 1e-9));
+    std::fprintf(stderr, "  k_dp5_spec generic windows, cycles each: shortcut %.0f (%.0f of them), run row integer %.0f (%.0f), run row doubles %.0f (%.0f), other row %.0f (%.0f), window header %.0f (%.0f)\n",
+                 a[32] / (a[33] + 1e-9), a[33], a[34] / (a[35] + 1e-9), a[35], a[36] / (a[37] + 1e-9), a[37], a[38] / (a[39] + 1e-9), a[39], a[40] / (a[41] + 1e-9), a[41]);
     const char* nm[5] = {"32", "16", "8", "8 (two registers)", "generic"};
     for (int i = 0; i < 5; ++i)
       std::fprintf(stderr, "  path %-18s %5.1f%% of positions, %6.1f cycles/position\n", nm[i], 100.0 * a[6 + 2 * i] / a[4],
@@ -1571,6 +1745,48 @@ int zmx_hash_links_download(zmx_ctx* c, zmx_tables* t, size_t block, uint16_t* s
   if (t->links_partial) return FailMsg("zmx_hash_links_download: tables built from a parent hold the hash arrays only near the block ends");
   const BlockDesc& d = t->blocks[block];
   const size_t n = static_cast<size_t>(d.inend - d.ws);
+  if (t->buckets) {
+    // k_bucket's arrays, read back as the reference's links: the previous position of the same hash value is the
+    // entry below in the chunk's order, or the last of that value's bucket in the previous chunk — if it is
+    // less than 32768 back (hash.c:110-114).  Every array of the structure is read here: sorted, rank, bucket.
+    if (n) HIPCHK(hipMemcpy(same, t->d_same16 + d.reg_off, n * sizeof(u16), hipMemcpyDeviceToHost));
+    const size_t nch = (n + BK_CH - 1) / BK_CH;
+    std::vector<u16> srt(n), rnk(n);
+    std::vector<u32> bkt(nch * 32768u);
+    for (int h = 0; h < 2; ++h) {
+      uint16_t* prev = h == 0 ? prev1 : prev2;
+      if (n) {
+        HIPCHK(hipMemcpy(srt.data(), t->d_sorted[h] + d.reg_off, n * sizeof(u16), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(rnk.data(), t->d_rank[h] + d.reg_off, n * sizeof(u16), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(bkt.data(), t->d_bucket[h] + static_cast<size_t>(t->chunk_base[block]) * 32768u, bkt.size() * sizeof(u32),
+                         hipMemcpyDeviceToHost));
+      }
+      for (size_t k = 0; k < n; ++k) {
+        const size_t cch = k / BK_CH, off = k % BK_CH;
+        const unsigned char* in = c->h_in + d.ws;
+        const u32 b0 = in[k], b1 = k + 1 < n ? in[k + 1] : 0u, b2 = k + 2 < n ? in[k + 2] : 0u;
+        u32 key = ((b0 << 10) ^ (b1 << 5) ^ b2) & 32767u;
+        if (h) key ^= (static_cast<u32>(same[k]) - 3u) & 255u;
+        const u32 e = bkt[cch * 32768u + key];
+        const u32 r = rnk[k];
+        if (srt[cch * BK_CH + r] != off || r < (e & 0xffffu) || r >= (e >> 16)) {
+          return FailMsg("zmx_hash_links_download: sorted / rank / bucket disagree at region position " + std::to_string(k));
+        }
+        u32 dist = 0;
+        if (r > (e & 0xffffu)) {
+          dist = static_cast<u32>(off) - srt[cch * BK_CH + r - 1];
+        } else if (cch > 0) {
+          const u32 ep = bkt[(cch - 1) * 32768u + key];
+          if ((ep >> 16) > (ep & 0xffffu)) {
+            const u32 offp = srt[(cch - 1) * BK_CH + (ep >> 16) - 1];
+            if (offp > off) dist = BK_CH + static_cast<u32>(off) - offp;
+          }
+        }
+        prev[k] = static_cast<uint16_t>(dist);
+      }
+    }
+    return 0;
+  }
   std::vector<ushort4> lk(n);
   if (n) HIPCHK(hipMemcpy(lk.data(), t->d_links + d.reg_off, n * sizeof(ushort4), hipMemcpyDeviceToHost));
   for (size_t i = 0; i < n; ++i) {

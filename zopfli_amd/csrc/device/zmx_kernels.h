@@ -275,6 +275,7 @@ __global__ __launch_bounds__(64) void k_chain(const u8* __restrict__ in, const B
 #define MT 2048u
 #define MWIN_BYTES (32768u + MT + 288u)     // + slack for 16-byte alignment and 4-byte compares
 #define SCRATCH_CPS 256u                      // per-lane overflow change points
+#define M_XCD_GROUP 16u                        // consecutive tiles that go to one XCD (k_match*)
 #define MATCH_BATCH 8u                        // lanes that wait for a record write / a new position before the wave serves them
 
 struct MatchParams {
@@ -381,7 +382,7 @@ __device__ __forceinline__ uint2 greedy_window(const u32* rbase, u32 wb, u32 lan
 struct RowScanParams {
   const BlockDesc* blocks;
   const u32* recs;
-  uint2* dph;          // per block position: {roff, kend | shortcut << 16}
+  uint2* dph;          // per block position: {roff, kend | shortcut << 16 | run row << 17 | literal << 18}
   u64* block_edges;    // per block: total row length
 };
 
@@ -400,12 +401,17 @@ __global__ __launch_bounds__(1024) void k_rowscan(RowScanParams P) {
     if (act) {
       const uint2 h = *reinterpret_cast<const uint2*>(rbase + (u64)jj * 8);
       const u32 leng = h.x & 0xffffu, same_i = h.y & 0xffffu;
+      // a "run row": one change point, at distance 1 — every match edge of the position is (k, distance 1), k = 3 .. kend
+      // (the inside of a run of equal bytes): the chain kernels take its weights from a 258-entry table instead of
+      // the row's codes (zmx_dp5.h).  And the literal, so that they need not look at the codes at all.
+      if (leng >= 3 && (h.x >> 16) == 1u && (h.y >> 24) == 1u) sflag |= 2u;
+      sflag |= ((h.y >> 16) & 255u) << 2;
       kend = leng < B - jj ? leng : B - jj;        // squeeze.c:286
       if (kend < 3) kend = 1;
       // long-run shortcut test (squeeze.c:251-258): i > instart + 259, i + 517 < inend
       if (same_i > 2 * ZMX_MAX_MATCH && jj > ZMX_MAX_MATCH + 1 && jj + 2 * ZMX_MAX_MATCH + 1 < B) {
         const u32 same_back = rbase[(u64)(jj - ZMX_MAX_MATCH) * 8 + 1] & 0xffffu;
-        sflag = same_back > ZMX_MAX_MATCH ? 1u : 0u;
+        sflag |= same_back > ZMX_MAX_MATCH ? 1u : 0u;
       }
     }
     const u32 incl = wave_scan_add(kend);
@@ -671,7 +677,7 @@ __global__ __launch_bounds__(256) void k_badscan(BadScanParams P) {
 }
 
 // ------------------------------------------- shared by the chain kernels (zmx_dp4.h)
-#define ZMX_PROF_N 32u                // u64 profiling counters per block (ZOPFLI_AMD_PROF)
+#define ZMX_PROF_N 48u                // u64 profiling counters per block (ZOPFLI_AMD_PROF)
 #define DP_RING 16384u                // weight codes in the LDS ring (32 KB)
 #define DP_PIECE 512u                 // codes per LDS-DMA instruction (64 lanes x 16 B)
 #define DP_XN 704u                    // long-run shortcut staging: 384 cells

@@ -42,18 +42,20 @@ __global__ __launch_bounds__(M2_THREADS, 8) void k_match2(MatchParams P) {
 
   const u32 tid = threadIdx.x;
   const u32 xcd = blockIdx.x & 7;
-  const u32 t_begin = (u32)(((u64)P.total_tiles * xcd) / 8);
-  const u32 t_end = (u32)(((u64)P.total_tiles * (xcd + 1)) / 8);
   u32* my_scratch = P.scratch + ((u64)blockIdx.x * M2_THREADS + tid) * SCRATCH_CPS;
 
   for (;;) {
     __syncthreads();  // previous tile fully consumed before the window is overwritten
     if (tid == 0) {
-      s_tile = t_begin + atomicAdd(&P.counters[8 + xcd], 1u);
+      // tiles are dealt to the XCDs in groups of M_XCD_GROUP consecutive tiles (one 32 KiB stretch: its window
+      // stays in one L2), round robin — not in contiguous eighths of the input: a stretch of expensive data (long
+      // chains) would be one XCD's alone while the others sit idle
+      const u32 k = atomicAdd(&P.counters[8 + xcd], 1u);
+      s_tile = ((k / M_XCD_GROUP) * 8u + xcd) * M_XCD_GROUP + (k % M_XCD_GROUP);
       s_next = 0;
     }
     __syncthreads();
-    if (s_tile >= t_end) break;
+    if (s_tile >= P.total_tiles) break;
     const u32 tile = P.tile_list ? P.tile_list[s_tile] : s_tile;
 
     // block of this tile: largest b with tile_off[b] <= tile

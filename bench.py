@@ -1,8 +1,18 @@
 """bench.py — zopfli hot path on MI355X.
 
-One step = one pass of the hot path over the workload: ZopfliCompress(gzip) semantics on an
-input that is already resident in HBM (H2D is outside the timed region), i.e. match tables,
-greedy seeds, numiterations squeeze runs, host cost model, block choice, encoding, merge.
+One step = one pass of the hot path over the workload, match tables, greedy seeds, numiterations squeeze
+runs, host cost model, block choice, encoding, merge.  Two ways in, both measured at N = 1:
+
+  value            the reference's entry point: ZopfliCompress(options, GZIP, host buffer, size, &out, &outsize) of
+                   libzopfli_amd.so — what a drop-in user calls (zopfli_lib.c:28-42, zopfli_bin.c:99-127; BASELINE.md
+                   section 3: "wall-clock around ZopfliCompress only").  Host buffer in, malloc'ed gzip stream out;
+                   the copy to HBM and the device context's reuse are inside the clock.
+  value_resident   the same work on an input that is already resident in HBM (zmx_set_input outside the clock,
+                   zmx_deflate_range + zmx_chunks_merge): the kernels' own rate, and the only form N > 1 has (every
+                   rank compresses its shard, the blobs are gathered to rank 0 over RCCL).
+
+`blocksplitting1` repeats the entry-point measurement with the reference's DEFAULT options (blocksplitting = 1,
+util.c:28-35: BASELINE configs[2]) so that the number a real caller of ZopfliInitOptions gets is in the line too.
 
 Workload at N=1 (BASELINE.json configs[1]): 100 000 000 bytes of the seeded text-like class T
 (enwik8 stand-in), numiterations=15, blocksplitting=0 (one deflate block per 1 MB
@@ -28,8 +38,20 @@ sys.path.insert(0, ROOT)
 
 MB = 1000000
 WINDOW = 32768
-PMC_PROFILE = "r02_bench100MB_pmc.json"
+PMC_PROFILE = "r03_bench100MB_pmc.json"
 SHADER_CLOCK_HZ = 2.4e9   # MI355X peak engine clock; s_memtime counts at this rate (measured)
+
+
+def device_source_hash():
+    """SHA-256 (16 hex digits) over the device sources: a committed PMC profile is quoted only for the build it was
+    taken on (tools/pmc_summary.py stores the same hash in the profile)."""
+    d = os.path.join(ROOT, "zopfli_amd", "csrc", "device")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(sample, options):
@@ -140,6 +162,10 @@ def main():
                     help="N>1: weak = --size bytes per GPU (default), strong = --size bytes in total "
                          "(BASELINE configs[2]: one 100 MB stream sharded by master block)")
     ap.add_argument("--device-index", type=int, default=None, help="HIP device of this rank (default LOCAL_RANK)")
+    ap.add_argument("--entry", default="both", choices=["both", "zopfli_compress", "resident"],
+                    help="N = 1: which way into the library is timed (default both: `value` = ZopfliCompress, "
+                         "`value_resident` = resident input); N > 1 always times the sharded resident path")
+    ap.add_argument("--no-blocksplitting1", action="store_true", help="skip the extra line with blocksplitting = 1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -282,27 +308,85 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    timing_acc.clear()
-    seg_acc.clear()
-    sync()
-    t0 = time.perf_counter()
-    out = None
-    for _ in range(args.steps):
-        out = step()
-    sync()
-    dt = time.perf_counter() - t0
+    libc = ctypes.CDLL(None)
+    libc.free.argtypes = [ctypes.c_void_p]
+
+    def entry_step(opts):
+        """ZopfliCompress on the host buffer, as a C caller does it; returns (output pointer, size) — caller frees."""
+        outp, outsize = ctypes.POINTER(ctypes.c_ubyte)(), ctypes.c_size_t(0)
+        lib.ZopfliCompress(ctypes.byref(opts), api.FORMAT_GZIP, shard, len(shard), ctypes.byref(outp), ctypes.byref(outsize))
+        for k, v in api.last_timing(lib).items():
+            timing_acc[k] = timing_acc.get(k, 0.0) + v
+        for k, v in api.last_seg_stats(lib).items():
+            seg_acc[k] = seg_acc.get(k, 0.0) + v
+        return outp, outsize.value
+
+    def run_entry(opts, steps, warmup):
+        """`steps` timed ZopfliCompress calls after `warmup` untimed ones; the last output as bytes."""
+        for _ in range(warmup):
+            o, n = entry_step(opts)
+            libc.free(o)
+        timing_acc.clear()
+        seg_acc.clear()
+        sync()
+        t0 = time.perf_counter()
+        last = None
+        for _ in range(steps):
+            if last is not None:
+                libc.free(last[0])
+            last = entry_step(opts)
+        sync()
+        dt_ = time.perf_counter() - t0
+        data = ctypes.string_at(last[0], last[1])   # outside the timed region
+        libc.free(last[0])
+        return dt_, data
+
+    def run_resident(steps, warmup):
+        for _ in range(warmup):
+            step()
+        timing_acc.clear()
+        seg_acc.clear()
+        sync()
+        t0 = time.perf_counter()
+        o = None
+        for _ in range(steps):
+            o = step()
+        sync()
+        return time.perf_counter() - t0, o
+
+    entry_dt = entry_out = None
+    resident_timing = resident_seg = None
+    if world == 1 and args.entry in ("both", "resident"):
+        dt, out = run_resident(args.steps, args.warmup)
+        resident_timing, resident_seg = dict(timing_acc), dict(seg_acc)
+    if world == 1 and args.entry in ("both", "zopfli_compress"):
+        entry_dt, entry_out = run_entry(options, args.steps, args.warmup)   # (timing_acc / seg_acc now hold the entry point's)
+        if args.entry == "zopfli_compress":
+            dt, out = entry_dt, None
+    if world > 1:
+        dt, out = run_resident(args.steps, args.warmup)
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
     if rank == 0:
-        out = out.tobytes()   # outside the timed region
         total = total_bytes
-        ms = dt / args.steps * 1e3
-        value = total / MB / (dt / args.steps)
+        resident_out = out.tobytes() if out is not None else None   # outside the timed region
+        value_resident = ms_resident = None
+        if world > 1 or args.entry != "zopfli_compress":
+            ms_resident = dt / args.steps * 1e3
+            value_resident = total / MB / (dt / args.steps)
+        if entry_dt is not None:
+            # the headline: through the reference's entry point
+            ms = entry_dt / args.steps * 1e3
+            value = total / MB / (entry_dt / args.steps)
+            if resident_out is not None and resident_out != entry_out:
+                raise SystemExit("bench.py: ZopfliCompress and the resident path produced different streams")
+            out = entry_out
+        else:
+            ms, value = ms_resident, value_resident
+            out = resident_out
         # ---- correctness of the measured output (outside the timed region)
         bitexact = None
         roundtrip = None
@@ -313,7 +397,7 @@ def main():
                 dd = zlib.decompressobj(31)
                 roundtrip = (len(dd.decompress(out)) + len(dd.flush())) == total
             sha = hashlib.sha256(out).hexdigest()
-            for name in ("vectors_big.json", "vectors_big2.json", "vectors.json"):
+            for name in ("vectors_big.json", "vectors_big2.json", "vectors_big3.json", "vectors.json"):
                 p = os.path.join(ROOT, "tests", "golden", name)
                 if os.path.exists(p):
                     for c in json.load(open(p)):
@@ -340,15 +424,23 @@ def main():
             # WRITE_SIZE, MI355X_MICROARCH.md): only reported when the committed profile was taken on the
             # same configuration
             traffic = None
+            traffic_note = "no PMC profile of this workload"
             pmc = os.path.join(ROOT, "profiles", PMC_PROFILE)
             if (os.path.exists(pmc) and size == 100 * MB and args.numiterations == 15 and args.cls == "T"
                     and args.blocksplitting == 0 and world == 1):
                 with open(pmc) as f:
-                    traffic = round(json.load(f).get("chain", {}).get("hbm_bytes", 0) / 1e9, 3) or None
+                    prof = json.load(f)
+                if prof.get("device_source_sha16") == device_source_hash():
+                    traffic = round(prof.get("chain", {}).get("hbm_bytes", 0) / 1e9, 3) or None
+                    traffic_note = "rocprofv3 PMC passes of THIS build (device sources sha16 %s), profiles/%s" % (
+                        prof.get("device_source_sha16"), PMC_PROFILE)
+                else:
+                    traffic_note = ("profiles/%s was taken on device sources sha16 %s, this build is %s: not quoted (re-run "
+                                    "tools/collect_profiles.sh)" % (PMC_PROFILE, prof.get("device_source_sha16"), device_source_hash()))
             roofline = {"bound": "hbm", "kernel": "the chain of one squeeze run: k_dp5_spec + k_dpcheck + k_dp4_fix",
                         "achieved": round(achieved, 3), "peak": 8000.0,
                         "unit": "GB/s", "frac": round(achieved / 8000.0, 6), "traffic": traffic,
-                        "traffic_unit": "GB per launch (rocprofv3 PMC, profiles/" + PMC_PROFILE + ")",
+                        "traffic_unit": "GB per launch", "traffic_source": traffic_note,
                         "algorithmic_gb_per_launch": round(per_launch_bytes / 1e9, 3),
                         "avg_launch_ms": round(ksec / launches * 1e3, 3), "launches_per_step": launches / args.steps,
                         "measured_copy_peak_gbs": copy_gbs}
@@ -366,7 +458,7 @@ def main():
         roofline_match = None
         if msec > 0 and mpos > 0:
             ach = 29.0 * mpos / msec / 1e9
-            roofline_match = {"bound": "hbm", "kernel": "k_match2", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
+            roofline_match = {"bound": "hbm", "kernel": "k_match2 (prev links; ZOPFLI_AMD_MATCH selects k_match3 / k_match4)", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
                               "frac": round(ach / 8000.0, 6), "seconds_per_step": round(msec / args.steps, 5),
                               "positions_per_step": mpos / args.steps,
                               "ns_per_position": round(msec / mpos * 1e9, 4),
@@ -375,6 +467,11 @@ def main():
             "metric": "input MB/s at numiterations=15 (gzip, bit-exact vs reference)",
             "value": round(value, 4), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "entry": ("ZopfliCompress(options, ZOPFLI_FORMAT_GZIP, host buffer, size, &out, &outsize) of libzopfli_amd.so: host "
+                      "to device copy and context reuse inside the clock" if entry_dt is not None else
+                      "resident input: zmx_deflate_range + zmx_chunks_merge (H2D outside the clock)"),
+            "value_resident": None if value_resident is None else round(value_resident, 4),
+            "ms_per_step_resident": None if ms_resident is None else round(ms_resident, 2),
             "vs_baseline": None,
             "dtype": "u8 (f32/f64 cost DP)", "data": "synthetic",
             "config": {"workload": f"class-{args.cls} synthetic {size} B {'in total' if strong else 'per GPU'} "
@@ -403,6 +500,28 @@ def main():
                 "formula": "T(N) = c + (T1 - c)/N, c = runs x (chain time / rounds of task waves) + merge + gather",
                 "wave_rounds_per_run": round(rounds, 2), "c_ms": round(c * 1e3, 2),
                 "predicted_speedup": {str(n): round(t1 / (c + (t1 - c) / n), 2) for n in (2, 4, 8)}}
+        if world == 1 and args.blocksplitting == 0 and not args.no_blocksplitting1 and entry_dt is not None:
+            # the reference's default options (util.c:28-35): block splitting on — BASELINE configs[2] on one GPU
+            opt1 = ZopfliOptions(args.numiterations, 1, 15)
+            dt1, out1 = run_entry(opt1, max(1, min(args.steps, 2)), 1)
+            n1 = max(1, min(args.steps, 2))
+            bit1 = None
+            sha1 = hashlib.sha256(out1).hexdigest()
+            for name in ("vectors_big.json", "vectors_big2.json", "vectors_big3.json", "vectors.json"):
+                pth = os.path.join(ROOT, "tests", "golden", name)
+                if os.path.exists(pth):
+                    for c in json.load(open(pth)):
+                        if (c["input"].get("cls") == args.cls and c["input"].get("seed") in (None, seed0)
+                                and c["insize"] == size and c["format"] == 0 and c["numiterations"] == args.numiterations
+                                and c["blocksplitting"] == 1 and c["blocksplittingmax"] == 15):
+                            bit1 = (sha1 == c["sha256"])
+            line["blocksplitting1"] = {
+                "value": round(total / MB / (dt1 / n1), 4), "unit": "MB/s", "ms_per_step": round(dt1 / n1 * 1e3, 2), "steps": n1,
+                "output_bytes": len(out1), "roundtrip_ok": gzip.decompress(out1) == shard, "bitexact_vs_reference": bit1,
+                "breakdown_s_per_step": {k: round(v / n1, 4) for k, v in timing_acc.items()
+                                         if k in ("tables", "greedy", "squeeze", "cost_model", "split", "encode", "dp_kernel", "match_kernel")},
+                "config": "the same input through ZopfliCompress with the reference's default options: blocksplitting=1, "
+                          "blocksplittingmax=15 (configs[2] on one GPU)"}
         if world == 1 and not args.no_cpu_baseline:
             sample = shard[:min(args.cpu_sample, size)]
             res = cpu_baseline(sample, options)

@@ -47,6 +47,7 @@ int zmx_device_count(void) {
   return e ? std::atoi(e) : 1;
 }
 const char* zmx_last_error(void) { return g_err.c_str(); }
+void zmx_internal_set_error(const char* msg) { g_err = msg; }
 
 int zmx_ctx_create(int, zmx_ctx** ctx) {
   *ctx = new zmx_ctx();

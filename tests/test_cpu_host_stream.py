@@ -297,3 +297,26 @@ def test_checksum_pieces_and_combine(host):
         left, right = data[:cut], data[cut:]
         assert host.zmx_checksum_combine(api.CRC32, zlib.crc32(left), zlib.crc32(right), len(right)) == zlib.crc32(data)
         assert host.zmx_checksum_combine(api.ADLER32, zlib.adler32(left), zlib.adler32(right), len(right)) == zlib.adler32(data)
+
+
+def test_concurrent_callers():
+    """The reference has no globals: concurrent calls on distinct buffers are allowed.  Here a request
+    takes one of a device's contexts (api.cc ContextPool: ZOPFLI_AMD_LANES of them per device, two by default) and
+    other callers overlap with it or wait: four threads, each with its own input, get what they get alone."""
+    import threading
+
+    import oracle_lib as ol
+    from zopfli_amd import ZopfliOptions, api, generate
+    lib = ol.hosttest_library()
+    inputs = [generate(cls, n, seed) for cls, n, seed in (("T", 150000, 3), ("X", 90000, 4), ("M", 200000, 5), ("R", 30000, 6))]
+    want = [api.compress(d, 0, ZopfliOptions(2), lib=lib) for d in inputs]
+    got = [None] * len(inputs)
+
+    def work(i):
+        got[i] = api.compress(inputs[i], 0, ZopfliOptions(2), lib=lib)
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(inputs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert got == want

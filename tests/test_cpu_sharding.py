@@ -83,3 +83,20 @@ def test_crc32_combine():
     a, b = os.urandom(1000), os.urandom(777)
     assert sharding.crc32_combine(zlib.crc32(a), zlib.crc32(b), len(b)) == zlib.crc32(a + b)
     assert sharding.crc32_combine(zlib.crc32(a), 0, 0) == zlib.crc32(a)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_gather_logic_over_sockets(world):
+    """dist.cc's gather bookkeeping (zopfli_amd/csrc/host/dist_core.h: the size all-gather, the offsets, rank 0's
+    own blob staying put, an empty blob, the agreed failure when ONE rank cannot prepare its buffers) with `world`
+    ranks — forked processes around a socket hub instead of RCCL (tests/hostlib/gather_socket_test.cc).  On a GPU the
+    same function runs over ncclAllGather / ncclSend / ncclRecv."""
+    import ctypes
+
+    import oracle_lib as ol
+    lib = ol.hosttest_library()
+    lib.zamd_test_gather.argtypes = [ctypes.c_int, ctypes.c_int]
+    lib.zamd_test_gather.restype = ctypes.c_int
+    assert lib.zamd_test_gather(world, -1) == 0
+    for fail in range(world):
+        assert lib.zamd_test_gather(world, fail) == 0, f"rank {fail} failing its preparation"

@@ -395,7 +395,7 @@ def test_deflate_part_vs_reference(gpu_lib, btype):
 
 def _big_cases():
     out = []
-    for name in ("vectors_big.json", "vectors_big2.json"):
+    for name in ("vectors_big.json", "vectors_big2.json", "vectors_big3.json"):
         path = os.path.join(os.path.dirname(GOLDEN), name)
         if os.path.exists(path):
             with open(path) as f:
@@ -405,9 +405,10 @@ def _big_cases():
 
 @pytest.mark.parametrize("case", _big_cases(), ids=_gid)
 def test_full_size_round_trip(gpu_lib, case):
-    """The bench shapes at 20 MB (20 master blocks, numiterations 15) on text-like, markup-like and
-    mixed data, with and without block splitting (BASELINE configs 2 and 3): round trip through zlib
-    and the reference's SHA-256 (tests/golden/vectors_big*.json, written by make_golden.py --big / --big2)."""
+    """The bench shapes at 20 MB (20 master blocks, numiterations 15) on every class of data — text-like, markup-like,
+    mixed, long runs, two-symbol, PNG-like, random — with and without block splitting (BASELINE configs 2 and 3),
+    and the mixed corpus at numiterations 50 (configs[3]'s shape): round trip through zlib and the reference's
+    SHA-256 (tests/golden/vectors_big*.json, written by make_golden.py --big / --big2 / --big3)."""
     data = _input(case["input"])
     opt = ZopfliOptions(case["numiterations"], case["blocksplitting"], case["blocksplittingmax"])
     out = api.compress(data, case["format"], opt, lib=gpu_lib)

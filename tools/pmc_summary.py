@@ -42,6 +42,16 @@ def main(paths):
             v["write_bytes"] = v["WRITE_SIZE"] * 1024
         if "fetch_bytes" in v and "write_bytes" in v:
             v["hbm_bytes"] = v["fetch_bytes"] + v["write_bytes"]
+    # which build this was taken on (bench.py quotes `traffic` only for the same device sources)
+    import hashlib
+    import os
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zopfli_amd", "csrc", "device")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    out["device_source_sha16"] = h.hexdigest()[:16]
     json.dump(out, sys.stdout, indent=1, sort_keys=True)
 
 

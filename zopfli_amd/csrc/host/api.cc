@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -26,24 +28,17 @@ extern "C" void zmx_internal_match_stats(double* out4, int reset);
 extern "C" size_t zmx_internal_input_size(zmx_ctx* ctx);
 // implemented by the device layer: the caller's host copy of the resident input (borrowed)
 extern "C" const unsigned char* zmx_internal_input_host(zmx_ctx* ctx);
+extern "C" void zmx_internal_set_error(const char* msg);
 
 namespace {
 
 using zamd::kMasterBlock;
-
-std::mutex g_mutex;       // one request at a time on the shared contexts
-std::vector<zmx_ctx*> g_ctx;   // one per device the Zopfli* entry points use
 
 [[noreturn]] void Die(const char* what) {
   std::fprintf(stderr, "zopfli_amd: %s: %s\n", what, zmx_last_error());
   std::exit(EXIT_FAILURE);
 }
 
-// The devices the Zopfli* entry points run on.  ZOPFLI_AMD_DEVICES = "all", a count, or a comma
-// separated list of HIP device indices (an index may repeat: two contexts on one device, which is how
-// the multi-device path is exercised on a one-GPU box); else ZOPFLI_AMD_DEVICE or LOCAL_RANK (one
-// process per GPU under torchrun) name the single device; else every visible device: master blocks
-// are independent (deflate.c:916-923), so a request with several of them is dealt across the devices.
 // ZOPFLI_AMD_KEEP_HEAP=1: freed host memory stays with the process (glibc: no mmap for large blocks, no trimming).
 // With block splitting the symbols of every block pass through host vectors (hundreds of MB per 100 MB of input),
 // and every munmap of a process with a few hundred worker threads is a TLB shootdown on all their CPUs: on
@@ -62,40 +57,127 @@ void MaybeKeepHeap() {
   (void)once;
 }
 
-const std::vector<zmx_ctx*>& SharedContexts() {
-  MaybeKeepHeap();
-  if (!g_ctx.empty()) return g_ctx;
-  std::vector<int> devices;
-  const int visible = zmx_device_count();
-  if (const char* e = std::getenv("ZOPFLI_AMD_DEVICES")) {
-    if (std::strcmp(e, "all") == 0) {
-      for (int i = 0; i < visible; ++i) devices.push_back(i);
-    } else if (std::strchr(e, ',')) {
-      for (const char* p = e; *p;) {
-        devices.push_back(std::atoi(p));
-        const char* q = std::strchr(p, ',');
-        if (!q) break;
-        p = q + 1;
+// The device contexts of the Zopfli* entry points.
+//
+// Which devices: ONE by default — ZOPFLI_AMD_DEVICE, else LOCAL_RANK (one process per GPU under torchrun), else
+// device 0: a program that links libzopfli.so.1 must not find itself holding every GPU of the node.  Several only
+// when asked: ZOPFLI_AMD_DEVICES = "all", a count, or a comma separated list of HIP device indices (an index may
+// repeat: two contexts on one device, which is how the multi-device path is exercised on a one-GPU box); master
+// blocks are independent (deflate.c:916-923), so a request with several of them is dealt across those devices.
+//
+// Re-entrancy (the reference has no globals: callers may run concurrent calls on distinct buffers): a
+// device has up to ZOPFLI_AMD_LANES contexts (default 2), created when first needed; a request takes one free
+// context on each device it uses and gives them back when it is done, so two callers overlap — one's host phases
+// (cost models, block splitting, merging) with the other's kernels — and a third waits.  A device whose context
+// cannot be created (not gfx950, out of memory) is dropped from the list; only when none is left does the call die.
+class ContextPool {
+ public:
+  // one free context on each of up to `want` devices (at least one), in device order
+  std::vector<zmx_ctx*> Acquire(size_t want) {
+    std::unique_lock<std::mutex> lock(mu_);
+    Init();
+    for (;;) {
+      std::vector<zmx_ctx*> got;
+      std::vector<Slot*> slots;
+      for (auto& dev : devices_) {
+        if (got.size() == want) break;
+        if (dev.dead) continue;
+        Slot* s = nullptr;
+        for (auto& sl : dev.slots) if (!sl->busy) { s = sl.get(); break; }
+        if (!s && dev.slots.size() < lanes_) {
+          zmx_ctx* c = nullptr;
+          if (zmx_ctx_create(dev.index, &c) != 0) {
+            if (dev.slots.empty()) {
+              std::fprintf(stderr, "zopfli_amd: device %d is not usable: %s\n", dev.index, zmx_last_error());
+              dev.dead = true;
+            }
+            continue;
+          }
+          dev.slots.emplace_back(new Slot{c, false});
+          s = dev.slots.back().get();
+        }
+        if (s) { got.push_back(s->ctx); slots.push_back(s); }
       }
-    } else {
-      const int n = std::atoi(e);
-      for (int i = 0; i < n && i < visible; ++i) devices.push_back(i);
+      bool any_alive = false;
+      for (auto& dev : devices_) any_alive |= !dev.dead;
+      if (!any_alive) Die("no usable gfx950 device (there is no CPU fallback)");
+      if (!got.empty()) {
+        for (Slot* s : slots) s->busy = true;
+        return got;
+      }
+      cv_.wait(lock);   // every context of every device is busy
     }
-  } else if (const char* e = std::getenv("ZOPFLI_AMD_DEVICE")) {
-    devices.push_back(std::atoi(e));
-  } else if (const char* r = std::getenv("LOCAL_RANK")) {
-    devices.push_back(std::atoi(r));
-  } else {
-    for (int i = 0; i < visible; ++i) devices.push_back(i);
   }
-  if (devices.empty()) devices.push_back(0);
-  for (int d : devices) {
-    zmx_ctx* c = nullptr;
-    if (zmx_ctx_create(d, &c) != 0) Die("no usable gfx950 device (there is no CPU fallback)");
-    g_ctx.push_back(c);
+  void Release(const std::vector<zmx_ctx*>& ctxs) {
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      for (auto& dev : devices_)
+        for (auto& sl : dev.slots)
+          if (std::find(ctxs.begin(), ctxs.end(), sl->ctx) != ctxs.end()) sl->busy = false;
+    }
+    cv_.notify_all();
   }
-  return g_ctx;
+
+ private:
+  struct Slot { zmx_ctx* ctx; bool busy; };
+  struct Device { int index; bool dead = false; std::vector<std::unique_ptr<Slot>> slots; };
+  void Init() {
+    if (!devices_.empty()) return;
+    MaybeKeepHeap();
+    const int visible = zmx_device_count();
+    std::vector<int> list;
+    if (const char* e = std::getenv("ZOPFLI_AMD_DEVICES")) {
+      if (std::strcmp(e, "all") == 0) {
+        for (int i = 0; i < visible; ++i) list.push_back(i);
+      } else if (std::strchr(e, ',')) {
+        for (const char* p = e; *p;) {
+          list.push_back(std::atoi(p));
+          const char* q = std::strchr(p, ',');
+          if (!q) break;
+          p = q + 1;
+        }
+      } else {
+        const int n = std::atoi(e);
+        for (int i = 0; i < n && i < visible; ++i) list.push_back(i);
+      }
+    } else if (const char* e = std::getenv("ZOPFLI_AMD_DEVICE")) {
+      list.push_back(std::atoi(e));
+    } else if (const char* r = std::getenv("LOCAL_RANK")) {
+      list.push_back(std::atoi(r));
+    } else {
+      list.push_back(0);
+    }
+    for (int d : list) {
+      if (d < 0 || d >= visible) {
+        std::fprintf(stderr, "zopfli_amd: no HIP device %d (%d visible): ignored\n", d, visible);
+        continue;
+      }
+      Device dev;
+      dev.index = d;
+      devices_.push_back(std::move(dev));
+    }
+    if (devices_.empty()) {
+      zmx_internal_set_error("no HIP device to run on");
+      Die("no usable gfx950 device (there is no CPU fallback)");
+    }
+    if (const char* e = std::getenv("ZOPFLI_AMD_LANES")) lanes_ = static_cast<size_t>(std::max(1, std::atoi(e)));
+  }
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::vector<Device> devices_;
+  size_t lanes_ = 2;
+};
+
+ContextPool& Pool() {
+  static ContextPool* pool = new ContextPool();   // (never destroyed: HIP may be gone by the time statics are)
+  return *pool;
 }
+
+struct Lease {
+  std::vector<zmx_ctx*> ctxs;
+  explicit Lease(size_t want) : ctxs(Pool().Acquire(want)) {}
+  ~Lease() { Pool().Release(ctxs); }
+};
 
 size_t PartsPerBatch() {
   static const size_t n = [] {
@@ -157,7 +239,8 @@ struct ChecksumRequest {
 int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char* in,
                     const std::vector<zamd::Part>& parts, std::vector<zamd::Chunk>* chunks,
                     ChecksumRequest* sum = nullptr) {
-  const std::vector<zmx_ctx*>& ctxs = SharedContexts();
+  const Lease lease(parts.size());
+  const std::vector<zmx_ctx*>& ctxs = lease.ctxs;
   const size_t ndev = std::min(ctxs.size(), parts.size());
   struct Shard {
     size_t first = 0, last = 0, base = 0;
@@ -265,7 +348,6 @@ void ZopfliInitOptions(ZopfliOptions* options) {
 void ZopfliDeflatePart(const ZopfliOptions* options, int btype, int final, const unsigned char* in,
                        size_t instart, size_t inend, unsigned char* bp, unsigned char** out,
                        size_t* outsize) {
-  std::lock_guard<std::mutex> lock(g_mutex);
   ResetTiming();
   // only in[windowstart, inend) is read (lz77.c:551-552): that becomes the resident input
   std::vector<zamd::Part> parts{{instart, inend, final != 0}};
@@ -280,7 +362,6 @@ void DeflateWhole(const ZopfliOptions* options, int btype, int final, const unsi
                   unsigned char* bp, unsigned char** out, size_t* outsize, ChecksumRequest* sum) {
   const size_t offset = *outsize;
   {
-    std::lock_guard<std::mutex> lock(g_mutex);
     ResetTiming();
     const std::vector<zamd::Part> parts = MasterBlocks(insize, final != 0);
     std::vector<zamd::Chunk> chunks;

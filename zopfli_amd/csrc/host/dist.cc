@@ -18,6 +18,7 @@
 #include <string>
 #include <vector>
 
+#include "dist_core.h"
 #include "zopfli_amd.h"
 
 extern "C" int zmx_internal_device(zmx_ctx* ctx);
@@ -111,101 +112,125 @@ int zmx_dist_unique_id(unsigned char* id128) {
   return 0;
 }
 
+namespace {
+// the caller's current HIP device, put back whichever way a function is left
+struct DeviceScope {
+  int old = -1;
+  DeviceScope() { if (hipGetDevice(&old) != hipSuccess) old = -1; }
+  ~DeviceScope() { if (old >= 0) (void)hipSetDevice(old); }
+};
+}  // namespace
+
+void zmx_dist_destroy(zmx_dist* d);
+
 int zmx_dist_init(zmx_ctx* ctx, int rank, int world, const unsigned char* id128, zmx_dist** out) {
   Rccl* r = LoadRccl();
   if (!r->error.empty()) return Fail(r->error);
   if (world < 1 || rank < 0 || rank >= world) return Fail("zmx_dist_init: bad rank / world");
+  DeviceScope scope;
   zmx_dist* d = new zmx_dist();
   d->rccl = r;
   d->rank = rank;
   d->world = world;
   d->device = zmx_internal_device(ctx);
-  int old = -1;
-  (void)hipGetDevice(&old);
-  HIPCHK2(hipSetDevice(d->device));
+  // (every failure below frees what exists so far: zmx_dist_destroy copes with a half-built object)
+  const auto fail = [&](const std::string& m) { zmx_dist_destroy(d); return Fail(m); };
+  hipError_t e = hipSetDevice(d->device);
+  if (e != hipSuccess) return fail(std::string("hipSetDevice: ") + hipGetErrorString(e));
   ncclUniqueId id;
   std::memcpy(&id, id128, sizeof(id));
-  RCCLCHK(d, r->CommInitRank(&d->comm, world, id, rank));
-  HIPCHK2(hipStreamCreate(&d->stream));
-  HIPCHK2(hipMalloc(reinterpret_cast<void**>(&d->d_sizes), sizeof(uint64_t) * (1 + static_cast<size_t>(world))));
-  if (old >= 0) (void)hipSetDevice(old);
+  const ncclResult_t rc = r->CommInitRank(&d->comm, world, id, rank);
+  if (rc != ncclSuccess) { d->comm = nullptr; return fail(std::string("ncclCommInitRank: ") + r->GetErrorString(rc)); }
+  e = hipStreamCreate(&d->stream);
+  if (e != hipSuccess) { d->stream = nullptr; return fail(std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+  e = hipMalloc(reinterpret_cast<void**>(&d->d_sizes), sizeof(uint64_t) * (1 + static_cast<size_t>(world)));
+  if (e != hipSuccess) { d->d_sizes = nullptr; return fail(std::string("hipMalloc: ") + hipGetErrorString(e)); }
   *out = d;
   return 0;
 }
 
 void zmx_dist_destroy(zmx_dist* d) {
   if (!d) return;
-  int old = -1;
-  (void)hipGetDevice(&old);
+  DeviceScope scope;
   (void)hipSetDevice(d->device);
   if (d->comm) (void)d->rccl->CommDestroy(d->comm);
   (void)hipFree(d->d_send);
   (void)hipFree(d->d_recv);
   (void)hipFree(d->d_sizes);
   if (d->stream) (void)hipStreamDestroy(d->stream);
-  if (old >= 0) (void)hipSetDevice(old);
   delete d;
 }
 
-int zmx_dist_gather(zmx_dist* d, const unsigned char* blob, size_t size, unsigned char** gathered,
-                    size_t* sizes) {
-  int old = -1;
-  (void)hipGetDevice(&old);
-  HIPCHK2(hipSetDevice(d->device));
-  const size_t world = static_cast<size_t>(d->world);
-  // ---- sizes
-  const uint64_t mine = size;
+namespace {
+// ---- the RCCL transport of zamd::GatherBlobs (dist_core.h): device staging buffers, the wires are xGMI
+int RcclAllGather(void* self, uint64_t mine, uint64_t* all) {
+  zmx_dist* d = static_cast<zmx_dist*>(self);
   HIPCHK2(hipMemcpyAsync(d->d_sizes, &mine, sizeof(mine), hipMemcpyHostToDevice, d->stream));
   RCCLCHK(d, d->rccl->AllGather(d->d_sizes, d->d_sizes + 1, 1, ncclUint64, d->comm, d->stream));
-  std::vector<uint64_t> all(world);
-  HIPCHK2(hipMemcpyAsync(all.data(), d->d_sizes + 1, world * sizeof(uint64_t), hipMemcpyDeviceToHost, d->stream));
+  HIPCHK2(hipMemcpyAsync(all, d->d_sizes + 1, static_cast<size_t>(d->world) * sizeof(uint64_t), hipMemcpyDeviceToHost, d->stream));
   HIPCHK2(hipStreamSynchronize(d->stream));
-  // ---- payload
-  if (size > d->send_cap) {
+  return 0;
+}
+
+int RcclPrepare(void* self, size_t size, size_t total) {
+  zmx_dist* d = static_cast<zmx_dist*>(self);
+  if (d->rank != 0 && size > d->send_cap) {
     (void)hipFree(d->d_send);
     d->d_send = nullptr;
     d->send_cap = 0;
     HIPCHK2(hipMalloc(reinterpret_cast<void**>(&d->d_send), size + size / 4));
     d->send_cap = size + size / 4;
   }
-  if (size) HIPCHK2(hipMemcpyAsync(d->d_send, blob, size, hipMemcpyHostToDevice, d->stream));
-  size_t total = 0;
-  std::vector<size_t> off(world + 1, 0);
-  for (size_t r = 0; r < world; ++r) {
-    off[r] = total;
-    total += all[r];
-  }
-  off[world] = total;
-  if (d->rank == 0 && total > d->recv_cap) {
+  if (d->rank == 0 && total - size > d->recv_cap) {
     (void)hipFree(d->d_recv);
     d->d_recv = nullptr;
     d->recv_cap = 0;
-    HIPCHK2(hipMalloc(reinterpret_cast<void**>(&d->d_recv), total + total / 4));
-    d->recv_cap = total + total / 4;
+    const size_t cap = (total - size) + (total - size) / 4;
+    HIPCHK2(hipMalloc(reinterpret_cast<void**>(&d->d_recv), cap));
+    d->recv_cap = cap;
   }
+  return 0;
+}
+
+int RcclExchange(void* self, const unsigned char* blob, size_t size, const uint64_t* all, const size_t* off,
+                 unsigned char* host) {
+  zmx_dist* d = static_cast<zmx_dist*>(self);
+  const size_t world = static_cast<size_t>(d->world);
+  if (d->rank != 0 && size) HIPCHK2(hipMemcpyAsync(d->d_send, blob, size, hipMemcpyHostToDevice, d->stream));
+  const size_t base = world > 1 ? off[1] : 0;          // rank 0's own bytes are not staged
   RCCLCHK(d, d->rccl->GroupStart());
   if (d->rank != 0) {
     if (size) RCCLCHK(d, d->rccl->Send(d->d_send, size, ncclUint8, 0, d->comm, d->stream));
   } else {
     for (size_t r = 1; r < world; ++r) {
-      if (all[r]) RCCLCHK(d, d->rccl->Recv(d->d_recv + off[r], all[r], ncclUint8, static_cast<int>(r), d->comm, d->stream));
+      if (all[r]) RCCLCHK(d, d->rccl->Recv(d->d_recv + (off[r] - base), all[r], ncclUint8, static_cast<int>(r), d->comm, d->stream));
     }
   }
   RCCLCHK(d, d->rccl->GroupEnd());
-  if (d->rank == 0) {
-    unsigned char* host = static_cast<unsigned char*>(std::malloc(total ? total : 1));
-    if (!host) return Fail("zmx_dist_gather: out of memory");
-    if (size) std::memcpy(host, blob, size);   // rank 0's own blob does not travel
-    if (total > size) HIPCHK2(hipMemcpyAsync(host + off[1], d->d_recv + off[1], total - size, hipMemcpyDeviceToHost, d->stream));
-    HIPCHK2(hipStreamSynchronize(d->stream));
-    *gathered = host;
-    for (size_t r = 0; r < world; ++r) sizes[r] = all[r];
-  } else {
-    HIPCHK2(hipStreamSynchronize(d->stream));
-    *gathered = nullptr;
+  if (d->rank == 0 && world > 1 && off[world] > base) {
+    HIPCHK2(hipMemcpyAsync(host + base, d->d_recv, off[world] - base, hipMemcpyDeviceToHost, d->stream));
   }
-  if (old >= 0) (void)hipSetDevice(old);
+  HIPCHK2(hipStreamSynchronize(d->stream));
   return 0;
+}
+}  // namespace
+
+int zmx_dist_gather(zmx_dist* d, const unsigned char* blob, size_t size, unsigned char** gathered,
+                    size_t* sizes) {
+  DeviceScope scope;
+  HIPCHK2(hipSetDevice(d->device));
+  std::string err;
+  zamd::GatherTransport t;
+  t.self = d;
+  t.rank = d->rank;
+  t.world = d->world;
+  t.all_gather_u64 = RcclAllGather;
+  t.prepare = RcclPrepare;
+  t.exchange = RcclExchange;
+  t.error = &err;
+  const int rc = zamd::GatherBlobs(t, blob, size, gathered, sizes);
+  if (rc != 0 && !err.empty()) zmx_internal_set_error(err.c_str());
+  return rc;
 }
 
 }  // extern "C"

@@ -413,8 +413,12 @@ def main():
         # ---- roofline of the dominant kernels: the chain (GetBestLengths: k_dp5_spec + k_dpcheck + k_dp4_fix of
         #      one squeeze run; algorithmic bytes = 31 B per position per run: 28 B match record + 1 B literal +
         #      2 B length_array) and, beside it, the match-table kernel (29 B per position)
-        launches = timing_acc.get("squeeze_launches", 0.0)
-        ksec = timing_acc.get("dp_kernel", 0.0)
+        # (kernel durations and task statistics from the RESIDENT run where there is one: a single context, one stream — the
+        #  entry point deals a large request over two contexts of the device, whose kernels interleave)
+        k_timing = resident_timing if resident_timing is not None else timing_acc
+        k_seg = resident_seg if resident_seg is not None else seg_acc
+        launches = k_timing.get("squeeze_launches", 0.0)
+        ksec = k_timing.get("dp_kernel", 0.0)
         copy_gbs = measured_copy_gbs(torch, device) if world == 1 else None
         roofline = None
         if launches > 0 and ksec > 0:
@@ -444,17 +448,17 @@ def main():
                         "algorithmic_gb_per_launch": round(per_launch_bytes / 1e9, 3),
                         "avg_launch_ms": round(ksec / launches * 1e3, 3), "launches_per_step": launches / args.steps,
                         "measured_copy_peak_gbs": copy_gbs}
-            tasks = seg_acc.get("tasks", 0.0)
+            tasks = k_seg.get("tasks", 0.0)
             if tasks:
                 # how the chain's tasks fared: what was accepted as computed, what was run again serially and why
                 roofline["chain"] = {
                     "tasks_per_launch": round(tasks / launches, 1),
-                    "accepted_frac": round(seg_acc.get("accepted", 0.0) / tasks, 5),
-                    "rerun_state_frac": round((seg_acc.get("rerun_state", 0.0) + seg_acc.get("rerun_values", 0.0)) / tasks, 5),
-                    "rerun_level_frac": round(seg_acc.get("rerun_level", 0.0) / tasks, 5),
-                    "rerun_tie_frac": round(seg_acc.get("rerun_tie", 0.0) / tasks, 5),
-                    "positions_rerun_frac": round(seg_acc.get("positions_rerun", 0.0) / max(seg_acc.get("positions", 1.0), 1.0), 5)}
-        msec, mpos = timing_acc.get("match_kernel", 0.0), timing_acc.get("positions_matched", 0.0)
+                    "accepted_frac": round(k_seg.get("accepted", 0.0) / tasks, 5),
+                    "rerun_state_frac": round((k_seg.get("rerun_state", 0.0) + k_seg.get("rerun_values", 0.0)) / tasks, 5),
+                    "rerun_level_frac": round(k_seg.get("rerun_level", 0.0) / tasks, 5),
+                    "rerun_tie_frac": round(k_seg.get("rerun_tie", 0.0) / tasks, 5),
+                    "positions_rerun_frac": round(k_seg.get("positions_rerun", 0.0) / max(k_seg.get("positions", 1.0), 1.0), 5)}
+        msec, mpos = k_timing.get("match_kernel", 0.0), k_timing.get("positions_matched", 0.0)
         roofline_match = None
         if msec > 0 and mpos > 0:
             ach = 29.0 * mpos / msec / 1e9
@@ -462,7 +466,7 @@ def main():
                               "frac": round(ach / 8000.0, 6), "seconds_per_step": round(msec / args.steps, 5),
                               "positions_per_step": mpos / args.steps,
                               "ns_per_position": round(msec / mpos * 1e9, 4),
-                              "hash_kernels_seconds_per_step": round(timing_acc.get("hash_kernels", 0.0) / args.steps, 5)}
+                              "hash_kernels_seconds_per_step": round(k_timing.get("hash_kernels", 0.0) / args.steps, 5)}
         line = {
             "metric": "input MB/s at numiterations=15 (gzip, bit-exact vs reference)",
             "value": round(value, 4), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -488,13 +492,13 @@ def main():
             "breakdown_s_per_step": {k: round(v / args.steps, 4) for k, v in timing_acc.items()
                                      if k not in ("squeeze_launches", "table_builds", "positions_matched")},
         }
-        tasks_per_launch = seg_acc.get("tasks", 0.0) / launches if launches else 0.0
+        tasks_per_launch = k_seg.get("tasks", 0.0) / launches if launches else 0.0
         if world == 1 and tasks_per_launch and ksec > 0:
             # Predicted strong-scaling ceiling from the chain's latency: a squeeze run cannot take less than one
             # round of task waves (a task is a serial chain of ~4600 positions) however few blocks a GPU holds;
             # the merge on rank 0 and the gather do not shrink either.  T(N) = c + (T1 - c) / N.
             rounds = max(1.0, tasks_per_launch / (256 * 16))
-            c = (ksec / rounds + timing_acc.get("merge", 0.0) + timing_acc.get("gather", 0.0)) / args.steps
+            c = (ksec / rounds + k_timing.get("merge", 0.0) + k_timing.get("gather", 0.0)) / args.steps
             t1 = ms / 1e3
             line["strong_scaling_model"] = {
                 "formula": "T(N) = c + (T1 - c)/N, c = runs x (chain time / rounds of task waves) + merge + gather",

@@ -33,10 +33,15 @@ extern "C" {
  * fails, util.h:135-155) the Zopfli* functions below print a message to stderr and exit(EXIT_FAILURE)
  * when the device side fails: no usable gfx950 device, a HIP error such as an allocation that does
  * not fit in HBM, or a single deflate block whose DP edges do not fit 32-bit row offsets (more than
- * 2^32 - 1 match-length candidates in one block: beyond ~16 MB of highly repetitive data; the limit
- * applies to one block [instart, inend) of ZopfliDeflatePart with blocksplitting = 0 only — ZopfliDeflate
- * and ZopfliCompress cut their input into 1 000 000-byte master blocks first).  The zmx_* functions of
- * part 2 return non-zero instead and leave a message for zmx_last_error(). */
+ * 2^32 - 65536 match-length candidates in one block: some 150 - 300 MB of input in ONE block, which only
+ * ZopfliDeflatePart with blocksplitting = 0 can ask for — ZopfliDeflate and ZopfliCompress cut their
+ * input into 1 000 000-byte master blocks first).  The zmx_* functions of part 2 return non-zero instead
+ * and leave a message for zmx_last_error().
+ *
+ * Devices and threads.  The Zopfli* functions run on ONE device unless told otherwise: ZOPFLI_AMD_DEVICE,
+ * else LOCAL_RANK, else device 0; ZOPFLI_AMD_DEVICES = "all" | a count | a list of indices deals the master
+ * blocks of a call over several.  They may be called from several threads at once (as the reference's may):
+ * a device has ZOPFLI_AMD_LANES contexts (default 2), a call takes what it needs and later callers wait. */
 
 /* ------------------------------------------------------------------ Part 1 */
 
@@ -253,14 +258,14 @@ int zmx_dist_gather(zmx_dist* dist, const unsigned char* blob, size_t size, unsi
 
 /* Timing breakdown of the last Zopfli* / zmx_deflate_range call on this
  * thread: seconds spent in [0] match tables [1] greedy [2] squeeze runs
- * [3] host cost model [4] block split [5] encode [6] DP-chain kernel (k_dp3) time
- * (HIP events on the launch stream) [7] squeeze runs launched.  For bench.py's
- * roofline object. */
+ * [3] host cost model [4] block split [5] encode [6] the chain kernels of the squeeze runs (k_dp5_spec,
+ * k_dpcheck, k_dpscan, k_dp4_fix: GetBestLengths; HIP events on the launch stream) [7] squeeze runs launched.
+ * For bench.py's roofline object. */
 int zmx_last_timing(double* out8);
 
 /* Kernel-only seconds (HIP events) of the squeeze runs since the last Zopfli* /
- * zmx_deflate_range call started: [0] k_edges [1] k_dp3 [2] k_trace_* (exits + link + emit)
- * [3] squeeze runs launched. */
+ * zmx_deflate_range call started: [0] k_wtab + k_badscan (the run's weight tables) [1] the chain kernels
+ * [2] k_trace_* (exits + link + emit) [3] squeeze runs launched. */
 int zmx_last_kernel_timing(double* out4);
 
 /* Host tail of the last call on this thread, seconds: [0] best LZ77 stores device -> host
@@ -268,7 +273,8 @@ int zmx_last_kernel_timing(double* out4);
 int zmx_last_host_timing(double* out2);
 
 /* Match-table builds since the last Zopfli* / zmx_deflate_range call started (HIP events):
- * [0] seconds in k_match2 [1] seconds in k_same + k_chain [2] table builds [3] positions whose record
+ * [0] seconds in the match kernel (k_match2; ZOPFLI_AMD_MATCH = 3 / 4: k_match3 / k_match4) [1] seconds in k_same +
+ * k_chain (or k_bucket) [2] table builds [3] positions whose record
  * the match kernel computed (the others were copied from the parent tables). */
 int zmx_last_match_timing(double* out4);
 

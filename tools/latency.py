@@ -24,5 +24,5 @@ for cls, size, n in (("T", 65536, 1), ("T", 65536, 15), ("T", 1000000, 15), ("P"
     res.append({"cls": cls, "size": size, "numiterations": n, "ms_min": round(min(ts), 2), "ms_median": round(sorted(ts)[2], 2),
                 "out": len(out), "breakdown_ms": {k: round(v * 1e3, 2) for k, v in t.items()
                                                   if k in ("tables", "greedy", "squeeze", "cost_model", "split", "encode",
-                                                           "download", "dp_kernel", "edges_kernel", "trace_kernel")}})
+                                                           "download", "dp_kernel", "wtab_kernel", "trace_kernel")}})
     print(json.dumps(res[-1]), flush=True)

@@ -25,6 +25,7 @@ def _sources():
     cc = sorted(os.path.join(host, f) for f in os.listdir(host) if f.endswith(".cc"))
     hdr = [os.path.join(d, f) for d in (host, dev) for f in os.listdir(d) if f.endswith(".h")]
     hdr.append(os.path.join(ROOT, "include", "zopfli_amd.h"))
+    hdr.append(os.path.join(CSRC, "libzopfli_amd.map"))
     return os.path.join(dev, "zmx_hip.hip"), cc, hdr
 
 
@@ -36,6 +37,7 @@ def build_product(force=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
            "-fvisibility=hidden", "-Wl,-soname,libzopfli.so.1",
+           "-Wl,--version-script=" + os.path.join(CSRC, "libzopfli_amd.map"),
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(CSRC, "host"),
            "-I" + os.path.join(CSRC, "device"), hip] + cc + ["-o", LIB, "-lpthread", "-ldl"]
     subprocess.check_call(cmd)

@@ -163,7 +163,7 @@ def last_timing(lib=None):
     d = dict(zip(keys, list(t)))
     k = (ctypes.c_double * 4)()
     lib.zmx_last_kernel_timing(k)
-    d["edges_kernel"], d["trace_kernel"] = k[0], k[2]
+    d["wtab_kernel"], d["trace_kernel"] = k[0], k[2]
     h = (ctypes.c_double * 2)()
     lib.zmx_last_host_timing(h)
     d["download"], d["serialize"] = h[0], h[1]

@@ -4,24 +4,25 @@
 // Included only by zmx_hip.hip, after zmx_dp4.h (same jobs, snapshots, cell registers, arithmetic).
 //
 // k_dp4's four-wave pipeline is built for the latency of ONE chain (one workgroup per CU, 142 KB of
-// LDS): right for the stretches k_dp4_fix has to run serially, wasteful when 24 000 independent tasks
+// LDS): right for the stretches k_dp4_fix has to run serially, wasteful when 50 000 independent tasks
 // are waiting.  Here the unit is a WINDOW of 32 positions (the cell registers move 32 cells at a
-// time, as in k_dp4).  For a window whose positions all reach no further than cell register 0 and
-// carry no flag (99 % of text), the wave fetches the 32 edge rows itself, straight from rows[] in
-// HBM/L2 into registers, already in the lane layout the chain wants:
+// time, as in k_dp4), and a window is one of three kinds (k_mkdesc):
 //
-//     lane l of row u  =  wtab[codes[roff_u + l - u - 1]]   if 0 <= l - u - 1 < kend_u, else +inf
+//   class 1  every position's edges stay inside cell register 0, no shortcut flag, no edge below mincost
+//            (91 % of the positions of text).  The window's rows are consecutive in codes[]: they come as
+//            one piece by LDS-DMA into the wave's staging area, requested a window ahead together with the
+//            window's 40-word record (wmeta); lane l of row u then reads code l - u - 1 from LDS and its
+//            weight from the run's table in LDS.  Inside one binade the chain step is integer arithmetic on
+//            the floats' bit patterns (D5IntTab below).
+//   class 2  longer rows, no flags: two buffer_load_ushort per row (lanes 0..127 of the row), the range
+//            check of a per-row buffer descriptor dropping the lanes outside it; the few rows that reach
+//            further fetch the rest on demand.
+//   class 0  everything else, position by position with the reference's tests literally: long-run shortcut
+//            positions (squeeze.c:251-271), edges below mincost (:293), ragged tails — and runs of equal
+//            bytes, for which the RUNS variant of the job (below) has table-driven rows and staged codes.
 //
-// with everything per position on the scalar side: a ready-made buffer descriptor whose buffer IS
-// the row's 16-bit weight codes (base codes + roff, kend * 2 bytes; k_mkdesc) arrives by s_load
-// (uniform address); lane l asks for offset 2 (l - u - 1), which wraps below the row and overshoots
-// beyond it, so the hardware's range check drops those lanes before they reach the L1 (a plain
-// 64-lane load costs an L1 access per 32 bytes of lanes whatever they point at: measured, the first
-// version was L1-bound) and returns zero for them — the code of "no edge", weight +inf.  The weight
-// itself comes from the run's table (k_wtab) that the four waves of the workgroup, four tasks of one
-// block, share in LDS: one buffer_load_ushort, one ds_read_b64 and one VALU instruction per position,
-// then the 8-instruction chain step of k_dp4.  Other windows (long matches, shortcut flags, edges below mincost, ragged
-// tails) take the generic path, position by position, with the reference's tests literally.
+// (The first version fetched every row through a buffer descriptor per position: the CU's address unit is
+// busy 16 cycles per wave-wide load whatever the lanes do — DESIGN.md section 4 has the history.)
 #pragma once
 
 // A pointer every lane holds the same value of, as the compiler can see it (an SGPR pair).

@@ -231,10 +231,11 @@ __global__ __launch_bounds__(256) void k_verify(VerifyParams P) {
           if (P.in[pos + k] != P.in[pos + k - dist]) { why = 2; break; }
         }
       }
-      if (why) { atomicMax(&P.bad[2 * blockIdx.x], i + 1); P.bad[2 * blockIdx.x + 1] = why; }
+      // (symbol and reason in ONE word, so that the reason reported is the reported symbol's: (i + 1) << 2 | why)
+      if (why) atomicMax(&P.bad[2 * blockIdx.x], ((i + 1) << 2) | why);
     }
     base += tot;
     __syncthreads();
   }
-  if (threadIdx.x == 0 && base != J.inend) { atomicMax(&P.bad[2 * blockIdx.x], J.nsym + 1); P.bad[2 * blockIdx.x + 1] = 3; }
+  if (threadIdx.x == 0 && base != J.inend) atomicMax(&P.bad[2 * blockIdx.x], ((J.nsym + 1) << 2) | 3u);
 }

@@ -1574,7 +1574,7 @@ int zmx_verify_stores(zmx_ctx* c, zmx_tables* t, size_t n, const size_t* block, 
     if (bad[2 * i] == 0) continue;
     static const char* why[4] = {"", "length or distance out of range", "the bytes it stands for are not the input's", "the symbols do not add up to the block"};
     char msg[200];
-    std::snprintf(msg, sizeof(msg), "zmx_verify_stores: block %zu, symbol %u: %s", block[i], bad[2 * i] - 1, why[bad[2 * i + 1] & 3]);
+    std::snprintf(msg, sizeof(msg), "zmx_verify_stores: block %zu, symbol %u: %s", block[i], (bad[2 * i] >> 2) - 1, why[bad[2 * i] & 3]);
     g_err = msg;
     return -1;
   }

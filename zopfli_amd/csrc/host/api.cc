@@ -72,31 +72,43 @@ void MaybeKeepHeap() {
 // cannot be created (not gfx950, out of memory) is dropped from the list; only when none is left does the call die.
 class ContextPool {
  public:
-  // one free context on each of up to `want` devices (at least one), in device order
-  std::vector<zmx_ctx*> Acquire(size_t want) {
+  // one free context on each of up to `want` devices (at least one), in device order; with `per_device` > 1 up to
+  // that many free contexts of every device it uses (a large request on one device is dealt over two of its
+  // contexts: one half's host phases run beside the other half's kernels)
+  std::vector<zmx_ctx*> Acquire(size_t want, size_t per_device = 1) {
     std::unique_lock<std::mutex> lock(mu_);
     Init();
     for (;;) {
       std::vector<zmx_ctx*> got;
       std::vector<Slot*> slots;
+      size_t used_devices = 0;
       for (auto& dev : devices_) {
-        if (got.size() == want) break;
+        if (used_devices == want) break;
         if (dev.dead) continue;
-        Slot* s = nullptr;
-        for (auto& sl : dev.slots) if (!sl->busy) { s = sl.get(); break; }
-        if (!s && dev.slots.size() < lanes_) {
-          zmx_ctx* c = nullptr;
-          if (zmx_ctx_create(dev.index, &c) != 0) {
-            if (dev.slots.empty()) {
-              std::fprintf(stderr, "zopfli_amd: device %d is not usable: %s\n", dev.index, zmx_last_error());
-              dev.dead = true;
-            }
-            continue;
+        size_t here = 0;
+        for (size_t lane = 0; lane < per_device; ++lane) {
+          Slot* s = nullptr;
+          for (auto& sl : dev.slots) {
+            if (!sl->busy && std::find(slots.begin(), slots.end(), sl.get()) == slots.end()) { s = sl.get(); break; }
           }
-          dev.slots.emplace_back(new Slot{c, false});
-          s = dev.slots.back().get();
+          if (!s && dev.slots.size() < lanes_) {
+            zmx_ctx* c = nullptr;
+            if (zmx_ctx_create(dev.index, &c) != 0) {
+              if (dev.slots.empty()) {
+                std::fprintf(stderr, "zopfli_amd: device %d is not usable: %s\n", dev.index, zmx_last_error());
+                dev.dead = true;
+              }
+              break;
+            }
+            dev.slots.emplace_back(new Slot{c, false});
+            s = dev.slots.back().get();
+          }
+          if (!s) break;
+          got.push_back(s->ctx);
+          slots.push_back(s);
+          ++here;
         }
-        if (s) { got.push_back(s->ctx); slots.push_back(s); }
+        if (here) ++used_devices;
       }
       bool any_alive = false;
       for (auto& dev : devices_) any_alive |= !dev.dead;
@@ -139,6 +151,7 @@ class ContextPool {
       } else {
         const int n = std::atoi(e);
         for (int i = 0; i < n && i < visible; ++i) list.push_back(i);
+        if (list.empty()) list.push_back(0);   // ("0": no count — device 0)
       }
     } else if (const char* e = std::getenv("ZOPFLI_AMD_DEVICE")) {
       list.push_back(std::atoi(e));
@@ -175,7 +188,7 @@ ContextPool& Pool() {
 
 struct Lease {
   std::vector<zmx_ctx*> ctxs;
-  explicit Lease(size_t want) : ctxs(Pool().Acquire(want)) {}
+  explicit Lease(size_t want, size_t per_device = 1) : ctxs(Pool().Acquire(want, per_device)) {}
   ~Lease() { Pool().Release(ctxs); }
 };
 
@@ -239,7 +252,33 @@ struct ChecksumRequest {
 int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char* in,
                     const std::vector<zamd::Part>& parts, std::vector<zamd::Chunk>* chunks,
                     ChecksumRequest* sum = nullptr) {
-  const Lease lease(parts.size());
+  // (ZOPFLI_AMD_SPLIT_MB: from this many master blocks on, a request is dealt over two contexts of each device;
+  //  0 = never.  The GPU idles while the host computes a hundred cost models between two squeeze runs — 6 % of a
+  //  100 MB call — and through the whole block-split search; two halves fill each other's gaps.)
+  static const size_t split_from = [] {
+    const char* e = std::getenv("ZOPFLI_AMD_SPLIT_MB");
+    return e ? static_cast<size_t>(std::max(0, std::atoi(e))) : static_cast<size_t>(32);
+  }();
+  static const size_t split_ways = [] {
+    const char* e = std::getenv("ZOPFLI_AMD_SPLIT_WAYS");
+    return e ? static_cast<size_t>(std::max(1, std::atoi(e))) : static_cast<size_t>(2);
+  }();
+  // Not on data with long runs of equal bytes: there the squeeze runs wait for a few very long single-wave tasks
+  // (zmx_dp5.h), and a second context's tasks on the same SIMDs slow exactly those (class Z: 61 -> 35 MB/s).  Sampled:
+  // one probe every 4096 bytes, "the next 64 bytes are equal"; 1 % of the probes is enough to stay on one context.
+  bool runs = false;
+  if (split_from && parts.size() >= split_from && in != nullptr) {
+    const size_t lo = parts.front().instart, hi = parts.back().inend;
+    size_t probes = 0, hits = 0;
+    for (size_t i = lo; i + 64 <= hi; i += 4096, ++probes) {
+      const unsigned char c0 = in[i];
+      size_t k = 1;
+      while (k < 64 && in[i + k] == c0) ++k;
+      hits += k == 64;
+    }
+    runs = probes > 0 && hits * 100 >= probes;
+  }
+  const Lease lease(parts.size(), split_from && parts.size() >= split_from && !runs ? split_ways : 1);
   const std::vector<zmx_ctx*>& ctxs = lease.ctxs;
   const size_t ndev = std::min(ctxs.size(), parts.size());
   struct Shard {

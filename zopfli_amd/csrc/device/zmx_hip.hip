@@ -170,7 +170,7 @@ struct zmx_tables {
   std::vector<u32> seg_off;
   std::vector<u64> block_edges;
   std::vector<u32> tile_off;
-  u32* d_counters = nullptr;  // 16 words, see MatchParams
+  u32* d_counters = nullptr;  // 24 words, see MatchParams (16 .. 21: k_match3's profile counts)
   u32* d_flags = nullptr;     // 4 words
   // what a squeeze run takes and gives, each side ONE array on the device and one pinned mirror on the host, so
   // that a run has one copy down and one up (eight small copies a run were 3 ms of copy kernels per 15 runs):
@@ -689,7 +689,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   HIPCHK(PoolAlloc(c, &t->d_code_base, nb));
   HIPCHK(PoolAlloc(c, &t->d_wtab, nb * ZMX_WTAB));
   HIPCHK(PoolAlloc(c, &t->d_badcodes, nb * 40));
-  HIPCHK(PoolAlloc(c, &t->d_counters, 16));
+  HIPCHK(PoolAlloc(c, &t->d_counters, 24));
   HIPCHK(hipMemcpyAsync(t->d_blocks, t->blocks.data(), nb * sizeof(BlockDesc), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(t->d_tile_off, tile_off.data(), (nb + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemsetAsync(t->d_flags, 0, 4 * sizeof(u32), c->stream));
@@ -810,7 +810,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     KCHK(c, "k_copy_recs");
     HIPCHK(hipGetLastError());
     // the pool cursor continues where the parent's stopped
-    HIPCHK(hipMemsetAsync(t->d_counters, 0, 16 * sizeof(u32), c->stream));
+    HIPCHK(hipMemsetAsync(t->d_counters, 0, 24 * sizeof(u32), c->stream));
     HIPCHK(hipMemcpyAsync(t->d_counters, parent->d_counters, sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
     if (launch_match(parent->d_pool, parent->pool_cap, static_cast<u32>(tile_list.size()), d_tile_list, false) != 0) return -1;
     u32 counters[2] = {0, 0};
@@ -842,7 +842,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     t->d_pool = nullptr;
     HIPCHK(PoolAlloc(c, &t->d_pool, cap));
     t->pool_cap = static_cast<u32>(cap);
-    HIPCHK(hipMemsetAsync(t->d_counters, 0, 16 * sizeof(u32), c->stream));
+    HIPCHK(hipMemsetAsync(t->d_counters, 0, 24 * sizeof(u32), c->stream));
     static const bool match_prof = std::getenv("ZOPFLI_AMD_PROF") != nullptr;
     if (launch_match(t->d_pool, t->pool_cap, tile_off[nb], nullptr, match_prof) != 0) return -1;
     u32 counters[2] = {0, 0};
@@ -872,6 +872,14 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
                    "position, %.1f of 64 lanes with a hit per wave-loop iteration; %.1f SIMD cycles per hit (2.4 GHz, 1024 SIMDs)\n", MatchKernel() == 4 ? "k_match4" : MatchKernel() == 3 ? "k_match3" : "k_match2", ms_match, pos,
                    static_cast<double>(hc[0]) / pos, static_cast<double>(hc[0]) / static_cast<double>(hc[1] ? hc[1] : 1),
                    ms_match * 1e-3 * 2.4e9 * 1024 / static_cast<double>(hc[0] ? hc[0] : 1));
+      if (MatchKernel() == 3) {
+        unsigned long long h3[3] = {0, 0, 0};
+        HIPCHK(hipMemcpy(h3, t->d_counters + 16, sizeof(h3), hipMemcpyDeviceToHost));
+        const double nbat = static_cast<double>(hc[1] ? hc[1] : 1);
+        std::fprintf(stderr, "k_match3: per batch of <= 64 candidates: %.2f pass the 4-byte filter, %.2f steps of the byte compare, "
+                     "%.1f %% of the batches change nothing; %.0f SIMD cycles per batch\n", static_cast<double>(h3[0]) / nbat,
+                     static_cast<double>(h3[1]) / nbat, 100.0 * static_cast<double>(h3[2]) / nbat, ms_match * 1e-3 * 2.4e9 * 1024 / nbat);
+      }
     }
   }
 

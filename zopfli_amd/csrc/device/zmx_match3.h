@@ -192,6 +192,7 @@ __global__ __launch_bounds__(BK_THREADS) void k_bucket(BucketParams P) {
 // ---------------------------------------------------------------------------------------------
 // k_match3
 // ---------------------------------------------------------------------------------------------
+#define M4_PAD 32u      // sorted[] / ssame[] have this many entries in front: a 16-byte read of k_match4 may start below index 0
 #define M3_THREADS 512u
 #define M3_WAVES 8u
 #define M3_SCR 264u                      // change points of one position (lengths 2..258 strictly increasing: at most 257)
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(M3_THREADS, 6) void k_match3(Match3Params P) {
   u32* const scr = s_scr[wave];
   u32* const srec = s_rec[wave];
   const u64 lt_mask = (1ull << lane) - 1;
-  u64 n_hits = 0, n_batches = 0;
+  u64 n_hits = 0, n_batches = 0, n_pass = 0, n_lcp = 0, n_quiet = 0;
 
   for (;;) {
     __syncthreads();  // previous tile fully consumed before the window is overwritten
@@ -365,32 +366,23 @@ __global__ __launch_bounds__(M3_THREADS, 6) void k_match3(Match3Params P) {
         u32 bestlen = 1, bestdist = 0, ncp = 0, hits_left = ZMX_MAX_CHAIN_HITS;
         u32 foff = 0, fmask = 0xffffu;                 // the filter: bytes [foff, foff + 4) under fmask must equal pos's
         u32 pbytes = rdlane_u32(b012, u);
+        const u32 kp = li0 + first + u;                // region index of the position (same[] of a candidate: kp - dist)
         if (lane < 8) srec[lane] = 0;
-        for (;;) {
-          if (idx == lo) {
-            // this chunk's part of the slice is used up: the previous chunk's bucket, from its end
-            if (cc != cp_chunk || cc == 0) break;
-            cc = cp_chunk - 1;
-            const u32 e = h ? bkp1 : bkp0;
-            lo = e & 0xffffu;
-            idx = e >> 16;
-            if (idx == lo) break;
-          }
-          u32 nb = idx - lo < 64u ? idx - lo : 64u;
-          nb = nb < hits_left ? nb : hits_left;
-          const bool in_b = lane < nb;
-          const u32 si = cc * 32768u + idx - 1u - (in_b ? lane : 0u);
-          const u32 off = (h ? g_sorted1 : g_sorted0)[si];
-          u32 s8 = 0;
-          if (h == 0) s8 = g_ssame[si];
+
+        // One batch of up to 64 candidates in visit order: lane i holds entry idx - 1 - i of the slice (its offset in
+        // chunk cc; s8 = its same & 255, first hash only), the first nb_in of them exist.  Returns 0: all of them dealt
+        // with, the walk goes on in this slice (idx, hits_left moved); 1: the walk is over; 2: it switched to the second
+        // hash (the cursor h / idx / lo was put there).
+        auto batch = [&](u32 off, u32 s8, u32 nb_in) -> u32 {
+          u32 nb = nb_in;
           bool ended = false;
           if (cc != cp_chunk) {
             // previous chunk: only candidates less than 32768 back (lz77.c:464); offsets fall along the lanes
-            const u64 ok = __ballot(in_b && off > op);
+            const u64 ok = __ballot(lane < nb && off > op);
             const u32 nv = (u32)__popcll(ok);
             ended = nv < nb;
             nb = nv;
-            if (nb == 0) break;
+            if (nb == 0) return 1u;
           }
           const bool act = lane < nb;
           const u32 dist = (cp_chunk - cc) * 32768u + op - off;
@@ -401,17 +393,45 @@ __global__ __launch_bounds__(M3_THREADS, 6) void k_match3(Match3Params P) {
           {
             const u32 cw = m3_lds_u32(win, act ? lc + foff : 0u);
             bool go = act && ((cw ^ pbytes) & fmask) == 0;
-            u32 cur = 0;
-            while (__any(go)) {                        // GetMatch (lz77.c:297), 8 bytes per step
-              if (go) {
-                const u64 x = m3_lds_u64(win, lp + cur) ^ m3_lds_u64(win, lc + cur);
-                const u32 m = x ? (u32)(__ffsll((unsigned long long)x) - 1) >> 3 : 8u;
-                cur += m;
-                go = m == 8 && cur < limit;
+            u64 m_go = __ballot(go);
+            if (m_go != 0) {
+              u32 cur = 0;
+              if (same_p > 2u) {
+                // lz77.c:481-490: inside a run both sides repeat their first byte — skip what same[] vouches for
+                if (go && lds_byte(win, lc) == byte0) {
+                  const u32 lz = g_same[kp - dist];
+                  const u32 sk = same_p < lz ? same_p : lz;
+                  cur = sk < limit ? sk : limit;
+                  go = cur < limit;
+                }
               }
+              // (the whole wave comparing one passed candidate at a time, 264 bytes in one step, was tried for batches
+              //  with few of them: 1.5 - 2x slower on the long-list classes — their common prefixes are short)
+              if (PROF) n_pass += (u32)__popcll(m_go);
+              while (__any(go)) {                      // GetMatch (lz77.c:297), 8 bytes per step
+                if (PROF) ++n_lcp;
+                if (go) {
+                  const u64 x = m3_lds_u64(win, lp + cur) ^ m3_lds_u64(win, lc + cur);
+                  const u32 m = x ? (u32)(__ffsll((unsigned long long)x) - 1) >> 3 : 8u;
+                  cur += m;
+                  go = m == 8 && cur < limit;
+                }
+              }
+              len = cur < limit ? cur : limit;
+              if (!act || ((m_go >> lane) & 1ull) == 0) len = 0;
             }
-            len = cur < limit ? cur : limit;
-            if (!act) len = 0;
+            // nobody beats bestlen and nobody satisfies the switch rule (lz77.c:509-519: it needs no improvement, only
+            // bestlength >= same and the second hash value): the batch changes nothing but the counts — most batches of
+            // a long list
+            u64 m_ev = __ballot(len > bestlen);
+            if (h == 0 && bestlen >= same_p) m_ev |= __ballot(act && s8 == (same_p & 255u));
+            if (m_ev == 0) {
+              if (PROF) ++n_quiet;
+              hits_left -= nb;
+              if (hits_left == 0 || ended) return 1u;
+              idx -= nb;
+              return 0u;
+            }
           }
           // ---- in visit order: running maximum, change points, where the walk stops or switches
           const u32 incl = wave_scan_max(len);
@@ -447,21 +467,49 @@ __global__ __launch_bounds__(M3_THREADS, 6) void k_match3(Match3Params P) {
             fmask = bestlen >= 3 ? 0xffffffffu : 0xffffffu;
             pbytes = m3_sgpr(m3_lds_u32(win, lp + foff));
           }
-          if (l_stop < nb && !sw) break;               // the limit is reached
+          if (l_stop < nb && !sw) return 1u;           // the limit is reached
           if (sw) {
             hits_left -= l_sw + 1;
-            if (hits_left == 0) break;
+            if (hits_left == 0) return 1u;
             // on in the second hash's order, just below this candidate (its chunk stays cc)
             const u32 off_sw = rdlane_u32(off, l_sw);
             h = 1;
-            idx = g_rank1[cc * 32768u + off_sw];
-            idx = m3_sgpr(idx);
+            idx = m3_sgpr((u32)g_rank1[cc * 32768u + off_sw]);
             lo = (cc == cp_chunk ? bk1 : bkp1) & 0xffffu;
-            continue;
+            return 2u;
           }
           hits_left -= nb;
-          if (hits_left == 0 || ended) break;
+          if (hits_left == 0 || ended) return 1u;
           idx -= nb;
+          return 0u;
+        };
+        for (;;) {
+          if (idx == lo) {
+            // this chunk's part of the slice is used up: the previous chunk's bucket, from its end
+            if (cc != cp_chunk || cc == 0) break;
+            cc = cp_chunk - 1;
+            const u32 e = h ? bkp1 : bkp0;
+            lo = e & 0xffffu;
+            idx = e >> 16;
+            if (idx == lo) break;
+          }
+          u32 nb = idx - lo < 64u ? idx - lo : 64u;
+          nb = nb < hits_left ? nb : hits_left;
+          const u32 si = cc * 32768u + idx - 1u - (lane < nb ? lane : 0u);
+          const u32 off = (h ? g_sorted1 : g_sorted0)[si];
+          u32 s8 = 0;
+          if (h == 0) s8 = g_ssame[si];
+          // Tried on top of this and measured (profiles/r03_match_ab.txt), none of them a gain across the classes:
+          //  - the entries of the next batches requested ahead (register sets refilled in turn, also across positions):
+          //    same time on long lists, 25 % slower on text;
+          //  - a test of 256 entries at a time (four loads, the filter, the first 8 bytes) that skips the quarters in which
+          //    no candidate can change anything: 87 % of class P's batches skipped for 8 % of the time, B 45 % slower;
+          //  - the whole wave comparing one passed candidate at a time, 264 bytes in one step: 1.5 - 2x slower, the
+          //    common prefixes are short (one 8-byte step per batch on average).
+          // PMC on class P: ~115 instructions per batch, 66 scalar; each wave issues one every ~12 cycles outside its
+          // wait for the load — a chain of scalar / vector round trips and taken branches that 6 waves per SIMD (the
+          // window's 37 KiB of LDS allow no more) do not cover.
+          if (batch(off, s8, nb) == 1u) break;
         }
         // ---- the record (same layout as k_match2's)
         wave_lds_sync();
@@ -491,5 +539,8 @@ __global__ __launch_bounds__(M3_THREADS, 6) void k_match3(Match3Params P) {
   if (PROF) {
     atomicAdd(reinterpret_cast<unsigned long long*>(P.counters + 4), (unsigned long long)(lane == 0 ? n_hits : 0));
     atomicAdd(reinterpret_cast<unsigned long long*>(P.counters + 6), (unsigned long long)(lane == 0 ? n_batches : 0));
+    atomicAdd(reinterpret_cast<unsigned long long*>(P.counters + 16), (unsigned long long)(lane == 0 ? n_pass : 0));
+    atomicAdd(reinterpret_cast<unsigned long long*>(P.counters + 18), (unsigned long long)(lane == 0 ? n_lcp : 0));
+    atomicAdd(reinterpret_cast<unsigned long long*>(P.counters + 20), (unsigned long long)(lane == 0 ? n_quiet : 0));
   }
 }

@@ -30,7 +30,6 @@
 #define M4_PEND 3u      // walk ended, record not written yet
 #define M4_DONE 4u      // the tile has no more positions
 #define M4_QS_NONE 0xffffu
-#define M4_PAD 32u      // sorted[] has this many entries in front: a 16-byte read may start below index 0
 
 __device__ __forceinline__ u32 m4_hash3(u32 b012) {
   return (((b012 & 255u) << 10) ^ (((b012 >> 8) & 255u) << 5) ^ ((b012 >> 16) & 255u)) & 32767u;

@@ -36,6 +36,7 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
 // constant address space is what makes the compiler use s_load for it although the kernel stores
 // to other global arrays in between
 typedef u32 d5_u32x4 __attribute__((ext_vector_type(4)));
+typedef u32 d5_u32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) d5_u32x4* d5_cdscp;
 
 // What k_dp5_spec needs to fetch the rows of a 32-position window (aligned to the block start).  The rows of
@@ -125,6 +126,8 @@ struct D5IntTab {
   u32 span;            // 33 x the largest finite RR (saturated)
 };
 #define D5_NOEDGE 0x40000000u
+#define D5_RK0 32u       // s_rk: entry of k - 1 = 0 (window positions 0 .. 31: up to 32 entries below it are asked for)
+#define D5_RKN 352u      // ... and its size (k - 1 up to 63 + 256 above)
 // the lane mask of bits [OFS, OFS + WIDTH) (WIDTH < 64; only the low six bits of either operand count)
 #define D5_BFM(M, WIDTH, OFS) asm("s_bfm_b64 %0, %1, %2" : "=s"(M) : "s"(WIDTH), "n"(OFS))
 
@@ -216,7 +219,7 @@ template <bool PROF, bool RUNS>
 __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u32 b, const BlockDesc& bd,
                                            const double (&s_wtab)[ZMX_WTAB], float* s_xc, u16* s_xl, u16* s_stage,
                                            const uint2 (&s_itab)[ZMX_WTAB], const D5IntTab& IT, const double* s_w1,
-                                           const u8* s_sym1, uint2* s_ri) {
+                                           const u8* s_sym1, uint2* s_ri, uint2* s_rk) {
   typedef __attribute__((address_space(3))) const u16* lds_u16p;
   typedef __attribute__((address_space(3))) d5_u32x4* lds_u4p;
   // (the LDS byte address of the wave's staging area, halved: it joins the scalar part of the lanes' addresses)
@@ -282,13 +285,53 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
   // the wave's integer table of the run-row weights (29 length symbols at distance symbol 0, and one literal) for one
   // binade: r1_lo = bit pattern of its 2^e (0 = none built), see the run-row step below
   u32 r1_lo = 0, r1_lit = 0xffffffffu, r1_rmax = 0;
+  const u32 tiemask_b = P.tiemask[b];
+  // (re)builds the table for the binade of source value sj (a float's bit pattern) and literal byte lit; r1_lo stays 0
+  // if that binade can tie.  s_ri: by symbol (0 .. 28 the length symbols, 29 the literal, 30 / 31 no edge); s_rk: by
+  // k - 1 + D5_RK0 for a FULL row (k = 1 the literal, 2 no edge, 3 .. 258), no edge on either side of it — what lane l
+  // of cell register s needs for the row of window position p is entry l + 64 s - p - 1 + D5_RK0, whatever l, s, p.
+  auto r1_build = [&](u32 sj, u32 lit) {
+    const int e = (int)(sj >> 23) - 127;
+    r1_lo = 0;
+    if (((tiemask_b >> (e & 31)) & 1u) == 0) {
+      double w = kInf;
+      if (lane < 29) w = s_wtab[257u + 30u * lane];
+      else if (lane == 29) w = s_wtab[1u + lit];
+      uint2 v = make_uint2(D5_NOEDGE, D5_NOEDGE);
+      u32 rr = 0;
+      if (w < 1e300) {
+        const u64 r = d5_rne_scaled(w, e);
+        const u64 rh = r >> 29;
+        if (rh < 0x800000ull) {
+          rr = (u32)rh + ((r & 0x1fffffffull) > 0x10000000ull ? 1u : 0u);
+          v.x = rr;
+          v.y = (u32)rh;
+        } else {
+          rr = 0x800000u;                 // (a weight of the binade's own size: the room test keeps every position out)
+        }
+      }
+      wave_lds_sync();
+      if (lane < 32) s_ri[lane] = v;
+      wave_lds_sync();
+      if (RUNS) {
+#pragma unroll
+        for (u32 i = 0; i < D5_RKN; i += 64) {
+          const u32 k1 = i + lane - D5_RK0;
+          if (i + lane < D5_RKN) s_rk[i + lane] = s_ri[k1 < ZMX_MAX_MATCH ? s_sym1[k1] : 31u];
+        }
+        wave_lds_sync();
+      }
+      r1_rmax = d5_max64(rr);
+      r1_lo = sj & 0x7f800000u;
+      r1_lit = lit;
+    }
+  };
   // the header (dph, bad-edge word) of the generic window that will follow the current one, asked for as soon as the
   // current one's shortcut flags say where that is: behind a shortcut a window is one position and a jump, and the
   // header's round trip was most of its time
   u32 st_base = 0, st_n = 0;        // codes [st_base, st_base + st_n) of the block are in the staging area (generic rows)
   u32 gpf_base = SEG_NONE, gpf_bw = 0;
   uint2 gpf_dh = make_uint2(0, 0);
-  const u32 tiemask_b = P.tiemask[b];
   u64 n_fast = 0, n_slow = 0, n_int = 0;
   u64 kc[4] = {0, 0, 0, 0}, kn[4] = {0, 0, 0, 0};   // PROF: cycles / positions per window class: integer, class 1 in doubles, class 2, generic
   u64 pw[4] = {0, 0, 0, 0};   // PROF, integer windows: class decision, wait for the prefetched data, staging + prefetch issue, retire
@@ -569,7 +612,81 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
       if (noshort) W.ms &= ~(1ull << skip);   // squeeze.c:273: the position right after a shortcut is not tested again
       if (fine_) { gq[8] += (u64)__builtin_readcyclecounter() - th0_ + (u64)(W.kend & 0u); ++gq[9]; }
       const u32 skip0 = skip;                 // (cells below it were given their lengths by the shortcut)
-      for (u32 p = skip; p < W.nav; ++p) {
+      u32 p_first = skip;
+      if (RUNS && P.int_path != 0) {
+        // ---- the interior of a run: every position left in the window is a FULL run row (the literal and k = 3 .. 258
+        // at distance 1, same byte), no shortcut, no edge below mincost.  Lane l of register s then needs entry
+        // l + 64 s - p - 1 of ONE table (s_rk) — an LDS address that moves down 8 bytes per position, the five registers
+        // 512 bytes apart in the instruction's offset: per position one v_readlane, the room test, five ds_read_b64 and
+        // the 25 integer operations of the five registers, ~40 instructions against ~100 of the general run-row step
+        // below (a symbol look-up and a table look-up per register, clamped to the row's length).  A lone wave pays
+        // ~10 cycles for every instruction: 1 086 cycles a position there.
+        const u32 f0 = rdlane_u32(W.fl, skip);
+        const u64 rest = (~0ull << skip) & (W.nav >= 64u ? ~0ull : ((1ull << W.nav) - 1ull));
+        const u64 odd = __ballot(W.fl != f0 || W.kend != ZMX_MAX_MATCH) & rest;
+        if ((f0 & 1u) != 0 && odd == 0 && (W.ms & rest) == 0 && (W.mb & rest) == 0) {
+          const u32 lit = (f0 >> 1) & 255u;
+          const u64 tr0_ = fine_ ? (u64)__builtin_readcyclecounter() : 0ull;
+          typedef __attribute__((address_space(3))) const d5_u32x2* lds_u2p;
+          const u32 rk_lane = (u32)(size_t)(__attribute__((address_space(3))) void*)s_rk + 8u * (lane + D5_RK0 - 1u);
+          auto row = [&](u32 sj, u32 a, u32 src1) {
+            d5_u32x2 e5[5];
+#pragma unroll
+            for (int s = 0; s < 5; ++s) e5[s] = *(lds_u2p)(a + 512u * (u32)s);
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+              const u32 t_ = sj + e5[s].x, th_ = sj + e5[s].y;
+              const u32 cb = __float_as_uint(c[s]);
+              l[s] = th_ < cb ? src1 : l[s];
+              c[s] = __uint_as_float(cb < t_ ? cb : t_);
+            }
+          };
+          u32 p = skip;
+          // Room for the whole window at once?  Every cell of it reached and inside the table's binade with the largest
+          // weight to spare: cells only go down, and not below the smallest of them plus a weight, so every source of the
+          // window passes the test the loop below makes per position — which then is not in the chain any more (a scalar
+          // compare and branch between dependent vector instructions: half of a position's time).
+          bool roomy = false;
+          {
+            const u32 cb0 = __float_as_uint(c[0]);
+            const u32 s0 = rdlane_u32(cb0, skip);
+            if (s0 >= 0x41800000u && s0 < 0x4f000000u) {
+              if ((s0 & 0x7f800000u) != r1_lo || lit != r1_lit) r1_build(s0, lit);
+              if (r1_lo != 0) {
+                const bool inw = lane >= skip && lane < W.nav;
+                const u32 mx = d5_max64(inw ? cb0 : 0u), mn = d5_min64(inw ? cb0 : 0xffffffffu);
+                roomy = mn >= r1_lo && mx + r1_rmax < r1_lo + 0x800000u;
+              }
+            }
+          }
+          if (roomy && skip == 0 && W.nav == 32u) {
+#pragma unroll
+            for (u32 q = 0; q < 32u; ++q) row(rdlane_u32(__float_as_uint(c[0]), q), rk_lane - 8u * q, wbase + q + 1u);
+            p = 32u;
+          } else if (roomy) {
+            u32 a0 = rk_lane - 8u * skip;
+            for (; p < W.nav; ++p, a0 -= 8u) row(rdlane_u32(__float_as_uint(c[0]), p), a0, wbase + p + 1u);
+          } else {
+            u32 a0 = rk_lane - 8u * skip;
+            for (; p < W.nav; ++p, a0 -= 8u) {
+              const u32 sj = rdlane_u32(__float_as_uint(c[0]), p);
+              if (sj < 0x41800000u || sj >= 0x4f000000u) break;                       // (2^4 .. 2^31)
+              if ((sj & 0x7f800000u) != r1_lo || lit != r1_lit) r1_build(sj, lit);
+              if (r1_lo == 0 || sj + r1_rmax >= r1_lo + 0x800000u) break;
+              row(sj, a0, wbase + p + 1u);
+            }
+          }
+          if (p > skip) {
+            reach = reach > ZMX_MAX_MATCH + p - 1u ? reach : ZMX_MAX_MATCH + p - 1u;
+            noshort = false;
+            n_slow += p - skip;
+            if (PROF) n_int += p - skip;
+            if (fine_) { gq[2] += (u64)__builtin_readcyclecounter() - tr0_ + (u64)(__float_as_uint(c[0]) & 0u); gq[3] += p - skip; }
+          }
+          p_first = p;
+        }
+      }
+      for (u32 p = p_first; p < W.nav; ++p) {
         const u32 j = wbase + p;
         const u64 tp0_ = fine_ ? (u64)__builtin_readcyclecounter() : 0ull;
         u32 gk_ = 6;
@@ -632,34 +749,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
           // and is rebuilt when the chain leaves the binade or the literal changes (a few times per task).
           const u32 sj = rdlane_u32(__float_as_uint(c[0]), p);
           bool ipos = P.int_path != 0 && ((W.mb >> p) & 1ull) == 0 && sj >= 0x41800000u && sj < 0x4f000000u;   // (2^4 .. 2^31)
-          if (ipos && ((sj & 0x7f800000u) != r1_lo || lit != r1_lit)) {
-            const int e = (int)(sj >> 23) - 127;
-            r1_lo = 0;
-            if (((tiemask_b >> (e & 31)) & 1u) == 0) {
-              double w = kInf;
-              if (lane < 29) w = s_wtab[257u + 30u * lane];
-              else if (lane == 29) w = s_wtab[1u + lit];
-              uint2 v = make_uint2(D5_NOEDGE, D5_NOEDGE);
-              u32 rr = 0;
-              if (w < 1e300) {
-                const u64 r = d5_rne_scaled(w, e);
-                const u64 rh = r >> 29;
-                if (rh < 0x800000ull) {
-                  rr = (u32)rh + ((r & 0x1fffffffull) > 0x10000000ull ? 1u : 0u);
-                  v.x = rr;
-                  v.y = (u32)rh;
-                } else {
-                  rr = 0x800000u;                 // (a weight of the binade's own size: the room test below keeps every position out)
-                }
-              }
-              wave_lds_sync();
-              if (lane < 32) s_ri[lane] = v;
-              wave_lds_sync();
-              r1_rmax = d5_max64(rr);
-              r1_lo = sj & 0x7f800000u;
-              r1_lit = lit;
-            }
-          }
+          if (ipos && ((sj & 0x7f800000u) != r1_lo || lit != r1_lit)) r1_build(sj, lit);
           ipos = ipos && r1_lo != 0 && sj + r1_rmax < r1_lo + 0x800000u;
           if (ipos) {
             // branch-free over the five registers a row can reach (index <= 31 + 258): the five symbol reads, then the five
@@ -910,6 +1000,7 @@ __global__ __launch_bounds__(64 * D5_WG, WAVES) void k_dp5_spec(Dp4Params P) {
   __shared__ __align__(8) double s_w1[D5_W1];
   __shared__ u8 s_sym1[D5_W1];
   __shared__ __align__(8) uint2 s_ri[D5_WG][32];
+  __shared__ __align__(8) uint2 s_rk[RUNS ? D5_WG : 1u][RUNS ? D5_RKN : 1u];
   __shared__ u32 s_rmax;
   const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (P.redo_pass && blockIdx.x >= *P.redo_count) return;
@@ -975,7 +1066,7 @@ __global__ __launch_bounds__(64 * D5_WG, WAVES) void k_dp5_spec(Dp4Params P) {
     if (P.est_bits && (threadIdx.x & 63) == 0) P.lvl[t] = J.level;
   }
   d5_run_job<PROF, RUNS>(P, J, T.block, bd, s_wtab, reinterpret_cast<float*>(s_buf[wave]), reinterpret_cast<u16*>(s_buf[wave] + 4u * DP_XN),
-                   reinterpret_cast<u16*>(s_buf[wave]), s_itab, IT, s_w1, s_sym1, s_ri[wave]);
+                   reinterpret_cast<u16*>(s_buf[wave]), s_itab, IT, s_w1, s_sym1, s_ri[wave], s_rk[RUNS ? wave : 0u]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1113,7 +1204,8 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
       if (threadIdx.x < 64) {
         D5IntTab IT;
         IT.on = false; IT.lo = 0; IT.span = 0;
-        d5_run_job<PROF, true>(P, J, b, bd, s_wtab, s_xc, s_xl, s_ring, *reinterpret_cast<const uint2 (*)[ZMX_WTAB]>(&s_t1[0][0]), IT, s_w1, s_sym1, s_ri);
+        d5_run_job<PROF, true>(P, J, b, bd, s_wtab, s_xc, s_xl, s_ring, *reinterpret_cast<const uint2 (*)[ZMX_WTAB]>(&s_t1[0][0]), IT, s_w1, s_sym1, s_ri,
+                               reinterpret_cast<uint2*>(&s_t2[0][0]));   // (s_rk: the pipeline's tiles are idle in this job)
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __syncthreads();

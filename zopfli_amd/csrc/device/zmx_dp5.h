@@ -79,6 +79,10 @@ __global__ __launch_bounds__(256) void k_mkdesc(MkDescParams P) {
   // flagged for the shortcut, or short — or a wide run row (k_rowscan): those go position by position, where their
   // weights come from the run-row table instead of six scattered code loads (d5_run_job)
   const u64 not2 = __ballot(flagged || (((dhw.y >> 17) & 1u) != 0 && (dhw.y & 0xffffu) >= 64u));
+  // a row that reaches beyond cell register 1: kind 3 = kind 2 with such rows.  The text variant of the job takes it as
+  // kind 2 (the rest of such a row on demand: rare there); the run variant position by position with staged codes
+  // (the last 257 positions of every run of class Z are such rows: 1 800 cycles a position as kind 2)
+  const u64 far3 = __ballot(p < B && (dhw.y & 0xffffu) + (lane & 31u) >= 128u);
   const u32 first = (u32)__shfl((int)dhw.x, (int)(lane & 32u), 64);                  // row offset of the window's first position
   const u32 w = P.win_off[blockIdx.y] + (p >> 5);
   u32* wm = P.wmeta + (u64)w * D5_WM;
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) void k_mkdesc(MkDescParams P) {
   if (p < ((B + 31u) & ~31u)) wm[p & 31u] = p < B ? ((dhw.x - first + 32u - ((p & 31u) + 1u)) << 16) | kend : 0u;
   if ((lane & 31u) == 0 && p < B) {
     const u32 sh = lane & 32u;
-    const u32 f = (u32)(not1 >> sh) == 0 ? 1u : (u32)(not2 >> sh) == 0 ? 2u : 0u;
+    const u32 f = (u32)(not1 >> sh) == 0 ? 1u : (u32)(not2 >> sh) != 0 ? 0u : (u32)(far3 >> sh) == 0 ? 2u : 3u;
     P.winflag[w] = f;
     P.winroff[w] = dhw.x;
     wm[32] = dhw.x;
@@ -329,13 +333,18 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
   // the header (dph, bad-edge word) of the generic window that will follow the current one, asked for as soon as the
   // current one's shortcut flags say where that is: behind a shortcut a window is one position and a jump, and the
   // header's round trip was most of its time
-  u32 st_base = 0, st_n = 0;        // codes [st_base, st_base + st_n) of the block are in the staging area (generic rows)
+  // generic rows: the staging area is a ring of two regions of 1024 codes (region r of the block's codes at half r & 1);
+  // the regions below st_iss have been asked for, those below st_land are known to have arrived (st_ok: the ring is valid)
+  u32 st_iss = 0, st_land = 0;
+  bool st_ok = false;
   u32 gpf_base = SEG_NONE, gpf_bw = 0;
   uint2 gpf_dh = make_uint2(0, 0);
   u64 n_fast = 0, n_slow = 0, n_int = 0;
   u64 kc[4] = {0, 0, 0, 0}, kn[4] = {0, 0, 0, 0};   // PROF: cycles / positions per window class: integer, class 1 in doubles, class 2, generic
   u64 pw[4] = {0, 0, 0, 0};   // PROF, integer windows: class decision, wait for the prefetched data, staging + prefetch issue, retire
   u64 pq[3] = {0, 0, 0};   // PROF: cycles of the integer windows: issuing the row fetches, waiting for them, the chain
+  u64 gt[4] = {0, 0, 0, 0};   // PROF, cycles of generic windows: header, run interior in unrolled windows, in loops, the general step's loop
+  u64 gr[6] = {0, 0, 0, 0, 0, 0};   // PROF, positions: run interior (unrolled window, loop with room, loop with checks), run rows and other rows of the general step, class-2 rows that reach register 2
   u64 gq[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // PROF, generic windows: cycles / count of shortcuts, run rows (integer, doubles), other rows, window headers
   const u64 t_begin = PROF ? (u64)__builtin_readcyclecounter() : 0ull;
 
@@ -416,7 +425,11 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
     } else {
       kind = win_kind(wbase);
     }
-    if (kind != 0) st_n = 0;          // (the other windows use the staging area their own way)
+    if (kind == 3) kind = RUNS ? 0u : 2u;
+    if (kind != 0 && st_ok) {           // (the other windows use the staging area their own way)
+      if (st_land < st_iss) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      st_ok = false;
+    }
     if (kind == 1) {
       // ---- 32 positions, one cell register, no flags
       u32 lt_ = 0;                             // 1 + index of the last position that updated the cell
@@ -558,6 +571,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
           D3_RELAX_K(c[0], lt_, wa[u], p + 1u)
           D3_RELAX_K(c[1], lt1_, wb[u], p + 1u)
           if (ke8[u] + p >= 128u) {            // the row reaches cell register 2 or beyond
+            if (PROF) ++gr[5];
             const u16* row = reinterpret_cast<const u16*>(ra8[u]);
             const u32 src1 = wbase + p + 1;
             reach = reach > ke8[u] + p ? reach : ke8[u] + p;
@@ -585,7 +599,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
       D5Cls W;
       W.nav = B - wbase < 32u ? B - wbase : 32u;
       const bool fine_ = PROF && P.debug == 7;   // (the per-position timers cost a scalar-memory round trip each)
-      const u64 th0_ = fine_ ? (u64)__builtin_readcyclecounter() : 0ull;
+      const u64 th0_ = PROF ? (u64)__builtin_readcyclecounter() : 0ull;
       {
         const u32 jj = wbase + lane;
         const bool act = lane < W.nav;
@@ -611,11 +625,12 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
       }
       if (noshort) W.ms &= ~(1ull << skip);   // squeeze.c:273: the position right after a shortcut is not tested again
       if (fine_) { gq[8] += (u64)__builtin_readcyclecounter() - th0_ + (u64)(W.kend & 0u); ++gq[9]; }
+      if (PROF) gt[0] += (u64)__builtin_readcyclecounter() - th0_ + (u64)(W.kend & 0u);
       const u32 skip0 = skip;                 // (cells below it were given their lengths by the shortcut)
       u32 p_first = skip;
       if (RUNS && P.int_path != 0) {
-        // ---- the interior of a run: every position left in the window is a FULL run row (the literal and k = 3 .. 258
-        // at distance 1, same byte), no shortcut, no edge below mincost.  Lane l of register s then needs entry
+        // ---- the interior of a run: a stretch of FULL run rows (the literal and k = 3 .. 258 at distance 1, same byte),
+        // no shortcut, no edge below mincost.  Lane l of register s then needs entry
         // l + 64 s - p - 1 of ONE table (s_rk) — an LDS address that moves down 8 bytes per position, the five registers
         // 512 bytes apart in the instruction's offset: per position one v_readlane, the room test, five ds_read_b64 and
         // the 25 integer operations of the five registers, ~40 instructions against ~100 of the general run-row step
@@ -623,10 +638,21 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
         // ~10 cycles for every instruction: 1 086 cycles a position there.
         const u32 f0 = rdlane_u32(W.fl, skip);
         const u64 rest = (~0ull << skip) & (W.nav >= 64u ? ~0ull : ((1ull << W.nav) - 1ull));
-        const u64 odd = __ballot(W.fl != f0 || W.kend != ZMX_MAX_MATCH) & rest;
-        if ((f0 & 1u) != 0 && odd == 0 && (W.ms & rest) == 0 && (W.mb & rest) == 0) {
+        // (the stretch [skip, stop): up to the first position that is something else — a shortcut, a shorter or another
+        //  kind of row, an edge below mincost; behind a shortcut that is one position, the one squeeze.c:273 exempts)
+        // Rows shorter than 258 belong too if they all end at the same cell E (the last positions of a run whose matches do
+        // not continue elsewhere, or the block's end): the table has no edge beyond k = 258 but knows nothing of E, so the
+        // cells beyond E are put back as they were once the stretch is done — no row of the stretch has an edge to them
+        // (a full row of the same run ends at or before E), and no position of the stretch lies beyond E.
+        const u32 endp = lane + W.kend;                                   // the last cell of the row, from the window's base
+        const u64 shortm = __ballot(W.kend != ZMX_MAX_MATCH) & rest;
+        const u32 e_rel = shortm ? rdlane_u32(endp, (u32)__ffsll((long long)shortm) - 1u) : 0xffffffffu;
+        const u64 odd = (__ballot(W.fl != f0 || endp > e_rel || (W.kend != ZMX_MAX_MATCH && endp != e_rel) || W.kend < 3u) | W.ms | W.mb) & rest;
+        const u32 stop = odd ? (u32)__ffsll((long long)odd) - 1u : W.nav;
+        const bool cut_e = stop > skip && (shortm & ((stop >= 64u ? 0ull : (1ull << stop)) - 1ull)) != 0;   // a short row in [skip, stop)
+        if ((f0 & 1u) != 0 && stop > skip) {
           const u32 lit = (f0 >> 1) & 255u;
-          const u64 tr0_ = fine_ ? (u64)__builtin_readcyclecounter() : 0ull;
+          const u64 tr0_ = PROF ? (u64)__builtin_readcyclecounter() : 0ull;
           typedef __attribute__((address_space(3))) const d5_u32x2* lds_u2p;
           const u32 rk_lane = (u32)(size_t)(__attribute__((address_space(3))) void*)s_rk + 8u * (lane + D5_RK0 - 1u);
           auto row = [&](u32 sj, u32 a, u32 src1) {
@@ -642,6 +668,12 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
             }
           };
           u32 p = skip;
+          float c_sv[5];
+          u32 l_sv[5];
+          if (cut_e) {
+#pragma unroll
+            for (int s = 0; s < 5; ++s) { c_sv[s] = c[s]; l_sv[s] = l[s]; }
+          }
           // Room for the whole window at once?  Every cell of it reached and inside the table's binade with the largest
           // weight to spare: cells only go down, and not below the smallest of them plus a weight, so every source of the
           // window passes the test the loop below makes per position — which then is not in the chain any more (a scalar
@@ -653,31 +685,44 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
             if (s0 >= 0x41800000u && s0 < 0x4f000000u) {
               if ((s0 & 0x7f800000u) != r1_lo || lit != r1_lit) r1_build(s0, lit);
               if (r1_lo != 0) {
-                const bool inw = lane >= skip && lane < W.nav;
+                const bool inw = lane >= skip && lane < stop;
                 const u32 mx = d5_max64(inw ? cb0 : 0u), mn = d5_min64(inw ? cb0 : 0xffffffffu);
                 roomy = mn >= r1_lo && mx + r1_rmax < r1_lo + 0x800000u;
               }
             }
           }
-          if (roomy && skip == 0 && W.nav == 32u) {
+          if (roomy && skip == 0 && stop == 32u && !cut_e) {
 #pragma unroll
             for (u32 q = 0; q < 32u; ++q) row(rdlane_u32(__float_as_uint(c[0]), q), rk_lane - 8u * q, wbase + q + 1u);
             p = 32u;
+            if (PROF) { gr[0] += 32; gt[1] += (u64)__builtin_readcyclecounter() - tr0_ + (u64)(__float_as_uint(c[0]) & 0u); }
           } else if (roomy) {
+            if (PROF) gr[1] += stop - skip;
             u32 a0 = rk_lane - 8u * skip;
-            for (; p < W.nav; ++p, a0 -= 8u) row(rdlane_u32(__float_as_uint(c[0]), p), a0, wbase + p + 1u);
+            for (; p < stop; ++p, a0 -= 8u) row(rdlane_u32(__float_as_uint(c[0]), p), a0, wbase + p + 1u);
           } else {
             u32 a0 = rk_lane - 8u * skip;
-            for (; p < W.nav; ++p, a0 -= 8u) {
+            for (; p < stop; ++p, a0 -= 8u) {
               const u32 sj = rdlane_u32(__float_as_uint(c[0]), p);
               if (sj < 0x41800000u || sj >= 0x4f000000u) break;                       // (2^4 .. 2^31)
               if ((sj & 0x7f800000u) != r1_lo || lit != r1_lit) r1_build(sj, lit);
               if (r1_lo == 0 || sj + r1_rmax >= r1_lo + 0x800000u) break;
               row(sj, a0, wbase + p + 1u);
+              if (PROF) ++gr[2];
             }
           }
+          if (cut_e) {
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+              const bool beyond = 64u * (u32)s + lane > e_rel;
+              c[s] = beyond ? c_sv[s] : c[s];
+              l[s] = beyond ? l_sv[s] : l[s];
+            }
+          }
+          if (PROF && !(roomy && skip == 0 && stop == 32u && !cut_e)) gt[2] += (u64)__builtin_readcyclecounter() - tr0_ + (u64)(__float_as_uint(c[0]) & 0u);
           if (p > skip) {
-            reach = reach > ZMX_MAX_MATCH + p - 1u ? reach : ZMX_MAX_MATCH + p - 1u;
+            const u32 far_ = ZMX_MAX_MATCH + p - 1u < e_rel ? ZMX_MAX_MATCH + p - 1u : e_rel;
+            reach = reach > far_ ? reach : far_;
             noshort = false;
             n_slow += p - skip;
             if (PROF) n_int += p - skip;
@@ -686,6 +731,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
           p_first = p;
         }
       }
+      const u64 tg0_ = PROF ? (u64)__builtin_readcyclecounter() : 0ull;
       for (u32 p = p_first; p < W.nav; ++p) {
         const u32 j = wbase + p;
         const u64 tp0_ = fine_ ? (u64)__builtin_readcyclecounter() : 0ull;
@@ -693,7 +739,8 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
         if ((W.ms >> p) & 1) {
           // long-run shortcut at position j (squeeze.c:251-271)
           if (lane >= skip0 && lane < p && wbase + lane >= la_lo) put_la(wbase + lane, (u16)(l[0] ? wbase + lane + 1 - l[0] : 0u));
-          st_n = 0;                               // (the cells are spilled where the staged codes lie)
+          if (st_ok && st_land < st_iss) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          st_ok = false;                          // (the cells are spilled where the staged codes lie)
           wave_lds_sync();
 #pragma unroll
           for (int s = 0; s < 6; ++s) {
@@ -737,6 +784,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
         const u32 smax = (ke + p) >> 6;
         reach = reach > ke + p ? reach : ke + p;
         const u32 fl = rdlane_u32(W.fl, p);
+        if (PROF) ++gr[(fl & 1u) ? 3 : 4];
         if (RUNS && (fl & 1u)) {
           // a run row (k_rowscan): the literal and (k, distance 1) for k = 3 .. ke — weights from tables of those edges,
           // nothing read from codes[]: inside runs of equal bytes, where every row is 258 wide, the six scattered code
@@ -798,20 +846,32 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
           // next rows too — eight of the widest), brought in by LDS-DMA.  One scattered 2-byte global load per register
           // and position, a full memory round trip each time, was what these rows cost before (class Z: the last 257
           // positions of every long run are such rows).
-          if (ro < st_base || ro + ke > st_base + st_n) {
-            st_base = ro & ~7u;
-            const u16* src_ = rows + st_base + 8u * lane;
-#pragma unroll
-            for (u32 k = 0; k < 4; ++k) dp_dma_piece(src_ + 512u * k, (stage_half << 1) + 1024u * k);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            st_n = 2048u;
+          // (the row's first region and the one behind it are in the ring or on their way — the second is asked for
+          //  when the rows enter the first, three or more 258-wide rows before one of them reaches into it: with one
+          //  region of 2048 codes, fetched when a row ran over its end, every eighth position waited a full round trip)
+          const u32 rg0 = ro >> 10, rg1 = (ro + ke - 1u) >> 10;
+          if (!st_ok || st_iss < rg0 || st_iss > rg0 + 2u) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // (nothing still landing where the new regions go)
+            st_iss = rg0;
+            st_land = rg0;
+            st_ok = true;
           }
-          const u32 sb_ = ro - st_base;
+          while (st_iss < rg0 + 2u) {                                // (region st_iss takes the half of region st_iss - 2 < rg0)
+            const u16* src_ = rows + 1024u * st_iss + 8u * lane;
+            const u32 dst_ = (stage_half << 1) + 2048u * (st_iss & 1u);
+            dp_dma_piece(src_, dst_);
+            dp_dma_piece(src_ + 512, dst_ + 1024u);
+            ++st_iss;
+          }
+          if (st_land <= rg1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st_land = st_iss;
+          }
           u32 cd[5];
 #pragma unroll
           for (int s = 0; s < 5; ++s) {
             const u32 k1 = km1 + 64u * s;
-            cd[s] = s_stage[sb_ + (k1 < ke ? k1 : 0u)];
+            cd[s] = s_stage[(ro + (k1 < ke ? k1 : 0u)) & 2047u];
           }
           double wv[5];
 #pragma unroll
@@ -857,6 +917,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
         ++n_slow;
         if (fine_) { gq[gk_] += (u64)__builtin_readcyclecounter() - tp0_ + (u64)(__float_as_uint(c[0]) & 0u); ++gq[gk_ + 1]; }
       }
+      if (PROF) gt[3] += (u64)__builtin_readcyclecounter() - tg0_ + (u64)(__float_as_uint(c[0]) & 0u);
     }
     if (PROF) { kc[pcls] += (u64)__builtin_readcyclecounter() - tw0; kn[pcls] += n_fast + n_slow - np0; }
     if (jumped) continue;
@@ -895,6 +956,8 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
     for (int i = 0; i < 4; ++i) { atomicAdd(&o[24 + i], kc[i]); atomicAdd(&o[28 + i], kn[i]); }
     atomicAdd(&o[11], pq[0]); atomicAdd(&o[12], pq[1]); atomicAdd(&o[13], pq[2]);
     for (int i = 0; i < 10; ++i) atomicAdd(&o[32 + i], gq[i]);
+    for (int i = 0; i < 6; ++i) atomicAdd(&o[42 + i], gr[i]);
+    for (int i = 0; i < 4; ++i) atomicAdd(&o[48 + i], gt[i]);
     const u64 dt = (u64)__builtin_readcyclecounter() - t_begin;
     atomicMax(&o[7], dt);                               // the longest task of the block
     if (J.la_lo == 1) atomicAdd(&o[8], dt);             // the head task
@@ -982,7 +1045,7 @@ __global__ __launch_bounds__(64) void k_taskkind(TaskKindParams P) {
   const u32* wf = P.winflag + P.win_off[K.block];
   const u32 w0 = K.q >> 5, w1 = ((K.pend < B ? K.pend : B) + 31u) >> 5;
   u32 g = 0;
-  for (u32 w = w0 + threadIdx.x; w < w1; w += 64) g += wf[w] == 0 ? 1u : 0u;
+  for (u32 w = w0 + threadIdx.x; w < w1; w += 64) g += wf[w] == 0 || wf[w] == 3 ? 1u : 0u;
   g = wave_scan_add(g);
   if (threadIdx.x == 63) P.kind[t] = 4u * g >= (w1 - w0) && g >= 4u ? 1u : 0u;
 }

@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256) void k_badscan(BadScanParams P) {
 }
 
 // ------------------------------------------- shared by the chain kernels (zmx_dp4.h)
-#define ZMX_PROF_N 48u                // u64 profiling counters per block (ZOPFLI_AMD_PROF)
+#define ZMX_PROF_N 56u                // u64 profiling counters per block (ZOPFLI_AMD_PROF)
 #define DP_RING 16384u                // weight codes in the LDS ring (32 KB)
 #define DP_PIECE 512u                 // codes per LDS-DMA instruction (64 lanes x 16 B)
 #define DP_XN 704u                    // long-run shortcut staging: 384 cells

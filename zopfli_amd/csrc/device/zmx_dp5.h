@@ -343,6 +343,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
   u64 kc[4] = {0, 0, 0, 0}, kn[4] = {0, 0, 0, 0};   // PROF: cycles / positions per window class: integer, class 1 in doubles, class 2, generic
   u64 pw[4] = {0, 0, 0, 0};   // PROF, integer windows: class decision, wait for the prefetched data, staging + prefetch issue, retire
   u64 pq[3] = {0, 0, 0};   // PROF: cycles of the integer windows: issuing the row fetches, waiting for them, the chain
+  u64 go[2] = {0, 0};         // PROF: cycles / positions of whole windows of other rows
   u64 gt[4] = {0, 0, 0, 0};   // PROF, cycles of generic windows: header, run interior in unrolled windows, in loops, the general step's loop
   u64 gr[6] = {0, 0, 0, 0, 0, 0};   // PROF, positions: run interior (unrolled window, loop with room, loop with checks), run rows and other rows of the general step, class-2 rows that reach register 2
   u64 gq[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // PROF, generic windows: cycles / count of shortcuts, run rows (integer, doubles), other rows, window headers
@@ -628,7 +629,80 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
       if (PROF) gt[0] += (u64)__builtin_readcyclecounter() - th0_ + (u64)(W.kend & 0u);
       const u32 skip0 = skip;                 // (cells below it were given their lengths by the shortcut)
       u32 p_first = skip;
-      if (RUNS && P.int_path != 0) {
+      if (RUNS && skip == 0 && W.nav == 32u && W.ms == 0 && W.mb == 0 && (u32)__ballot((W.fl & 1u) != 0) == 0) {
+        // ---- a whole window of other rows (the last 257 positions of a run: 258 edges a row, two or three distances):
+        // nothing to decide per position, so the 32 rows are one piece of straight-line code — the codes of row p + 1 are
+        // read from the ring while row p is relaxed, no edge of the window lies below mincost (W.mb: squeeze.c:293 is a
+        // no-op, as in a kind-2 window).  Position by position below, such a row cost ~2 200 cycles: ~130 instructions
+        // with a scalar decision between every few of them, and a lone wave waits out every one.
+        const u64 to0_ = PROF ? (u64)__builtin_readcyclecounter() : 0ull;
+        auto ring = [&](u32 ro, u32 ke) {
+          const u32 rg0 = ro >> 10, rg1 = (ro + ke - 1u) >> 10;
+          if (!st_ok || st_iss < rg0 || st_iss > rg0 + 2u) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st_iss = rg0;
+            st_land = rg0;
+            st_ok = true;
+          }
+          while (st_iss < rg0 + 2u) {
+            const u16* src_ = rows + 1024u * st_iss + 8u * lane;
+            const u32 dst_ = (stage_half << 1) + 2048u * (st_iss & 1u);
+            dp_dma_piece(src_, dst_);
+            dp_dma_piece(src_ + 512, dst_ + 1024u);
+            ++st_iss;
+          }
+          if (st_land <= rg1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            st_land = st_iss;
+          }
+        };
+        // lane l of register s wants code l + 64 s - p - 1 of row p (none if that is not in [0, ke): code 0 = no edge)
+        auto codes = [&](u32 (&cd)[5], u32 ro, u32 ke, u32 p) {
+#pragma unroll
+          for (int s = 0; s < 5; ++s) {
+            const u32 k1 = lane + 64u * (u32)s - p - 1u;
+            const u32 v = s_stage[(ro + k1) & 2047u];
+            cd[s] = k1 < ke ? (v & 0x3ff8u) : 0u;
+          }
+        };
+        auto relax = [&](const u32 (&cd)[5], u32 p) {
+          const double cj = (double)rdlane_f32(c[0], p);
+          const u32 src1 = wbase + p + 1u;
+#pragma unroll
+          for (int s = 0; s < 5; ++s) {
+            const double w = code_w(cd[s]);
+            D3_RELAX_K(c[s], l[s], w, src1)
+          }
+        };
+        u32 cdA[5], cdB[5];
+        {
+          const u32 ro = rdlane_u32(W.roff, 0), ke = rdlane_u32(W.kend, 0);
+          ring(ro, ke);
+          codes(cdA, ro, ke, 0);
+        }
+#pragma unroll 1
+        for (u32 p = 0; p < 32u; p += 2u) {
+          {
+            const u32 ro = rdlane_u32(W.roff, p + 1u), ke = rdlane_u32(W.kend, p + 1u);
+            ring(ro, ke);
+            codes(cdB, ro, ke, p + 1u);
+          }
+          relax(cdA, p);
+          if (p + 2u < 32u) {
+            const u32 ro = rdlane_u32(W.roff, p + 2u), ke = rdlane_u32(W.kend, p + 2u);
+            ring(ro, ke);
+            codes(cdA, ro, ke, p + 2u);
+          }
+          relax(cdB, p + 1u);
+        }
+        const u32 far_ = d5_max64(lane < 32u ? lane + W.kend : 0u);
+        reach = reach > far_ ? reach : far_;
+        noshort = false;
+        n_slow += 32;
+        if (PROF) { go[0] += (u64)__builtin_readcyclecounter() - to0_ + (u64)(__float_as_uint(c[0]) & 0u); go[1] += 32; }
+        p_first = 32u;
+      }
+      if (RUNS && P.int_path != 0 && p_first < W.nav) {
         // ---- the interior of a run: a stretch of FULL run rows (the literal and k = 3 .. 258 at distance 1, same byte),
         // no shortcut, no edge below mincost.  Lane l of register s then needs entry
         // l + 64 s - p - 1 of ONE table (s_rk) — an LDS address that moves down 8 bytes per position, the five registers
@@ -958,6 +1032,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
     for (int i = 0; i < 10; ++i) atomicAdd(&o[32 + i], gq[i]);
     for (int i = 0; i < 6; ++i) atomicAdd(&o[42 + i], gr[i]);
     for (int i = 0; i < 4; ++i) atomicAdd(&o[48 + i], gt[i]);
+    atomicAdd(&o[52], go[0]); atomicAdd(&o[53], go[1]);
     const u64 dt = (u64)__builtin_readcyclecounter() - t_begin;
     atomicMax(&o[7], dt);                               // the longest task of the block
     if (J.la_lo == 1) atomicAdd(&o[8], dt);             // the head task

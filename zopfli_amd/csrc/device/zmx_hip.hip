@@ -1478,6 +1478,7 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
                  a[42], a[43], a[44], a[45], a[46], a[47]);
     std::fprintf(stderr, "  k_dp5_spec generic windows, cycles: headers %.3g, run interior unrolled %.3g (%.0f per position), in loops %.3g (%.0f), the general step %.3g (%.0f per position incl. shortcuts)\n",
                  a[48], a[49], a[49] / (a[42] + 1e-9), a[50], a[50] / (a[43] + a[44] + 1e-9), a[51], a[51] / (a[45] + a[46] + a[33] + 1e-9));
+    std::fprintf(stderr, "  k_dp5_spec whole windows of other rows: %.0f positions at %.0f cycles each\n", a[53], a[52] / (a[53] + 1e-9));
     const char* nm[5] = {"32", "16", "8", "8 (two registers)", "generic"};
     for (int i = 0; i < 5; ++i)
       std::fprintf(stderr, "  path %-18s %5.1f%% of positions, %6.1f cycles/position\n", nm[i], 100.0 * a[6 + 2 * i] / a[4],

@@ -628,14 +628,17 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
       if (fine_) { gq[8] += (u64)__builtin_readcyclecounter() - th0_ + (u64)(W.kend & 0u); ++gq[9]; }
       if (PROF) gt[0] += (u64)__builtin_readcyclecounter() - th0_ + (u64)(W.kend & 0u);
       const u32 skip0 = skip;                 // (cells below it were given their lengths by the shortcut)
-      u32 p_first = skip;
-      if (RUNS && skip == 0 && W.nav == 32u && W.ms == 0 && W.mb == 0 && (u32)__ballot((W.fl & 1u) != 0) == 0) {
-        // ---- a whole window of other rows (the last 257 positions of a run: 258 edges a row, two or three distances):
-        // nothing to decide per position, so the 32 rows are one piece of straight-line code — the codes of row p + 1 are
-        // read from the ring while row p is relaxed, no edge of the window lies below mincost (W.mb: squeeze.c:293 is a
-        // no-op, as in a kind-2 window).  Position by position below, such a row cost ~2 200 cycles: ~130 instructions
-        // with a scalar decision between every few of them, and a lone wave waits out every one.
+      // ---- a stretch of OTHER rows from position p0 on (the last 257 positions of a run: 258 edges a row, two or three
+      // distances; neither run rows nor shortcuts, no edge below mincost — W.mb: squeeze.c:293 is a no-op for them, as in
+      // a kind-2 window): nothing to decide per position, so the rows are straight-line code, the codes of the next row
+      // read from the ring while this one is relaxed.  Position by position (the general step below) such a row cost
+      // ~2 200 cycles: ~130 instructions with a scalar decision between every few of them, and a lone wave waits out
+      // every one.  Returns the position the stretch ends at.
+      auto other_stretch = [&](u32 p0) -> u32 {
         const u64 to0_ = PROF ? (u64)__builtin_readcyclecounter() : 0ull;
+        const u64 rest = (~0ull << p0) & (W.nav >= 64u ? ~0ull : ((1ull << W.nav) - 1ull));
+        const u64 odd = (__ballot((W.fl & 1u) != 0) | W.ms | W.mb) & rest;
+        const u32 stop = odd ? (u32)__ffsll((long long)odd) - 1u : W.nav;
         auto ring = [&](u32 ro, u32 ke) {
           const u32 rg0 = ro >> 10, rg1 = (ro + ke - 1u) >> 10;
           if (!st_ok || st_iss < rg0 || st_iss > rg0 + 2u) {
@@ -657,7 +660,9 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
           }
         };
         // lane l of register s wants code l + 64 s - p - 1 of row p (none if that is not in [0, ke): code 0 = no edge)
-        auto codes = [&](u32 (&cd)[5], u32 ro, u32 ke, u32 p) {
+        auto codes = [&](u32 (&cd)[5], u32 p) {
+          const u32 ro = rdlane_u32(W.roff, p), ke = rdlane_u32(W.kend, p);
+          ring(ro, ke);
 #pragma unroll
           for (int s = 0; s < 5; ++s) {
             const u32 k1 = lane + 64u * (u32)s - p - 1u;
@@ -675,138 +680,143 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
           }
         };
         u32 cdA[5], cdB[5];
-        {
-          const u32 ro = rdlane_u32(W.roff, 0), ke = rdlane_u32(W.kend, 0);
-          ring(ro, ke);
-          codes(cdA, ro, ke, 0);
-        }
+        codes(cdA, p0);
+        if (p0 == 0 && stop == 32u) {           // (a whole window, the usual case: a loop without decisions — 717 cycles a position against 1 008)
 #pragma unroll 1
-        for (u32 p = 0; p < 32u; p += 2u) {
-          {
-            const u32 ro = rdlane_u32(W.roff, p + 1u), ke = rdlane_u32(W.kend, p + 1u);
-            ring(ro, ke);
-            codes(cdB, ro, ke, p + 1u);
+          for (u32 p = 0; p < 32u; p += 2u) {
+            codes(cdB, p + 1u);
+            relax(cdA, p);
+            if (p + 2u < 32u) codes(cdA, p + 2u);
+            relax(cdB, p + 1u);
           }
-          relax(cdA, p);
-          if (p + 2u < 32u) {
-            const u32 ro = rdlane_u32(W.roff, p + 2u), ke = rdlane_u32(W.kend, p + 2u);
-            ring(ro, ke);
-            codes(cdA, ro, ke, p + 2u);
+        } else {
+#pragma unroll 1
+          for (u32 p = p0; p < stop; p += 2u) {
+            if (p + 1u < stop) codes(cdB, p + 1u);
+            relax(cdA, p);
+            if (p + 1u >= stop) break;
+            if (p + 2u < stop) codes(cdA, p + 2u);
+            relax(cdB, p + 1u);
           }
-          relax(cdB, p + 1u);
         }
-        const u32 far_ = d5_max64(lane < 32u ? lane + W.kend : 0u);
+        const u32 far_ = d5_max64(lane >= p0 && lane < stop ? lane + W.kend : 0u);
         reach = reach > far_ ? reach : far_;
         noshort = false;
-        n_slow += 32;
-        if (PROF) { go[0] += (u64)__builtin_readcyclecounter() - to0_ + (u64)(__float_as_uint(c[0]) & 0u); go[1] += 32; }
-        p_first = 32u;
-      }
-      if (RUNS && P.int_path != 0 && p_first < W.nav) {
-        // ---- the interior of a run: a stretch of FULL run rows (the literal and k = 3 .. 258 at distance 1, same byte),
-        // no shortcut, no edge below mincost.  Lane l of register s then needs entry
-        // l + 64 s - p - 1 of ONE table (s_rk) — an LDS address that moves down 8 bytes per position, the five registers
-        // 512 bytes apart in the instruction's offset: per position one v_readlane, the room test, five ds_read_b64 and
-        // the 25 integer operations of the five registers, ~40 instructions against ~100 of the general run-row step
-        // below (a symbol look-up and a table look-up per register, clamped to the row's length).  A lone wave pays
-        // ~10 cycles for every instruction: 1 086 cycles a position there.
-        const u32 f0 = rdlane_u32(W.fl, skip);
-        const u64 rest = (~0ull << skip) & (W.nav >= 64u ? ~0ull : ((1ull << W.nav) - 1ull));
-        // (the stretch [skip, stop): up to the first position that is something else — a shortcut, a shorter or another
-        //  kind of row, an edge below mincost; behind a shortcut that is one position, the one squeeze.c:273 exempts)
-        // Rows shorter than 258 belong too if they all end at the same cell E (the last positions of a run whose matches do
-        // not continue elsewhere, or the block's end): the table has no edge beyond k = 258 but knows nothing of E, so the
-        // cells beyond E are put back as they were once the stretch is done — no row of the stretch has an edge to them
-        // (a full row of the same run ends at or before E), and no position of the stretch lies beyond E.
+        n_slow += stop - p0;
+        if (PROF) { go[0] += (u64)__builtin_readcyclecounter() - to0_ + (u64)(__float_as_uint(c[0]) & 0u); go[1] += stop - p0; }
+        return stop;
+      };
+      // ---- the interior of a run: a stretch of run rows from position p0 on — FULL ones (the literal and k = 3 .. 258 at
+      // distance 1), same byte, no shortcut, no edge below mincost.  Lane l of register s then needs entry
+      // l + 64 s - p - 1 of ONE table (s_rk) — an LDS address that moves down 8 bytes per position, the five registers
+      // 512 bytes apart in the instruction's offset: per position one v_readlane, five ds_read_b64 and the 25 integer
+      // operations of the five registers, ~35 instructions against ~100 of the general run-row step below (a symbol
+      // look-up and a table look-up per register, clamped to the row's length: 1 100 cycles a position; a whole window
+      // of this: 205).  Rows shorter than 258 belong too if they all end at the same cell E (the last positions of a run
+      // whose matches do not continue elsewhere, or the block's end): the table has no edge beyond k = 258 but knows
+      // nothing of E, so the cells beyond E are put back as they were once the stretch is done — no row of the stretch
+      // has an edge to them (a full row of the same run ends at or before E), and no position of it lies beyond E.
+      // Returns the position the stretch ends at (p0: no stretch — the general step takes the position).
+      auto run_stretch = [&](u32 p0) -> u32 {
+        const u32 f0 = rdlane_u32(W.fl, p0);
+        const u64 rest = (~0ull << p0) & (W.nav >= 64u ? ~0ull : ((1ull << W.nav) - 1ull));
         const u32 endp = lane + W.kend;                                   // the last cell of the row, from the window's base
         const u64 shortm = __ballot(W.kend != ZMX_MAX_MATCH) & rest;
         const u32 e_rel = shortm ? rdlane_u32(endp, (u32)__ffsll((long long)shortm) - 1u) : 0xffffffffu;
         const u64 odd = (__ballot(W.fl != f0 || endp > e_rel || (W.kend != ZMX_MAX_MATCH && endp != e_rel) || W.kend < 3u) | W.ms | W.mb) & rest;
         const u32 stop = odd ? (u32)__ffsll((long long)odd) - 1u : W.nav;
-        const bool cut_e = stop > skip && (shortm & ((stop >= 64u ? 0ull : (1ull << stop)) - 1ull)) != 0;   // a short row in [skip, stop)
-        if ((f0 & 1u) != 0 && stop > skip) {
-          const u32 lit = (f0 >> 1) & 255u;
-          const u64 tr0_ = PROF ? (u64)__builtin_readcyclecounter() : 0ull;
-          typedef __attribute__((address_space(3))) const d5_u32x2* lds_u2p;
-          const u32 rk_lane = (u32)(size_t)(__attribute__((address_space(3))) void*)s_rk + 8u * (lane + D5_RK0 - 1u);
-          auto row = [&](u32 sj, u32 a, u32 src1) {
-            d5_u32x2 e5[5];
+        if (stop <= p0) return p0;
+        const bool cut_e = (shortm & ((stop >= 64u ? 0ull : (1ull << stop)) - 1ull)) != 0;   // a short row in [p0, stop)
+        const u32 lit = (f0 >> 1) & 255u;
+        const u64 tr0_ = PROF ? (u64)__builtin_readcyclecounter() : 0ull;
+        typedef __attribute__((address_space(3))) const d5_u32x2* lds_u2p;
+        const u32 rk_lane = (u32)(size_t)(__attribute__((address_space(3))) void*)s_rk + 8u * (lane + D5_RK0 - 1u);
+        auto row = [&](u32 sj, u32 a, u32 src1) {
+          d5_u32x2 e5[5];
 #pragma unroll
-            for (int s = 0; s < 5; ++s) e5[s] = *(lds_u2p)(a + 512u * (u32)s);
+          for (int s = 0; s < 5; ++s) e5[s] = *(lds_u2p)(a + 512u * (u32)s);
 #pragma unroll
-            for (int s = 0; s < 5; ++s) {
-              const u32 t_ = sj + e5[s].x, th_ = sj + e5[s].y;
-              const u32 cb = __float_as_uint(c[s]);
-              l[s] = th_ < cb ? src1 : l[s];
-              c[s] = __uint_as_float(cb < t_ ? cb : t_);
-            }
-          };
-          u32 p = skip;
-          float c_sv[5];
-          u32 l_sv[5];
-          if (cut_e) {
+          for (int s = 0; s < 5; ++s) {
+            const u32 t_ = sj + e5[s].x, th_ = sj + e5[s].y;
+            const u32 cb = __float_as_uint(c[s]);
+            l[s] = th_ < cb ? src1 : l[s];
+            c[s] = __uint_as_float(cb < t_ ? cb : t_);
+          }
+        };
+        u32 p = p0;
+        float c_sv[5];
+        u32 l_sv[5];
+        if (cut_e) {
 #pragma unroll
-            for (int s = 0; s < 5; ++s) { c_sv[s] = c[s]; l_sv[s] = l[s]; }
-          }
-          // Room for the whole window at once?  Every cell of it reached and inside the table's binade with the largest
-          // weight to spare: cells only go down, and not below the smallest of them plus a weight, so every source of the
-          // window passes the test the loop below makes per position — which then is not in the chain any more (a scalar
-          // compare and branch between dependent vector instructions: half of a position's time).
-          bool roomy = false;
-          {
-            const u32 cb0 = __float_as_uint(c[0]);
-            const u32 s0 = rdlane_u32(cb0, skip);
-            if (s0 >= 0x41800000u && s0 < 0x4f000000u) {
-              if ((s0 & 0x7f800000u) != r1_lo || lit != r1_lit) r1_build(s0, lit);
-              if (r1_lo != 0) {
-                const bool inw = lane >= skip && lane < stop;
-                const u32 mx = d5_max64(inw ? cb0 : 0u), mn = d5_min64(inw ? cb0 : 0xffffffffu);
-                roomy = mn >= r1_lo && mx + r1_rmax < r1_lo + 0x800000u;
-              }
-            }
-          }
-          if (roomy && skip == 0 && stop == 32u && !cut_e) {
-#pragma unroll
-            for (u32 q = 0; q < 32u; ++q) row(rdlane_u32(__float_as_uint(c[0]), q), rk_lane - 8u * q, wbase + q + 1u);
-            p = 32u;
-            if (PROF) { gr[0] += 32; gt[1] += (u64)__builtin_readcyclecounter() - tr0_ + (u64)(__float_as_uint(c[0]) & 0u); }
-          } else if (roomy) {
-            if (PROF) gr[1] += stop - skip;
-            u32 a0 = rk_lane - 8u * skip;
-            for (; p < stop; ++p, a0 -= 8u) row(rdlane_u32(__float_as_uint(c[0]), p), a0, wbase + p + 1u);
-          } else {
-            u32 a0 = rk_lane - 8u * skip;
-            for (; p < stop; ++p, a0 -= 8u) {
-              const u32 sj = rdlane_u32(__float_as_uint(c[0]), p);
-              if (sj < 0x41800000u || sj >= 0x4f000000u) break;                       // (2^4 .. 2^31)
-              if ((sj & 0x7f800000u) != r1_lo || lit != r1_lit) r1_build(sj, lit);
-              if (r1_lo == 0 || sj + r1_rmax >= r1_lo + 0x800000u) break;
-              row(sj, a0, wbase + p + 1u);
-              if (PROF) ++gr[2];
-            }
-          }
-          if (cut_e) {
-#pragma unroll
-            for (int s = 0; s < 5; ++s) {
-              const bool beyond = 64u * (u32)s + lane > e_rel;
-              c[s] = beyond ? c_sv[s] : c[s];
-              l[s] = beyond ? l_sv[s] : l[s];
-            }
-          }
-          if (PROF && !(roomy && skip == 0 && stop == 32u && !cut_e)) gt[2] += (u64)__builtin_readcyclecounter() - tr0_ + (u64)(__float_as_uint(c[0]) & 0u);
-          if (p > skip) {
-            const u32 far_ = ZMX_MAX_MATCH + p - 1u < e_rel ? ZMX_MAX_MATCH + p - 1u : e_rel;
-            reach = reach > far_ ? reach : far_;
-            noshort = false;
-            n_slow += p - skip;
-            if (PROF) n_int += p - skip;
-            if (fine_) { gq[2] += (u64)__builtin_readcyclecounter() - tr0_ + (u64)(__float_as_uint(c[0]) & 0u); gq[3] += p - skip; }
-          }
-          p_first = p;
+          for (int s = 0; s < 5; ++s) { c_sv[s] = c[s]; l_sv[s] = l[s]; }
         }
-      }
+        // Room for the whole stretch at once?  Every cell of it reached and inside the table's binade with the largest
+        // weight to spare: cells only go down, and not below the smallest of them plus a weight, so every source of the
+        // stretch passes the test the last loop below makes per position — which then is not in the chain any more (a
+        // scalar compare and branch between dependent vector instructions: half of a position's time).
+        bool roomy = false;
+        {
+          const u32 cb0 = __float_as_uint(c[0]);
+          const u32 s0 = rdlane_u32(cb0, p0);
+          if (s0 >= 0x41800000u && s0 < 0x4f000000u) {
+            if ((s0 & 0x7f800000u) != r1_lo || lit != r1_lit) r1_build(s0, lit);
+            if (r1_lo != 0) {
+              const bool inw = lane >= p0 && lane < stop;
+              const u32 mx = d5_max64(inw ? cb0 : 0u), mn = d5_min64(inw ? cb0 : 0xffffffffu);
+              roomy = mn >= r1_lo && mx + r1_rmax < r1_lo + 0x800000u;
+            }
+          }
+        }
+        const bool whole = roomy && p0 == 0 && stop == 32u && !cut_e;
+        if (whole) {
+#pragma unroll
+          for (u32 q = 0; q < 32u; ++q) row(rdlane_u32(__float_as_uint(c[0]), q), rk_lane - 8u * q, wbase + q + 1u);
+          p = 32u;
+          if (PROF) { gr[0] += 32; gt[1] += (u64)__builtin_readcyclecounter() - tr0_ + (u64)(__float_as_uint(c[0]) & 0u); }
+        } else if (roomy) {
+          if (PROF) gr[1] += stop - p0;
+          u32 a0 = rk_lane - 8u * p0;
+          for (; p < stop; ++p, a0 -= 8u) row(rdlane_u32(__float_as_uint(c[0]), p), a0, wbase + p + 1u);
+        } else {
+          u32 a0 = rk_lane - 8u * p0;
+          for (; p < stop; ++p, a0 -= 8u) {
+            const u32 sj = rdlane_u32(__float_as_uint(c[0]), p);
+            if (sj < 0x41800000u || sj >= 0x4f000000u) break;                       // (2^4 .. 2^31)
+            if ((sj & 0x7f800000u) != r1_lo || lit != r1_lit) r1_build(sj, lit);
+            if (r1_lo == 0 || sj + r1_rmax >= r1_lo + 0x800000u) break;
+            row(sj, a0, wbase + p + 1u);
+            if (PROF) ++gr[2];
+          }
+        }
+        if (cut_e) {
+#pragma unroll
+          for (int s = 0; s < 5; ++s) {
+            const bool beyond = 64u * (u32)s + lane > e_rel;
+            c[s] = beyond ? c_sv[s] : c[s];
+            l[s] = beyond ? l_sv[s] : l[s];
+          }
+        }
+        if (PROF && !whole) gt[2] += (u64)__builtin_readcyclecounter() - tr0_ + (u64)(__float_as_uint(c[0]) & 0u);
+        if (p > p0) {
+          const u32 far_ = ZMX_MAX_MATCH + p - 1u < e_rel ? ZMX_MAX_MATCH + p - 1u : e_rel;
+          reach = reach > far_ ? reach : far_;
+          noshort = false;
+          n_slow += p - p0;
+          if (PROF) n_int += p - p0;
+        }
+        return p;
+      };
       const u64 tg0_ = PROF ? (u64)__builtin_readcyclecounter() : 0ull;
-      for (u32 p = p_first; p < W.nav; ++p) {
+      for (u32 p = skip; p < W.nav;) {
+        if (RUNS && ((W.ms >> p) & 1ull) == 0 && ((W.mb >> p) & 1ull) == 0) {
+          // (a window is cut into stretches of one kind; what is left for the step below: shortcuts, rows with an edge
+          //  below mincost, run rows outside the integer table's reach)
+          if ((rdlane_u32(W.fl, p) & 1u) == 0) { p = other_stretch(p); continue; }
+          if (P.int_path != 0) {
+            const u32 q = run_stretch(p);
+            if (q > p) { p = q; continue; }
+          }
+        }
         const u32 j = wbase + p;
         const u64 tp0_ = fine_ ? (u64)__builtin_readcyclecounter() : 0ull;
         u32 gk_ = 6;
@@ -990,6 +1000,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
         noshort = false;
         ++n_slow;
         if (fine_) { gq[gk_] += (u64)__builtin_readcyclecounter() - tp0_ + (u64)(__float_as_uint(c[0]) & 0u); ++gq[gk_ + 1]; }
+        ++p;
       }
       if (PROF) gt[3] += (u64)__builtin_readcyclecounter() - tg0_ + (u64)(__float_as_uint(c[0]) & 0u);
     }

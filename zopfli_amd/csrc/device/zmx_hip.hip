@@ -1476,9 +1476,11 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
                  a[32] / (a[33] + 1e-9), a[33], a[34] / (a[35] + 1e-9), a[35], a[36] / (a[37] + 1e-9), a[37], a[38] / (a[39] + 1e-9), a[39], a[40] / (a[41] + 1e-9), a[41]);
     std::fprintf(stderr, "  k_dp5_spec positions: run interior %.0f in unrolled windows, %.0f in loops with room, %.0f with checks; general step: %.0f run rows, %.0f other rows; class 2: %.0f rows that reach register 2\n",
                  a[42], a[43], a[44], a[45], a[46], a[47]);
-    std::fprintf(stderr, "  k_dp5_spec generic windows, cycles: headers %.3g, run interior unrolled %.3g (%.0f per position), in loops %.3g (%.0f), the general step %.3g (%.0f per position incl. shortcuts)\n",
-                 a[48], a[49], a[49] / (a[42] + 1e-9), a[50], a[50] / (a[43] + a[44] + 1e-9), a[51], a[51] / (a[45] + a[46] + a[33] + 1e-9));
-    std::fprintf(stderr, "  k_dp5_spec whole windows of other rows: %.0f positions at %.0f cycles each\n", a[53], a[52] / (a[53] + 1e-9));
+    {
+      const double gen = a[51] - a[49] - a[50] - a[52];     // (the loop over a window's positions, less its stretches)
+      std::fprintf(stderr, "  k_dp5_spec generic windows, cycles: headers %.3g, run stretches: whole windows %.3g (%.0f per position), others %.3g (%.0f); stretches of other rows %.3g (%.0f); the general step %.3g (%.0f per position incl. shortcuts)\n",
+                   a[48], a[49], a[49] / (a[42] + 1e-9), a[50], a[50] / (a[43] + a[44] + 1e-9), a[52], a[52] / (a[53] + 1e-9), gen, gen / (a[45] + a[46] + a[33] + 1e-9));
+    }
     const char* nm[5] = {"32", "16", "8", "8 (two registers)", "generic"};
     for (int i = 0; i < 5; ++i)
       std::fprintf(stderr, "  path %-18s %5.1f%% of positions, %6.1f cycles/position\n", nm[i], 100.0 * a[6 + 2 * i] / a[4],

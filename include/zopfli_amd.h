@@ -131,6 +131,12 @@ int zmx_set_input(zmx_ctx* ctx, const unsigned char* in, size_t insize);
  * hash replay + longest-match cache (cache.c) of the reference. */
 int zmx_tables_build(zmx_ctx* ctx, const zmx_block* blocks, size_t nblocks, zmx_tables** tables);
 
+/* The same without what only zmx_squeeze_run reads (the DP rows and their weight codes: two bytes for each of the up to
+ * 258 edges of a position): for zmx_lz77_greedy, zmx_store_download / zmx_verify of its store, and as `parent` of
+ * zmx_tables_build_from — the greedy pass over a master block that is about to be split (blocksplitter.c:296).
+ * zmx_squeeze_run on such tables fails. */
+int zmx_tables_build_matches(zmx_ctx* ctx, const zmx_block* blocks, size_t nblocks, zmx_tables** tables);
+
 /* The same, for blocks that lie inside blocks of `parent` (both lists ascending), e.g. the deflate
  * blocks a master block was split into (deflate.c:854-869) after the greedy pass over the master
  * block (blocksplitter.c:296): ZopfliFindLongestMatch depends on the block only through its end

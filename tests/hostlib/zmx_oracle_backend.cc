@@ -89,6 +89,10 @@ int zmx_tables_build(zmx_ctx* ctx, const zmx_block* blocks, size_t nblocks, zmx_
   return 0;
 }
 
+int zmx_tables_build_matches(zmx_ctx* ctx, const zmx_block* blocks, size_t nblocks, zmx_tables** tables) {
+  return zmx_tables_build(ctx, blocks, nblocks, tables);
+}
+
 int zmx_tables_build_from(zmx_ctx* ctx, zmx_tables*, const zmx_block* blocks, size_t nblocks, zmx_tables** tables) {
   return zmx_tables_build(ctx, blocks, nblocks, tables);
 }

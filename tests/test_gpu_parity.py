@@ -182,14 +182,16 @@ REUSE_CASES = [
 ]
 
 
+@pytest.mark.parametrize("matches_only", [True, False], ids=["parent_matches_only", "parent_full"])
 @pytest.mark.parametrize("case", REUSE_CASES, ids=lambda c: f"{c[0]}{c[1]}x{len(c[3])}")
-def test_match_table_reuse(gpu_ctx, case):
+def test_match_table_reuse(gpu_ctx, case, matches_only):
     """zmx_tables_build_from (records copied from the enclosing blocks' tables, tiles near the new
-    block ends recomputed) == ZopfliFindLongestMatch at every position of every sub-block."""
+    block ends recomputed) == ZopfliFindLongestMatch at every position of every sub-block.  The parent as the
+    library builds it for the greedy pass over master blocks (zmx_tables_build_matches), and as full tables."""
     cls, n, parents, blocks = case
     data = generate(cls, n)
     gpu_ctx.set_input(data)
-    pt = gpu_ctx.build_tables(parents)
+    pt = gpu_ctx.build_tables(parents, matches_only=matches_only)
     t = gpu_ctx.build_tables(blocks, parent=pt)
     pt.free()
     try:
@@ -211,13 +213,28 @@ def test_match_table_reuse(gpu_ctx, case):
         t.free()
 
 
+def test_matches_only_tables_refuse_the_squeeze(gpu_ctx):
+    """zmx_tables_build_matches: greedy works, zmx_squeeze_run fails with a message (no DP rows were built)."""
+    data = generate("T", 40000)
+    gpu_ctx.set_input(data)
+    t = gpu_ctx.build_tables([(0, len(data))], matches_only=True)
+    try:
+        nsym, _ = t.greedy(0)
+        assert nsym[0] == len(ol.OracleTable(data, 0, len(data)).greedy()[0])
+        with pytest.raises(Exception, match="matches only"):
+            t.squeeze_run(np.ones((1, 320)) * 8.0, np.array([8.0]), [1])
+    finally:
+        t.free()
+
+
+@pytest.mark.parametrize("matches_only", [False, True], ids=["full", "matches_only"])
 @pytest.mark.parametrize("case", TABLE_CASES, ids=_ids)
-def test_greedy(gpu_ctx, case):
+def test_greedy(gpu_ctx, case, matches_only):
     """k_greedy == ZopfliLZ77Greedy (lz77.c:544) + its histogram."""
     cls, n, blocks = case
     data = generate(cls, n)
     gpu_ctx.set_input(data)
-    t = gpu_ctx.build_tables(blocks)
+    t = gpu_ctx.build_tables(blocks, matches_only=matches_only)
     try:
         nsym, hist = t.greedy(0)
         for b, (s, e) in enumerate(blocks):

@@ -78,6 +78,7 @@ def bind(lib):
     lib.zmx_ctx_destroy.restype = None
     lib.zmx_set_input.argtypes = [vp, ctypes.c_char_p, sz]
     lib.zmx_tables_build.argtypes = [vp, P(ZmxBlock), sz, P(vp)]
+    lib.zmx_tables_build_matches.argtypes = [vp, P(ZmxBlock), sz, P(vp)]
     lib.zmx_tables_build_from.argtypes = [vp, vp, P(ZmxBlock), sz, P(vp)]
     lib.zmx_tables_free.argtypes = [vp, vp]
     lib.zmx_tables_free.restype = None
@@ -208,11 +209,15 @@ class Context:
         self._input = data
         self._check(self.lib.zmx_set_input(self.handle, data, len(data)), "zmx_set_input")
 
-    def build_tables(self, blocks, parent=None):
-        """zmx_tables_build, or zmx_tables_build_from when `parent` (Tables over enclosing blocks) is given."""
+    def build_tables(self, blocks, parent=None, matches_only=False):
+        """zmx_tables_build, zmx_tables_build_matches (no DP rows: for the greedy pass and as a parent), or
+        zmx_tables_build_from when `parent` (Tables over enclosing blocks) is given."""
         arr = (ZmxBlock * len(blocks))(*[ZmxBlock(s, e) for s, e in blocks])
         t = ctypes.c_void_p()
-        if parent is None:
+        if matches_only:
+            self._check(self.lib.zmx_tables_build_matches(self.handle, arr, len(blocks), ctypes.byref(t)),
+                        "zmx_tables_build_matches")
+        elif parent is None:
             self._check(self.lib.zmx_tables_build(self.handle, arr, len(blocks), ctypes.byref(t)), "zmx_tables_build")
         else:
             self._check(self.lib.zmx_tables_build_from(self.handle, parent.handle, arr, len(blocks), ctypes.byref(t)),

@@ -145,6 +145,7 @@ struct zmx_tables {
   u32* d_chunk_base = nullptr;
   std::vector<u32> chunk_base;    // [nb + 1] first chunk of each block
   size_t merged_tasks = 0;        // tasks merged into their predecessors (BuildTables): the set has long tasks
+  bool matches_only = false;      // built by zmx_tables_build_matches: no DP rows, codes, windows or tasks
   bool buckets = false;           // the hash arrays are k_bucket's (k_match3), not k_chain's links (k_match2)
   u32* d_recs = nullptr;
   u32* d_pool = nullptr;
@@ -561,7 +562,8 @@ static unsigned SegHead(size_t nb) {
 }
 static unsigned SegWarm() { static const unsigned v = (EnvU32("ZOPFLI_AMD_SEG_WARM", 512, 64, 1u << 20) + 63u) & ~63u; return v; }
 
-static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_tables* t, zmx_tables* parent = nullptr) {
+static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_tables* t, zmx_tables* parent = nullptr, bool with_dp = true) {
+  t->matches_only = !with_dp;
   t->nb = nb;
   t->blocks.resize(nb);
   t->bsize.resize(nb);
@@ -883,6 +885,10 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     }
   }
 
+  // (zmx_tables_build_matches: the greedy pass over master blocks that will be split wants the matches only; the codes
+  //  of its DP edges — two bytes for each of up to 258 edges a position, 52 GB for 100 MB of long runs — would be
+  //  written, never read, and held while the tables of the split blocks allocate their own)
+  if (with_dp) {
   // DP row layout (k_rowscan), then the edges as weight codes (k_codes) and a buffer descriptor per row
   RowScanParams rp;
   rp.blocks = t->d_blocks;
@@ -1095,6 +1101,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     if (!wg.empty()) HIPCHK(hipMemcpyAsync(t->d_wg_tasks, wg.data(), wg.size() * sizeof(u32), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));   // `wg` is a local
   }
+  }  // with_dp
   // trace segments (zmx_trace.h)
   t->seg_off.assign(nb + 1, 0);
   for (size_t b = 0; b < nb; ++b) t->seg_off[b + 1] = t->seg_off[b] + (t->bsize[b] + TS_SEG - 1) / TS_SEG;
@@ -1108,6 +1115,19 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
 
 int zmx_tables_build(zmx_ctx* c, const zmx_block* blocks, size_t nblocks, zmx_tables** out) {
   return zmx_tables_build_from(c, nullptr, blocks, nblocks, out);
+}
+
+int zmx_tables_build_matches(zmx_ctx* c, const zmx_block* blocks, size_t nblocks, zmx_tables** out) {
+  DeviceGuard dev_guard(c->device);
+  HIPCHK(dev_guard.err);
+  zmx_tables* t = new zmx_tables();
+  const int rc = BuildTables(c, blocks, nblocks, t, nullptr, false);
+  if (rc) {
+    zmx_tables_free(c, t);
+    return rc;
+  }
+  *out = t;
+  return 0;
 }
 
 int zmx_tables_build_from(zmx_ctx* c, zmx_tables* parent, const zmx_block* blocks, size_t nblocks, zmx_tables** out) {
@@ -1231,6 +1251,7 @@ __attribute__((visibility("default"))) void zmx_internal_run_info(const double* 
 int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double* mincost, const int32_t* slot,
                     uint32_t* nsym, uint32_t* hist) {
   if (t->nb == 0) return 0;
+  if (t->matches_only) return FailMsg("zmx_squeeze_run: these tables hold matches only (zmx_tables_build_matches)");
   DeviceGuard dev_guard(c->device);
   HIPCHK(dev_guard.err);
   for (size_t b = 0; b < t->nb; ++b) {

@@ -151,7 +151,7 @@ int Lz77GreedyBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks, std::vec
   if (nb == 0) return 0;
   zmx_tables* t = nullptr;
   double t0 = Now();
-  int rc = zmx_tables_build(ctx, blocks.data(), nb, &t);
+  int rc = zmx_tables_build_matches(ctx, blocks.data(), nb, &t);   // (nobody runs the squeeze on these blocks)
   if (rc) return rc;
   double t1 = Now();
   ThreadTiming().tables += t1 - t0;

@@ -17,9 +17,13 @@
 //   class 2  longer rows, no flags: two buffer_load_ushort per row (lanes 0..127 of the row), the range
 //            check of a per-row buffer descriptor dropping the lanes outside it; the few rows that reach
 //            further fetch the rest on demand.
+//   class 3  class 2 with rows that reach beyond cell register 1 (k_mkdesc): class 2 for the text variant of the
+//            job; the run variant takes it as class 0 — stretches of other rows, below.
 //   class 0  everything else, position by position with the reference's tests literally: long-run shortcut
 //            positions (squeeze.c:251-271), edges below mincost (:293), ragged tails — and runs of equal
-//            bytes, for which the RUNS variant of the job (below) has table-driven rows and staged codes.
+//            bytes, for which the RUNS variant of the job cuts a window into STRETCHES of one kind: run rows
+//            (one table by length for the wave's binade, whole windows as straight-line code) and other rows
+//            (codes from a ring of two regions kept ahead by LDS-DMA); DESIGN.md section 4, "Long runs".
 //
 // (The first version fetched every row through a buffer descriptor per position: the CU's address unit is
 // busy 16 cycles per wave-wide load whatever the lanes do — DESIGN.md section 4 has the history.)

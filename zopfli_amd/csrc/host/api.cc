@@ -277,6 +277,8 @@ int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char
       hits += k == 64;
     }
     runs = probes > 0 && hits * 100 >= probes;
+    static const bool split_runs = [] { const char* e = std::getenv("ZOPFLI_AMD_SPLIT_RUNS"); return e && std::atoi(e) != 0; }();
+    if (split_runs) runs = false;      // (ZOPFLI_AMD_SPLIT_RUNS=1: deal such data over two contexts all the same — for measuring)
   }
   const Lease lease(parts.size(), split_from && parts.size() >= split_from && !runs ? split_ways : 1);
   const std::vector<zmx_ctx*>& ctxs = lease.ctxs;

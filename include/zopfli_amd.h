@@ -41,7 +41,7 @@ extern "C" {
  * Devices and threads.  The Zopfli* functions run on ONE device unless told otherwise: ZOPFLI_AMD_DEVICE,
  * else LOCAL_RANK, else device 0; ZOPFLI_AMD_DEVICES = "all" | a count | a list of indices deals the master
  * blocks of a call over several.  They may be called from several threads at once (as the reference's may):
- * a device has ZOPFLI_AMD_LANES contexts (default 2), a call takes what it needs and later callers wait. */
+ * a device has ZOPFLI_AMD_LANES contexts (default 3), a call takes what it needs and later callers wait. */
 
 /* ------------------------------------------------------------------ Part 1 */
 
@@ -146,6 +146,11 @@ int zmx_tables_build_matches(zmx_ctx* ctx, const zmx_block* blocks, size_t nbloc
 int zmx_tables_build_from(zmx_ctx* ctx, zmx_tables* parent, const zmx_block* blocks, size_t nblocks,
                           zmx_tables** tables);
 void zmx_tables_free(zmx_ctx* ctx, zmx_tables* tables);
+
+/* Gives back everything of a table set but its two LZ77 stores: afterwards only zmx_store_download*, zmx_encode_blocks
+ * and zmx_tables_free work on it (the others fail with a message).  For the caller that keeps the tables of a finished
+ * batch around for the device's bit writer while it builds the next ones (deflate.c:760: the fixed-tree re-parses). */
+int zmx_tables_trim(zmx_ctx* ctx, zmx_tables* tables);
 
 /* ZopfliLZ77Greedy (lz77.c:544-630) on every block, into store slot `slot`
  * (0 or 1).  nsym[b] = symbols emitted, hist[b*ZMX_HIST..] = their histogram

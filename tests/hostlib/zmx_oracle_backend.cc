@@ -89,6 +89,8 @@ int zmx_tables_build(zmx_ctx* ctx, const zmx_block* blocks, size_t nblocks, zmx_
   return 0;
 }
 
+int zmx_tables_trim(zmx_ctx*, zmx_tables*) { return 0; }
+
 int zmx_tables_build_matches(zmx_ctx* ctx, const zmx_block* blocks, size_t nblocks, zmx_tables** tables) {
   return zmx_tables_build(ctx, blocks, nblocks, tables);
 }

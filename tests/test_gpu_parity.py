@@ -227,6 +227,29 @@ def test_matches_only_tables_refuse_the_squeeze(gpu_ctx):
         t.free()
 
 
+def test_trimmed_tables_keep_their_stores(gpu_ctx):
+    """zmx_tables_trim: the stores can still be downloaded, everything else fails with a message."""
+    data = generate("X", 60000)
+    blocks = [(0, 30000), (30000, 60000)]
+    gpu_ctx.set_input(data)
+    t = gpu_ctx.build_tables(blocks)
+    try:
+        nsym, _ = t.greedy(1)
+        before = [t.store(b, 1, nsym[b]) for b in range(2)]
+        t.trim()
+        for b in range(2):
+            ll, dd = t.store(b, 1, nsym[b])
+            assert np.array_equal(ll, before[b][0]) and np.array_equal(dd, before[b][1])
+            oll, odd = ol.OracleTable(data, *blocks[b]).greedy()
+            assert np.array_equal(ll, oll) and np.array_equal(dd, odd)
+        with pytest.raises(Exception, match="trimmed"):
+            t.greedy(0)
+        with pytest.raises(Exception, match="trimmed"):
+            t.squeeze_run(np.ones((2, 320)) * 8.0, np.array([8.0, 8.0]), [0, 0])
+    finally:
+        t.free()
+
+
 @pytest.mark.parametrize("matches_only", [False, True], ids=["full", "matches_only"])
 @pytest.mark.parametrize("case", TABLE_CASES, ids=_ids)
 def test_greedy(gpu_ctx, case, matches_only):

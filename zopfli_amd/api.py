@@ -81,6 +81,7 @@ def bind(lib):
     lib.zmx_tables_build_matches.argtypes = [vp, P(ZmxBlock), sz, P(vp)]
     lib.zmx_tables_build_from.argtypes = [vp, vp, P(ZmxBlock), sz, P(vp)]
     lib.zmx_tables_free.argtypes = [vp, vp]
+    lib.zmx_tables_trim.argtypes = [vp, vp]
     lib.zmx_tables_free.restype = None
     lib.zmx_lz77_greedy.argtypes = [vp, vp, ctypes.c_int, P(ctypes.c_uint32), P(ctypes.c_uint32)]
     lib.zmx_squeeze_run.argtypes = [vp, vp, P(ctypes.c_double), P(ctypes.c_double), P(ctypes.c_int32),
@@ -322,6 +323,10 @@ class Tables:
         if self.handle:
             self.ctx.lib.zmx_tables_free(self.ctx.handle, self.handle)
             self.handle = None
+
+    def trim(self):
+        """zmx_tables_trim: everything but the two stores goes back to the pool."""
+        self.ctx._check(self.ctx.lib.zmx_tables_trim(self.ctx.handle, self.handle), "zmx_tables_trim")
 
     def greedy(self, slot=0):
         import numpy as np

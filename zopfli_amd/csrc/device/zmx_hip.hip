@@ -146,6 +146,7 @@ struct zmx_tables {
   std::vector<u32> chunk_base;    // [nb + 1] first chunk of each block
   size_t merged_tasks = 0;        // tasks merged into their predecessors (BuildTables): the set has long tasks
   bool matches_only = false;      // built by zmx_tables_build_matches: no DP rows, codes, windows or tasks
+  bool trimmed = false;           // zmx_tables_trim: only the stores are left
   bool buckets = false;           // the hash arrays are k_bucket's (k_match3), not k_chain's links (k_match2)
   u32* d_recs = nullptr;
   u32* d_pool = nullptr;
@@ -474,52 +475,73 @@ int zmx_set_input(zmx_ctx* c, const unsigned char* in, size_t insize) {
   return 0;
 }
 
+// Gives back the device arrays of a table set — all of them, or all but the two LZ77 stores (zmx_tables_trim).
+static void ReleaseTableArrays(zmx_ctx* c, zmx_tables* t, bool keep_stores) {
+  auto rel = [&](auto*& p) { PoolFree(c, p); p = nullptr; };
+  rel(t->d_blocks);
+  rel(t->d_tile_off);
+  rel(t->d_same16);
+  rel(t->d_links);
+  rel(t->d_sorted_alloc);
+  rel(t->d_ssame);
+  rel(t->d_chunk_base);
+  rel(t->d_recs);
+  rel(t->d_pool);
+  rel(t->d_la);
+  rel(t->d_dph);
+  rel(t->d_block_edges);
+  rel(t->d_badpos);
+  rel(t->d_code_base);
+  rel(t->d_codes);
+  rel(t->d_wtab);
+  rel(t->d_badcodes);
+  rel(t->d_seg_off);
+  rel(t->d_extab);
+  rel(t->d_seginfo);
+  rel(t->d_counters);
+  rel(t->d_prof);
+  rel(t->d_tasks);
+  rel(t->d_task_off);
+  rel(t->d_wg_tasks);
+  rel(t->d_wmeta);
+  rel(t->d_runin);
+  rel(t->d_runout);
+  rel(t->d_winroff);
+  rel(t->d_winflag);
+  rel(t->d_win_off);
+  rel(t->d_lvl);
+  rel(t->d_entry);
+  rel(t->d_exit);
+  rel(t->d_chk);
+  rel(t->d_over);
+  rel(t->d_redo);
+  for (int h = 0; h < 2; ++h) { rel(t->d_rank[h]); rel(t->d_bucket[h]); }
+  t->d_sorted[0] = t->d_sorted[1] = nullptr;
+  if (t->h_runin) { (void)hipHostFree(t->h_runin); t->h_runin = nullptr; }
+  if (t->h_runout) { (void)hipHostFree(t->h_runout); t->h_runout = nullptr; }
+  if (!keep_stores) { rel(t->d_store[0]); rel(t->d_store[1]); }
+}
+
 void zmx_tables_free(zmx_ctx* c, zmx_tables* t) {
   if (!t) return;
   DeviceGuard dev_guard(c ? c->device : 0);
-  PoolFree(c, t->d_blocks);
-  PoolFree(c, t->d_tile_off);
-  PoolFree(c, t->d_same16);
-  PoolFree(c, t->d_links);
-  PoolFree(c, t->d_sorted_alloc);
-  for (int h = 0; h < 2; ++h) { PoolFree(c, t->d_rank[h]); PoolFree(c, t->d_bucket[h]); }
-  PoolFree(c, t->d_ssame);
-  PoolFree(c, t->d_chunk_base);
-  PoolFree(c, t->d_recs);
-  PoolFree(c, t->d_pool);
-  PoolFree(c, t->d_la);
-  PoolFree(c, t->d_store[0]);
-  PoolFree(c, t->d_store[1]);
-  PoolFree(c, t->d_dph);
-  PoolFree(c, t->d_block_edges);
-  PoolFree(c, t->d_badpos);
-  PoolFree(c, t->d_code_base);
-  PoolFree(c, t->d_codes);
-  PoolFree(c, t->d_wtab);
-  PoolFree(c, t->d_badcodes);
-  PoolFree(c, t->d_seg_off);
-  PoolFree(c, t->d_extab);
-  PoolFree(c, t->d_seginfo);
-  PoolFree(c, t->d_counters);
-  PoolFree(c, t->d_prof);
-  PoolFree(c, t->d_tasks);
-  PoolFree(c, t->d_task_off);
-  PoolFree(c, t->d_wg_tasks);
-  PoolFree(c, t->d_wmeta);
-  PoolFree(c, t->d_runin);
-  PoolFree(c, t->d_runout);
-  if (t->h_runin) (void)hipHostFree(t->h_runin);
-  if (t->h_runout) (void)hipHostFree(t->h_runout);
-  PoolFree(c, t->d_winroff);
-  PoolFree(c, t->d_winflag);
-  PoolFree(c, t->d_win_off);
-  PoolFree(c, t->d_lvl);
-  PoolFree(c, t->d_entry);
-  PoolFree(c, t->d_exit);
-  PoolFree(c, t->d_chk);
-  PoolFree(c, t->d_over);
-  PoolFree(c, t->d_redo);
+  ReleaseTableArrays(c, t, false);
   delete t;
+}
+
+// What zmx_encode_blocks and zmx_store_download read of a table set are its two stores (and the host's notes on where
+// each block's symbols lie): everything else — 32 bytes of match record per position, the DP codes, window records, the
+// chain's snapshots — can go once the parses are final.  deflate.cc trims the tables of the optimal batch before it
+// builds the tables of the fixed-tree re-parses: on incompressible or short input, where most blocks ask for one, the
+// peak otherwise doubles.
+int zmx_tables_trim(zmx_ctx* c, zmx_tables* t) {
+  if (!t) return 0;
+  DeviceGuard dev_guard(c->device);
+  HIPCHK(dev_guard.err);
+  HIPCHK(hipStreamSynchronize(c->stream));      // (nothing of this table set may still be in flight)
+  ReleaseTableArrays(c, t, true);
+  t->trimmed = true;
+  return 0;
 }
 
 // `parent` (optional): a table set over blocks that contain the new ones.  The match record of a
@@ -1131,6 +1153,7 @@ int zmx_tables_build_matches(zmx_ctx* c, const zmx_block* blocks, size_t nblocks
 }
 
 int zmx_tables_build_from(zmx_ctx* c, zmx_tables* parent, const zmx_block* blocks, size_t nblocks, zmx_tables** out) {
+  if (parent && parent->trimmed) return FailMsg("zmx_tables_build_from: these tables were trimmed to their stores (zmx_tables_trim)");
   DeviceGuard dev_guard(c->device);
   HIPCHK(dev_guard.err);
   zmx_tables* t = new zmx_tables();
@@ -1144,6 +1167,7 @@ int zmx_tables_build_from(zmx_ctx* c, zmx_tables* parent, const zmx_block* block
 }
 
 int zmx_lz77_greedy(zmx_ctx* c, zmx_tables* t, int slot, uint32_t* nsym, uint32_t* hist) {
+  if (t && t->trimmed) return FailMsg("zmx_lz77_greedy: these tables were trimmed to their stores (zmx_tables_trim)");
   if (t->nb == 0) return 0;
   if (slot != 0 && slot != 1) return FailMsg("zmx_lz77_greedy: slot must be 0 or 1");
   DeviceGuard dev_guard(c->device);
@@ -1250,6 +1274,7 @@ __attribute__((visibility("default"))) void zmx_internal_run_info(const double* 
 
 int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double* mincost, const int32_t* slot,
                     uint32_t* nsym, uint32_t* hist) {
+  if (t && t->trimmed) return FailMsg("zmx_squeeze_run: these tables were trimmed to their stores (zmx_tables_trim)");
   if (t->nb == 0) return 0;
   if (t->matches_only) return FailMsg("zmx_squeeze_run: these tables hold matches only (zmx_tables_build_matches)");
   DeviceGuard dev_guard(c->device);
@@ -1574,6 +1599,7 @@ int zmx_store_download_batch(zmx_ctx* c, zmx_tables* t, size_t n, const size_t* 
 }
 
 int zmx_verify_stores(zmx_ctx* c, zmx_tables* t, size_t n, const size_t* block, const int32_t* slot, const size_t* nsym) {
+  if (t && t->trimmed) return FailMsg("zmx_verify_stores: these tables were trimmed to their stores (zmx_tables_trim)");
   if (n == 0) return 0;
   std::vector<VerifyJob> vj(n);
   for (size_t i = 0; i < n; ++i) {
@@ -1731,6 +1757,7 @@ int zmx_encode_blocks(zmx_ctx* c, zmx_tables* t, size_t njobs, const zmx_enc_job
 
 int zmx_find_longest_match(zmx_ctx* c, zmx_tables* t, size_t block, size_t pos, uint16_t* sublen,
                            uint16_t* distance, uint16_t* length) {
+  if (t && t->trimmed) return FailMsg("zmx_find_longest_match: these tables were trimmed to their stores (zmx_tables_trim)");
   if (block >= t->nb) return FailMsg("zmx_find_longest_match: bad block");
   const BlockDesc& d = t->blocks[block];
   if (pos < d.instart || pos >= d.inend) return FailMsg("zmx_find_longest_match: pos outside the block");
@@ -1775,6 +1802,7 @@ int zmx_find_longest_match(zmx_ctx* c, zmx_tables* t, size_t block, size_t pos, 
 }
 
 int zmx_hash_links_download(zmx_ctx* c, zmx_tables* t, size_t block, uint16_t* same, uint16_t* prev1, uint16_t* prev2) {
+  if (t && t->trimmed) return FailMsg("zmx_hash_links_download: these tables were trimmed to their stores (zmx_tables_trim)");
   if (block >= t->nb) return FailMsg("zmx_hash_links_download: bad block");
   DeviceGuard dev_guard(c->device);
   HIPCHK(dev_guard.err);
@@ -1834,6 +1862,7 @@ int zmx_hash_links_download(zmx_ctx* c, zmx_tables* t, size_t block, uint16_t* s
 }
 
 int zmx_length_array_download(zmx_ctx* c, zmx_tables* t, size_t block, uint16_t* out) {
+  if (t && t->trimmed) return FailMsg("zmx_length_array_download: these tables were trimmed to their stores (zmx_tables_trim)");
   if (block >= t->nb) return FailMsg("zmx_length_array_download: bad block");
   DeviceGuard dev_guard(c->device);
   HIPCHK(dev_guard.err);

@@ -66,9 +66,9 @@ void MaybeKeepHeap() {
 // blocks are independent (deflate.c:916-923), so a request with several of them is dealt across those devices.
 //
 // Re-entrancy (the reference has no globals: callers may run concurrent calls on distinct buffers): a
-// device has up to ZOPFLI_AMD_LANES contexts (default 2), created when first needed; a request takes one free
-// context on each device it uses and gives them back when it is done, so two callers overlap — one's host phases
-// (cost models, block splitting, merging) with the other's kernels — and a third waits.  A device whose context
+// device has up to ZOPFLI_AMD_LANES contexts (default 3), created when first needed; a request takes one free
+// context on each device it uses and gives them back when it is done, so callers overlap — one's host phases
+// (cost models, block splitting, merging) with the others' kernels — and a fourth waits.  A device whose context
 // cannot be created (not gfx950, out of memory) is dropped from the list; only when none is left does the call die.
 class ContextPool {
  public:
@@ -178,7 +178,7 @@ class ContextPool {
   std::mutex mu_;
   std::condition_variable cv_;
   std::vector<Device> devices_;
-  size_t lanes_ = 2;
+  size_t lanes_ = 3;
 };
 
 ContextPool& Pool() {
@@ -252,7 +252,8 @@ struct ChecksumRequest {
 int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char* in,
                     const std::vector<zamd::Part>& parts, std::vector<zamd::Chunk>* chunks,
                     ChecksumRequest* sum = nullptr) {
-  // (ZOPFLI_AMD_SPLIT_MB: from this many master blocks on, a request is dealt over two contexts of each device;
+  // (ZOPFLI_AMD_SPLIT_MB: from this many master blocks on, a request is dealt over ZOPFLI_AMD_SPLIT_WAYS = 3 contexts of
+  //  each device — measured on 100 MB of text: 2 ways 123.2 ms, 3 ways 121.1, 4 ways 140; with block splitting 225 / 197 / 231;
   //  0 = never.  The GPU idles while the host computes a hundred cost models between two squeeze runs — 6 % of a
   //  100 MB call — and through the whole block-split search; two halves fill each other's gaps.)
   static const size_t split_from = [] {
@@ -261,7 +262,7 @@ int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char
   }();
   static const size_t split_ways = [] {
     const char* e = std::getenv("ZOPFLI_AMD_SPLIT_WAYS");
-    return e ? static_cast<size_t>(std::max(1, std::atoi(e))) : static_cast<size_t>(2);
+    return e ? static_cast<size_t>(std::max(1, std::atoi(e))) : static_cast<size_t>(3);
   }();
   // Not on data with long runs of equal bytes: there the squeeze runs wait for a few very long single-wave tasks
   // (zmx_dp5.h), and a second context's tasks on the same SIMDs slow exactly those (class Z: 61 -> 35 MB/s).  Sampled:

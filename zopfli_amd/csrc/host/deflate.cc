@@ -261,6 +261,12 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
   //  their bits — where the fixed tree wins — from zmx_encode_blocks.  Incompressible input asks for a re-parse of
   //  every block: downloading those stores and indexing them on the host was most of what such input cost.)
   std::vector<SymbolRun> fixed_runs;
+  // (the tables of the optimal batch are only wanted for their stores from here on: the bit writer reads them.  Records,
+  //  codes, window records and snapshots go back to the pool before the fixed-tree batch builds its own)
+  if (keep.tables) {
+    rc = zmx_tables_trim(ctx, keep.tables);
+    if (rc) return rc;
+  }
   OptimalKeep fkeep;
   fkeep.skip_download = device_encode;
   rc = Lz77OptimalFixedBatch(ctx, fixed_requests, &fixed_runs, device_encode ? &fkeep : nullptr);

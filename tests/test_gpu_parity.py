@@ -801,3 +801,20 @@ def test_zopflipng_linked_against_libzopfli_amd(tmp_path):
             outs[name] = f.read()
     assert outs["amd"] == outs["ref"]
     assert len(outs["amd"]) < os.path.getsize(src)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_run_paths_fuzz(seed):
+    """tools/fuzz_runs.py in small: runs of equal bytes with lengths around 32 / 64 / 258 / 516 / 774 / 1024, back to
+    back, cut by block ends, with text and noise between them — the stretches of the run variant of the chain
+    (zmx_dp5.h: run_stretch, other_stretch, the shortcut) against the real reference, byte for byte."""
+    import random
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_runs
+    rng = random.Random(seed)
+    for size, n, bs in ((70000, 15, 1), (300000, 3, 0), (1000001, 3, 1), (300000, 15, 0)):
+        data = fuzz_runs.make_case(rng, size)
+        ref = ol.ref_compress(data, 0, n, bs, 15)
+        mine = api.compress(data, 0, ZopfliOptions(n, bs, 15))
+        assert mine == ref, f"seed {seed}: {size} bytes, numiterations {n}, blocksplitting {bs}"

@@ -3,6 +3,11 @@
 #include <algorithm>
 #include <vector>
 
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include "block_cost.h"
 #include "thread_pool.h"
 
@@ -10,13 +15,22 @@ namespace zamd {
 
 namespace {
 
+// ZOPFLI_AMD_PROF: evaluations of the split cost and the time they take, summed over all threads, printed per block.
+std::atomic<unsigned long long> g_split_evals{0}, g_split_ns{0};
+const bool g_split_prof = std::getenv("ZOPFLI_AMD_PROF") != nullptr;
+
 constexpr double kLarge = 1e30;  // ZOPFLI_LARGE_FLOAT, util.h:65
 
 struct SplitCost {
   const Lz77Store& lz77;
   size_t start, end;
   double operator()(size_t i) const {
-    return CalculateBlockSizeAutoType(lz77, start, i) + CalculateBlockSizeAutoType(lz77, i, end);
+    if (!g_split_prof) return CalculateBlockSizeAutoType(lz77, start, i) + CalculateBlockSizeAutoType(lz77, i, end);
+    const auto t0 = std::chrono::steady_clock::now();
+    const double v = CalculateBlockSizeAutoType(lz77, start, i) + CalculateBlockSizeAutoType(lz77, i, end);
+    g_split_ns += static_cast<unsigned long long>(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
+    ++g_split_evals;
+    return v;
   }
 };
 
@@ -105,6 +119,9 @@ void BlockSplitLz77(const Lz77Store& lz77, size_t maxblocks, std::vector<size_t>
     if (!found) break;
     if (lend - lstart < 10) break;
   }
+  if (g_split_prof)
+    std::fprintf(stderr, "BlockSplitLz77: %zu symbols, %zu split points; so far %llu evaluations of the split cost, %.1f us each\n", n,
+                 points->size(), g_split_evals.load(), g_split_evals.load() ? g_split_ns.load() * 1e-3 / g_split_evals.load() : 0.0);
 }
 
 std::vector<size_t> SplitPointsToBytes(const Lz77Store& lz77, const std::vector<size_t>& points,

@@ -15,6 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as ol  # noqa: E402
 from zopfli_amd import ZopfliOptions, api, generate  # noqa: E402
 
+TEXTY = os.environ.get("FUZZ_TEXT", "0") != "0"
 EDGES = [1, 2, 3, 4, 31, 32, 33, 63, 64, 65, 127, 128, 129, 257, 258, 259, 260, 289, 290, 515, 516, 517, 518, 773, 774, 775,
          1023, 1024, 1025, 1031, 1032, 1033, 2047, 2048, 2049]
 
@@ -25,6 +26,8 @@ def make_case(rng, size):
     alphabet = bytes(rng.sample(range(256), rng.choice([1, 2, 3, 4, 8])))
     while len(out) < size:
         kind = rng.random()
+        if TEXTY:                             # FUZZ_TEXT=1: mostly text and copies, a run now and then
+            kind = 0.72 + 0.18 * kind if rng.random() < 0.8 else kind
         if kind < 0.55:                       # a run
             r = rng.random()
             if r < 0.6:

@@ -329,6 +329,7 @@ struct Dp4Params {
   const float* est_bits;   // [nb_total] estimated block cost in bits (first run of a table set), or null
   SegSnap* entry;          // [tasks]
   SegSnap* exit;           // [tasks]
+  SegSnap* mid;            // [tasks] the state where a task first comes near the end of its binade (zmx_dp5.h), base = SEG_NONE: none
   SegCheck* chk;           // [tasks]
   const float* wmax;       // [nb_total] no edge weight of the run exceeds this
   const u32* tiemask;      // [nb_total] bit e: a weight of the run can tie in the float rounding of binade e
@@ -368,6 +369,7 @@ struct D4Job {
   const SegSnap* init;
   SegSnap* entry;
   SegSnap* exit;
+  SegSnap* mid = nullptr;  // spec: where to leave the state at the first window that comes near the end of the binade
   u16* over;               // [SEG_OVER] lengths of the cells from over_lo on
 };
 

@@ -284,6 +284,9 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
     else if (x - over_lo < SEG_OVER) over[x - over_lo] = v;
   };
   float vmax = 0.0f;
+  u32 mid_hi = 0;                                   // (set with the entry snapshot)
+  const float mid_margin = 2.0f * P.wmax[b];
+  if (J.mid != nullptr && lane == 0) J.mid->base = SEG_NONE;
   u32 wbase = (u32)__builtin_amdgcn_readfirstlane((int)J.start);
   bool noshort = J.noshort != 0;
   // After a long-run shortcut the cell registers are put back on the 32-position grid (windows at multiples of 32 from
@@ -415,6 +418,27 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
       if (lane == 0) { J.entry->base = wbase; J.entry->noshort = noshort ? 1u : 0u; J.entry->skip = skip; }
       la_lo = wbase;
       vmax = 0.0f;
+      // where the binade of the entry state ends (the bit pattern of its 2^(e+1)); 0: no mid snapshot for this task
+      const u32 e0_ = rdlane_u32(__float_as_uint(c[0]), skip < 32u ? skip : 0u);
+      mid_hi = (RUNS && J.mid != nullptr && e0_ < 0x70000000u) ? (e0_ & 0x7f800000u) + 0x00800000u : 0u;
+    }
+    // A task that grows out of its binade is only accepted with a level that was exactly right (zmx_dp4.h: d4_accept),
+    // and long tasks on long-run data mostly do grow out of one.  What they did BEFORE they came near the end of the
+    // binade is as good as any task's: so the state at the first window whose first cell lies within two of the largest
+    // weights of that end is left in mid[t], with the largest source value up to there — k_dp4_fix accepts that prefix by
+    // the ordinary test and re-runs the task from the snapshot instead of from its start.  (The trigger only decides
+    // WHERE the snapshot lies; whether the prefix stayed inside the binade is decided by its recorded maximum.)
+    // (at a multiple of 64 only: k_dp4's pipeline, which may be the one to continue from here, walks in groups of 64 and
+    //  has to stop at the base its successor started from)
+    if (RUNS && mid_hi != 0 && la_lo != SEG_NONE && skip == 0 && (wbase & 63u) == 0) {
+      const u32 c0_ = rdlane_u32(__float_as_uint(c[0]), 0);
+      if (c0_ < 0x70000000u && __uint_as_float(c0_) + mid_margin >= __uint_as_float(mid_hi)) {
+#pragma unroll
+        for (int s = 0; s < 6; ++s) { J.mid->c[64u * s + lane] = c[s]; J.mid->l[64u * s + lane] = l[s]; }
+        const float pv_ = wave_max_f32(vmax);
+        if (lane == 0) { J.mid->base = wbase; J.mid->noshort = noshort ? 1u : 0u; J.mid->skip = 0u; J.mid->vmax = pv_; }
+        mid_hi = 0;
+      }
     }
     bool jumped = false;
     const u64 tw0 = PROF ? (u64)__builtin_readcyclecounter() : 0ull;
@@ -1206,6 +1230,10 @@ __global__ __launch_bounds__(64 * D5_WG, WAVES) void k_dp5_spec(Dp4Params P) {
   J.init = nullptr;
   J.entry = &P.entry[t];
   J.exit = &P.exit[t];
+  // (run tasks only: they are the long ones — tens of thousands of positions between two cut points — that leave their
+  //  binade; the text variant keeps its window loop as it was, and its mid[t].base is set to none below)
+  J.mid = RUNS && T.pout != 0 && P.mid != nullptr ? &P.mid[t] : nullptr;
+  if (!RUNS && T.pout != 0 && P.mid != nullptr && (threadIdx.x & 63) == 0) P.mid[t].base = SEG_NONE;
   J.over_lo = T.pend <= B ? T.pend : SEG_NONE;
   J.over = P.over + (u64)t * SEG_OVER;
   if (T.pout == 0) {       // the head of the block
@@ -1253,7 +1281,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
   d4_copy_over(P, t0, B, la_block);   // the head is exact
   double delta_prev = 0.0;     // what has to be added to exit[t - 1] to get the true values
   bool rerun_prev = false;     // exit[t - 1] was rewritten by this workgroup: P.chk[t] is stale
-  u32 n_ok = 0, n_state = 0, n_level = 0, n_tie = 0, n_pos = 0, n_values = 0, n_lean = 0;
+  u32 n_ok = 0, n_state = 0, n_level = 0, n_tie = 0, n_pos = 0, n_values = 0, n_lean = 0, n_mid = 0;
   const u32* winflag = P.winflag + P.win_off[b];
   const u64 cyc0 = __builtin_readcyclecounter();
   u64 cyc_run = 0;
@@ -1326,7 +1354,6 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
     J.noshort = P.exit[t - 1].noshort;
     J.pout = 0;
     J.pend = T.pend;
-    J.la_lo = J.start;
     J.over_lo = SEG_NONE;    // (this workgroup is the only writer of the block's length_array now)
     J.spec = false;
     J.load = true;
@@ -1336,6 +1363,23 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
     J.entry = nullptr;
     J.exit = &P.exit[t];
     J.over = nullptr;
+    // The task matched its predecessor and only grew out of its binade: if what it did up to its mid snapshot passes the
+    // test (the same test, with the largest source value of that prefix), the prefix stands — its lengths are in
+    // length_array already — and the re-run starts at the snapshot, from the task's own cells plus the shift.
+    bool from_mid = false;
+    if (ck.match == 1 && why == 1 && P.mid != nullptr) {
+      const u32 mb_ = P.mid[t].base;
+      if (mb_ != SEG_NONE && mb_ > P.entry[t].base && mb_ < (T.pend < B ? T.pend : B) &&
+          d4_accept(ck.vmin, (double)P.mid[t].vmax, delta, wmax, tiemask) == 0) {
+        from_mid = true;
+        J.start = mb_;
+        J.noshort = P.mid[t].noshort;
+        J.delta = delta;
+        J.init = &P.mid[t];
+        ++n_mid;
+      }
+    }
+    J.la_lo = J.start;
     n_pos += (T.pend < B ? T.pend : B) - (J.start < B ? J.start : B);
     // windows of the task that k_dp5_spec's fast paths cannot take (k_mkdesc)
     const u32 w0 = J.start >> 5, w1 = ((T.pend < B ? T.pend : B) + 31u) >> 5;
@@ -1350,7 +1394,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
     const int n_have = __syncthreads_count(mine > 0 ? 1 : 0);
     // (a predecessor that stopped inside a shortcut's window — skip — can only be continued by the job that knows
     //  about it)
-    const bool lean = P.exit[t - 1].skip != 0 || (P.fix_lean_min >= 0 ? n_generic >= P.fix_lean_min : 2 * n_major >= n_have);
+    const bool lean = (!from_mid && P.exit[t - 1].skip != 0) || (P.fix_lean_min >= 0 ? n_generic >= P.fix_lean_min : 2 * n_major >= n_have);
     const u64 cr0 = __builtin_readcyclecounter();
     if (lean) {
       ++n_lean;
@@ -1384,8 +1428,8 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
   __syncthreads();
   }
   if (P.debug >= 2 && lead) {
-    printf("fix b %u: %u tasks ok %u state %u values %u level %u tie %u lean %u, %u positions re-run, %llu cycles in all, %llu in re-runs\n", b,
-           t1 - t0, n_ok, n_state, n_values, n_level, n_tie, n_lean, n_pos, (unsigned long long)(__builtin_readcyclecounter() - cyc0),
+    printf("fix b %u: %u tasks ok %u state %u values %u level %u (%u of them from their mid snapshot) tie %u lean %u, %u positions re-run, %llu cycles in all, %llu in re-runs\n", b,
+           t1 - t0, n_ok, n_state, n_values, n_level, n_mid, n_tie, n_lean, n_pos, (unsigned long long)(__builtin_readcyclecounter() - cyc0),
            (unsigned long long)cyc_run);
   }
   if (lead && P.stats) {

@@ -199,6 +199,7 @@ struct zmx_tables {
   float* d_lvl = nullptr;
   SegSnap* d_entry = nullptr;
   SegSnap* d_exit = nullptr;
+  SegSnap* d_mid = nullptr;      // per task: the state where it first came near the end of its binade (zmx_dp5.h)
   SegCheck* d_chk = nullptr;
   u16* d_over = nullptr;      // [tasks][SEG_OVER]
   u32* d_redo = nullptr;      // [1 + 3 pad + tasks * 4]: k_dpscan's list of tasks to run a second time
@@ -512,6 +513,7 @@ static void ReleaseTableArrays(zmx_ctx* c, zmx_tables* t, bool keep_stores) {
   rel(t->d_lvl);
   rel(t->d_entry);
   rel(t->d_exit);
+  rel(t->d_mid);
   rel(t->d_chk);
   rel(t->d_over);
   rel(t->d_redo);
@@ -1004,6 +1006,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     HIPCHK(PoolAlloc(c, &t->d_lvl, nt));
     HIPCHK(PoolAlloc(c, &t->d_entry, nt));
     HIPCHK(PoolAlloc(c, &t->d_exit, nt));
+    HIPCHK(PoolAlloc(c, &t->d_mid, nt));
     HIPCHK(PoolAlloc(c, &t->d_chk, nt));
     HIPCHK(PoolAlloc(c, &t->d_over, nt * SEG_OVER));
     HIPCHK(PoolAlloc(c, &t->d_redo, 4 + nt * 4));
@@ -1338,6 +1341,8 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   cp.est_bits = t->squeeze_runs == 0 ? t->d_runinfo + 2 * nb : nullptr;
   cp.entry = t->d_entry;
   cp.exit = t->d_exit;
+  static const bool mid_on = EnvU32("ZOPFLI_AMD_SEG_MID", 1, 0, 1) != 0;   // 0: no mid snapshots (tasks that leave their binade are re-run whole)
+  cp.mid = mid_on ? t->d_mid : nullptr;
   cp.chk = t->d_chk;
   cp.over = t->d_over;
   cp.wmax = t->d_runinfo;

@@ -216,6 +216,11 @@ uint32_t zmx_checksum_combine(int kind, uint32_t a, uint32_t b, uint64_t len_b);
 int zmx_find_longest_match(zmx_ctx* ctx, zmx_tables* tables, size_t block, size_t pos,
                            uint16_t* sublen, uint16_t* distance, uint16_t* length);
 
+/* Parity probe over whole tables: two 64-bit sums over all positions of a hash of the logical content of the match
+ * records (block, position, length, distance, same, literal, every change point of sublen).  Equal digests of two
+ * table sets over the same blocks = the same ZopfliFindLongestMatch results at every position. */
+int zmx_match_digest(zmx_ctx* ctx, zmx_tables* tables, uint64_t* out2);
+
 /* Parity probe: the static hash arrays of one block for positions max(0, instart - 32768) .. inend - 1
  * (inend - windowstart entries each): same[] (hash.c:116-126) and the distances to the previous
  * position of the same hash / of the same second hash (hash.c:110-114, 129-135; 0 = none).
@@ -288,6 +293,11 @@ int zmx_last_host_timing(double* out2);
  * k_chain (or k_bucket) [2] table builds [3] positions whose record
  * the match kernel computed (the others were copied from the parent tables). */
 int zmx_last_match_timing(double* out4);
+
+/* Which match-table kernel the table builds that START after this call use (the ZOPFLI_AMD_MATCH environment
+ * variable sets the initial choice): 2 = k_chain + k_match2, 3 / 4 = k_bucket + k_match3 / k_match4, 5 = k_chain +
+ * k_rank2 + k_levels + k_match5 (the exact skip-walk).  All produce the same records; an A/B and test hook. */
+int zmx_set_match_kernel(int kernel);
 
 /* The chain's tasks (GetBestLengths cut into verified stretches, zmx_dp4.h) since the last Zopfli* /
  * zmx_deflate_range call started: [0] tasks [1] accepted as computed [2] re-run because the entry

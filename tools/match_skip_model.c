@@ -21,8 +21,9 @@
 
 int zopfli_amd_datagen(char cls, unsigned long long seed, unsigned char* out, size_t n);
 
-#define MAXLEV 8
+#define MAXLEV 12
 static unsigned NL = 3, LEVK[MAXLEV] = {4, 8, 16}, HBITS = 15;
+static int RAW_A = 0;   /* 1: the first chain is walked hit by hit, levels only on the second chain */
 
 typedef struct {
   unsigned short* lv[MAXLEV]; /* level links: distance to the previous position of the same level hash, 0 = none */
@@ -121,6 +122,7 @@ static unsigned skip_walk(const zo_table* t, const Extra* x, size_t pos, Cp* cps
      * S + 2 shared bytes.  Where that beats the level's k bytes — inside runs, where a level chain links every
      * position of every run of the byte — the reference's own chain is the shorter list. */
     if (chain == 2 && k >= 0 && S + 2 > LEVK[k]) k = -1;
+    if (chain == 1 && RAW_A) k = -1;
     if (k < 0) {
       /* raw: the reference's own next hit */
       const unsigned step = chain == 1 ? t->prev1[cur - ws] : t->prev2[cur - ws];
@@ -135,7 +137,7 @@ static unsigned skip_walk(const zo_table* t, const Extra* x, size_t pos, Cp* cps
       int have1 = 0, havesw = 0;
       if (k != ek) {
         ek = k;
-        eq = (LEVK[k] <= b && cur != pos) ? cur : pos;
+        eq = (LEVK[k] <= b && bestdist != 0) ? pos - bestdist : pos;   /* the candidate that set bestlength shares b >= k bytes */
       }
       /* next level entry below cur: the entries at or above cur were visited or are not on the walk.
        * Not needed on the first chain once bestlength > S: a longer match has exactly the position's run length,
@@ -238,6 +240,7 @@ int main(int argc, char** argv) {
     while (*s && NL < MAXLEV) { LEVK[NL++] = (unsigned)strtoul(s, &s, 10); if (*s == ',') s++; }
   }
   if (argc > 4) HBITS = (unsigned)atoi(argv[4]);
+  if (argc > 5) RAW_A = atoi(argv[5]);
   in = (unsigned char*)calloc(n + 4096, 1);
   zopfli_amd_datagen(cls, 1, in, n);
   for (b = 0; b < n; b += MB) {

@@ -101,6 +101,7 @@ def bind(lib):
     lib.zmx_last_host_timing.argtypes = [P(ctypes.c_double)]
     lib.zmx_last_seg_stats.argtypes = [P(ctypes.c_double)]
     lib.zmx_last_match_timing.argtypes = [P(ctypes.c_double)]
+    lib.zmx_set_match_kernel.argtypes = [ctypes.c_int]
     lib.zmx_dist_unique_id.argtypes = [ctypes.c_char_p]
     lib.zmx_dist_init.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, P(vp)]
     lib.zmx_dist_destroy.argtypes = [vp]
@@ -407,6 +408,14 @@ class Tables:
                                                             ctypes.byref(d), ctypes.byref(l)),
                         "zmx_find_longest_match")
         return l.value, d.value, sub
+
+    def match_digest(self):
+        """zmx_match_digest: a digest of every match record of these tables."""
+        out = (ctypes.c_uint64 * 2)()
+        fn = self.ctx.lib.zmx_match_digest
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        self.ctx._check(fn(self.ctx.handle, self.handle, out), "zmx_match_digest")
+        return (int(out[0]), int(out[1]))
 
     def hash_links(self, block):
         """same[], prev1[], prev2[] of the block's positions from windowstart on (zmx_hash_links_download)."""

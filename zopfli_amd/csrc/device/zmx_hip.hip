@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +19,7 @@
 #include "zmx_match2.h"
 #include "zmx_match3.h"
 #include "zmx_match4.h"
+#include "zmx_match5.h"
 #include "zmx_dp4.h"
 #include "zmx_dp5.h"
 #include "zmx_encode.h"
@@ -68,6 +70,7 @@ struct DeviceGuard {
 constexpr int kTooLarge = -2;   // zmx_tables_build*: the batch does not fit the code budget, try fewer blocks
 constexpr u32 kMatchGrid = 1024;  // persistent workgroups: 256 CUs x 4 (LDS-limited)
 constexpr u32 kMatchGrid3 = 768;  // k_match3: 256 CUs x 3
+constexpr u32 kMatchGrid5 = 1024; // k_match5: what fits is decided by its registers; its scratch is kMatchGrid's
 constexpr size_t kInputPad = 4096;
 
 // ---------------------------------------------------------------------------------------------
@@ -286,8 +289,17 @@ bool MatchFilter() {
 // still the fastest on every class measured, profiles/r03_match_ab.txt), 3 = k_bucket + k_match3 (sorted candidate
 // slices, a wave per position, 64 candidates per coalesced load), 4 = k_bucket + k_match4 (the same slices streamed
 // by a lane per position, four candidates per step).  All three produce the same records (tests).
+// 5 = k_chain + k_rank2 + k_levels + k_match5 (zmx_match5.h): the exact skip-walk — level links, hits counted from
+// ranks instead of visited.  Tables built from a parent recompute their few tiles with k_match2 either way.
+std::atomic<int> g_match_kernel{-1};
 int MatchKernel() {
-  static const int v = [] { const char* e = std::getenv("ZOPFLI_AMD_MATCH"); const int k = e ? std::atoi(e) : 2; return k == 3 || k == 4 ? k : 2; }();
+  int v = g_match_kernel.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = std::getenv("ZOPFLI_AMD_MATCH");
+    const int k = e ? std::atoi(e) : 2;
+    v = k == 3 || k == 4 || k == 5 ? k : 2;
+    g_match_kernel.store(v, std::memory_order_relaxed);
+  }
   return v;
 }
 
@@ -382,6 +394,12 @@ int zmx_device_count(void) {
 }
 
 const char* zmx_last_error(void) { return g_err.c_str(); }
+
+int zmx_set_match_kernel(int kernel) {
+  if (kernel != 2 && kernel != 3 && kernel != 4 && kernel != 5) return FailMsg("zmx_set_match_kernel: 2, 3, 4 or 5");
+  g_match_kernel.store(kernel, std::memory_order_relaxed);
+  return 0;
+}
 
 size_t zmx_internal_input_size(zmx_ctx* ctx) { return ctx->insize; }
 int zmx_internal_device(zmx_ctx* ctx) { return ctx->device; }
@@ -587,6 +605,7 @@ static unsigned SegHead(size_t nb) {
 static unsigned SegWarm() { static const unsigned v = (EnvU32("ZOPFLI_AMD_SEG_WARM", 512, 64, 1u << 20) + 63u) & ~63u; return v; }
 
 static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_tables* t, zmx_tables* parent = nullptr, bool with_dp = true) {
+  const int mk = MatchKernel();   // (one choice per build: zmx_set_match_kernel may be called meanwhile)
   t->matches_only = !with_dp;
   t->nb = nb;
   t->blocks.resize(nb);
@@ -661,7 +680,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   HIPCHK(PoolAlloc(c, &t->d_blocks, nb));
   HIPCHK(PoolAlloc(c, &t->d_tile_off, nb + 1));
   HIPCHK(PoolAlloc(c, &t->d_same16, reg_off));
-  t->buckets = MatchKernel() != 2;
+  t->buckets = mk == 3 || mk == 4;
   t->chunk_base.assign(nb + 1, 0);
   for (size_t b = 0; b < nb; ++b) {
     const u64 L = t->blocks[b].inend - t->blocks[b].ws;
@@ -722,6 +741,9 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
 
   HIPCHK(hipEventRecord(c->ev[0], c->stream));
   PoolScope hash_tmp(c);
+  u16* d_lev = nullptr;    // k_levels / k_rank2 (ZOPFLI_AMD_MATCH=5), alive until the match kernel has run
+  u16* d_tot2 = nullptr;
+  uint4* d_xrec = nullptr;
   auto launch_hash = [&](const u64* d_link_lo) -> int {
     if (max_l == 0) return 0;
     const dim3 g1(static_cast<unsigned>((max_l + 256 * SAME_CH - 1) / (256 * SAME_CH)), static_cast<unsigned>(nb));
@@ -743,6 +765,31 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     } else {
       hipLaunchKernelGGL(k_chain, g2, dim3(64), CH_LDS_BYTES, c->stream, c->d_in, t->d_blocks, t->d_same16, t->d_links, d_link_lo);
       KCHK(c, "k_chain");
+      if (mk == 5 && d_link_lo == nullptr) {
+        // the skip-walk's arrays (whole blocks only: a table built from a parent recomputes a few tiles with k_match2)
+        if (!d_lev) HIPCHK(hash_tmp.AllocT(&d_lev, static_cast<size_t>(LV_N) * reg_off, "d_lev"));
+        if (!d_tot2) HIPCHK(hash_tmp.AllocT(&d_tot2, reg_off, "d_tot2"));
+        if (!d_xrec) HIPCHK(hash_tmp.AllocT(&d_xrec, 2 * reg_off, "d_xrec"));
+        LevelParams lp;
+        lp.in = c->d_in;
+        lp.blocks = t->d_blocks;
+        lp.lev = d_lev;
+        lp.total_l = reg_off;
+        const dim3 g4(static_cast<unsigned>((max_l + LV_CH - 1) / LV_CH), static_cast<unsigned>(nb), LV_N);
+        hipLaunchKernelGGL(k_levels, g4, dim3(64), 0, c->stream, lp);
+        KCHK(c, "k_levels");
+        RankParams rp;
+        rp.in = c->d_in;
+        rp.blocks = t->d_blocks;
+        rp.links = t->d_links;
+        rp.lev = d_lev;
+        rp.total_l = reg_off;
+        rp.tot2 = d_tot2;
+        rp.xrec = d_xrec;
+        const dim3 g3(static_cast<unsigned>((max_l + RK_CH - 1) / RK_CH), static_cast<unsigned>(nb));
+        hipLaunchKernelGGL(k_rank2, g3, dim3(64), 0, c->stream, rp);
+        KCHK(c, "k_rank2");
+      }
     }
     return 0;
   };
@@ -756,7 +803,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     t->links_partial = reuse;
   }
 
-  if (MatchKernel() != 3 && !c->d_scratch) HIPCHK(PoolAllocT(c, &c->d_scratch, static_cast<size_t>(kMatchGrid) * M2_THREADS * SCRATCH_CPS, "d_scratch"));
+  if (mk != 3 && !c->d_scratch) HIPCHK(PoolAllocT(c, &c->d_scratch, static_cast<size_t>(kMatchGrid) * M2_THREADS * SCRATCH_CPS, "d_scratch"));
   HIPCHK(hipEventRecord(c->ev[1], c->stream));
   double match_positions = 0;
   // the match-table kernel over `total_tiles` tiles (all of them, or those of tile_list)
@@ -779,7 +826,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
       mp.counters = t->d_counters;
       mp.tile_list = d_tiles;
       mp.scratch = c->d_scratch;
-      if (MatchKernel() == 3) {
+      if (mk == 3) {
         if (prof) hipLaunchKernelGGL((k_match3<true>), dim3(kMatchGrid3), dim3(M3_THREADS), 0, c->stream, mp);
         else hipLaunchKernelGGL((k_match3<false>), dim3(kMatchGrid3), dim3(M3_THREADS), 0, c->stream, mp);
         KCHK(c, "k_match3");
@@ -803,6 +850,15 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     mp.counters = t->d_counters;
     mp.scratch = c->d_scratch;
     mp.tile_list = d_tiles;
+    if (mk == 5 && d_tiles == nullptr) {
+      Match5Params q;
+      q.m = mp;
+      q.xrec = d_xrec;
+      if (prof) hipLaunchKernelGGL((k_match5<true>), dim3(kMatchGrid5), dim3(M5_THREADS), 0, c->stream, q);
+      else hipLaunchKernelGGL((k_match5<false>), dim3(kMatchGrid5), dim3(M5_THREADS), 0, c->stream, q);
+      KCHK(c, "k_match5");
+      return 0;
+    }
     const bool filt = MatchFilter();
     if (prof && filt) hipLaunchKernelGGL((k_match2<true, true>), dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
     else if (prof) hipLaunchKernelGGL((k_match2<true, false>), dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
@@ -895,10 +951,10 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
       HIPCHK(hipMemcpy(hc, t->d_counters + 4, sizeof(hc), hipMemcpyDeviceToHost));
       const double pos = static_cast<double>(pos_off);
       std::fprintf(stderr, "%s: %.2f ms for %.0f positions: %.1f chain hits per "
-                   "position, %.1f of 64 lanes with a hit per wave-loop iteration; %.1f SIMD cycles per hit (2.4 GHz, 1024 SIMDs)\n", MatchKernel() == 4 ? "k_match4" : MatchKernel() == 3 ? "k_match3" : "k_match2", ms_match, pos,
+                   "position, %.1f of 64 lanes with a hit per wave-loop iteration; %.1f SIMD cycles per hit (2.4 GHz, 1024 SIMDs)\n", mk == 5 ? "k_match5 (hits = entries touched)" : mk == 4 ? "k_match4" : mk == 3 ? "k_match3" : "k_match2", ms_match, pos,
                    static_cast<double>(hc[0]) / pos, static_cast<double>(hc[0]) / static_cast<double>(hc[1] ? hc[1] : 1),
                    ms_match * 1e-3 * 2.4e9 * 1024 / static_cast<double>(hc[0] ? hc[0] : 1));
-      if (MatchKernel() == 3) {
+      if (mk == 3) {
         unsigned long long h3[3] = {0, 0, 0};
         HIPCHK(hipMemcpy(h3, t->d_counters + 16, sizeof(h3), hipMemcpyDeviceToHost));
         const double nbat = static_cast<double>(hc[1] ? hc[1] : 1);
@@ -1757,6 +1813,68 @@ int zmx_encode_blocks(zmx_ctx* c, zmx_tables* t, size_t njobs, const zmx_enc_job
     const size_t nby = static_cast<size_t>((jobs[j].bit_start + jobs[j].nbits + 7) / 8);
     std::memcpy(out[j], stage + out_off[j], nby);
   });
+  return 0;
+}
+
+// Parity probe over WHOLE tables: two 64-bit sums over all positions of a hash of (block, position in the block,
+// length, distance, same, literal, every change point of sublen) — the logical content of the records, whatever
+// the order the pool handed out its entries in.  Two table sets over the same blocks with equal digests hold the
+// same ZopfliFindLongestMatch results (test_match_kernels_agree compares the kernels at sizes no per-position
+// loop reaches).
+__device__ __forceinline__ u64 dg_mix(u64 h, u64 v) {
+  h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+  h *= 0xBF58476D1CE4E5B9ull;
+  h ^= h >> 31;
+  return h;
+}
+__global__ __launch_bounds__(256) void k_rec_digest(const BlockDesc* __restrict__ blocks, const u32* __restrict__ recs,
+                                                    const u32* __restrict__ pool, unsigned long long* out) {
+  const BlockDesc bd = blocks[blockIdx.y];
+  const u64 B = bd.inend - bd.instart;
+  u64 s0 = 0, s1 = 0;
+  for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < B; i += (u64)gridDim.x * 256) {
+    const u32* r = recs + (bd.pos_off + i) * 8;
+    u64 h = dg_mix((u64)blockIdx.y * 0x100000001B3ull, i);
+    h = dg_mix(h, r[0]);
+    const u32 d1 = r[1];
+    const u32 ncpf = d1 >> 24;
+    h = dg_mix(h, d1 & 0xffffffu);
+    if (ncpf != 0xffu) {
+      const u8* b = reinterpret_cast<const u8*>(r) + 8;
+      h = dg_mix(h, ncpf);
+      for (u32 e = 0; e < ncpf; ++e) h = dg_mix(h, ((u32)b[3 * e] + 3u) | (((u32)b[3 * e + 1] | ((u32)b[3 * e + 2] << 8)) << 16));
+    } else {
+      const u32 off = r[2], n = r[3] & 0xffffu;
+      h = dg_mix(h, n);
+      for (u32 e = 0; e < n; ++e) h = dg_mix(h, pool[off + e]);
+    }
+    s0 += h;
+    s1 += (h >> 17 | h << 47) * 0x94D049BB133111EBull;
+  }
+  atomicAdd(out, s0);
+  atomicAdd(out + 1, s1);
+}
+
+int zmx_match_digest(zmx_ctx* c, zmx_tables* t, uint64_t* out2) {
+  if (!t || t->trimmed || !t->d_recs) return FailMsg("zmx_match_digest: no match records in these tables");
+  DeviceGuard dev_guard(c->device);
+  HIPCHK(dev_guard.err);
+  out2[0] = out2[1] = 0;
+  if (t->nb == 0) return 0;
+  PoolScope tmp(c);
+  unsigned long long* d_out = nullptr;
+  HIPCHK(tmp.AllocT(&d_out, 2, "d_digest"));
+  HIPCHK(hipMemsetAsync(d_out, 0, 2 * sizeof(unsigned long long), c->stream));
+  u64 max_b = 0;
+  for (size_t b = 0; b < t->nb; ++b) max_b = std::max<u64>(max_b, t->bsize[b]);
+  const unsigned gx = static_cast<unsigned>(std::min<u64>(std::max<u64>((max_b + 256 * 8 - 1) / (256 * 8), 1), 2048));
+  hipLaunchKernelGGL(k_rec_digest, dim3(gx, static_cast<unsigned>(t->nb)), dim3(256), 0, c->stream, t->d_blocks, t->d_recs, t->d_pool, d_out);
+  KCHK(c, "k_rec_digest");
+  unsigned long long h[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  out2[0] = h[0];
+  out2[1] = h[1];
   return 0;
 }
 

@@ -65,6 +65,59 @@ def test_match_table(gpu_ctx, case):
 
 
 @pytest.mark.parametrize("case", TABLE_CASES, ids=_ids)
+def test_match_table_skip_walk(gpu_ctx, case):
+    """k_levels + k_rank2 + k_match5 (the exact skip-walk: level links, hits counted from ranks, zmx_match5.h) ==
+    ZopfliFindLongestMatch at every position, on every class — forced for every block (kernel 5), whatever k_hits
+    would choose."""
+    cls, n, blocks = case
+    data = generate(cls, n)
+    gpu_ctx.set_input(data)
+    gpu_ctx.lib.zmx_set_match_kernel(5)
+    try:
+        t = gpu_ctx.build_tables(blocks)
+    finally:
+        gpu_ctx.lib.zmx_set_match_kernel(0)
+    try:
+        for b, (s, e) in enumerate(blocks):
+            o = ol.OracleTable(data, s, e)
+            bad = []
+            for pos in range(s, e):
+                gl, gd, gsub = t.find_longest_match(b, pos)
+                ol_, od, osub = o.find_longest_match(pos)
+                same = (gl == ol_ and gd == od) if ol_ >= 3 else (gl < 3 and ol_ < 3)
+                if same and ol_ >= 3:
+                    same = np.array_equal(gsub[3:ol_ + 1], osub[3:ol_ + 1])
+                if not same:
+                    bad.append((pos, (gl, gd), (ol_, od)))
+                    if len(bad) >= 5:
+                        break
+            assert not bad, f"block {b} [{s},{e}): first mismatches (pos, gpu, oracle) {bad}"
+    finally:
+        t.free()
+
+
+@pytest.mark.parametrize("cls", list("TXRZBPM"))
+def test_match_digests_at_size(gpu_ctx, cls):
+    """Every match record of 4 MB of every class (5 master blocks: windows, block ends, the hit cap and the hash
+    switch on B / Z / P) is the same from k_match2, from k_match5 and from the default per-block choice between
+    them (zmx_match_digest: a hash of the logical content of all records)."""
+    n = 4012345
+    data = generate(cls, n)
+    gpu_ctx.set_input(data)
+    blocks = [(s, min(s + 1000000, n)) for s in range(0, n, 1000000)]
+    dig = {}
+    try:
+        for kern in (2, 5, 0):
+            gpu_ctx.lib.zmx_set_match_kernel(kern)
+            t = gpu_ctx.build_tables(blocks, matches_only=True)
+            dig[kern] = t.match_digest()
+            t.free()
+    finally:
+        gpu_ctx.lib.zmx_set_match_kernel(0)
+    assert dig[2] == dig[5] == dig[0], dig
+
+
+@pytest.mark.parametrize("case", TABLE_CASES, ids=_ids)
 def test_hash_links(gpu_ctx, case):
     """k_same + k_chain == the reference's hash state as static arrays (hash.c:100-137): same[] and the
     links to the previous position of the same hash value, for both hashes, at every position of the
@@ -124,8 +177,9 @@ def test_change_point_pool_overflow_and_retry():
 
 
 def test_match_kernels_agree():
-    """The three match-table kernels (ZOPFLI_AMD_MATCH: 2 = k_chain + k_match2 on prev links, 3 = k_bucket + k_match3,
-    a wave per position on sorted candidate slices, 4 = k_bucket + k_match4, the slices streamed by a lane per position)
+    """The match-table kernels (ZOPFLI_AMD_MATCH: 2 = k_chain + k_match2 on prev links, 3 = k_bucket + k_match3,
+    a wave per position on sorted candidate slices, 4 = k_bucket + k_match4, the slices streamed by a lane per position,
+    5 = k_match5, the exact skip-walk on level links with counted hits, 0 = the default: k_match5 or k_match2 per block)
     produce the same records — (length, distance, sublen) at every position of every class, blocks with a window in
     front, tables built from a parent, and a change-point pool that overflows — and the same hash arrays
     (zmx_hash_links_download reads k_bucket's sorted / rank / bucket arrays back as prev links).  Kernel 2 is the one
@@ -161,7 +215,7 @@ def test_match_kernels_agree():
         "    t.free()\n"
         "print(h.hexdigest())\n" % os.path.dirname(os.path.dirname(__file__)))
     res = {}
-    for kern in ("2", "3", "4"):
+    for kern in ("2", "3", "4", "5", "0"):
         for entries in ("", "2000"):
             env = dict(os.environ, ZOPFLI_AMD_MATCH=kern)
             if entries:
@@ -453,6 +507,32 @@ def test_full_size_round_trip(gpu_lib, case):
     opt = ZopfliOptions(case["numiterations"], case["blocksplitting"], case["blocksplittingmax"])
     out = api.compress(data, case["format"], opt, lib=gpu_lib)
     assert gzip.decompress(out) == data
+    assert len(out) == case["outsize"]
+    assert hashlib.sha256(out).hexdigest() == case["sha256"]
+
+
+def _at_size_cases():
+    """BASELINE's own sizes: every class at 100 MB (configs[1] / [2] shapes, blocksplitting 0 and 1) and the mixed corpus
+    at 200 MB with numiterations 50 (configs[3]); goldens from the real reference (make_golden.py --big / --big2 /
+    --big3, make_golden_parallel.py)."""
+    out = []
+    for name in ("vectors_big.json", "vectors_big2.json", "vectors_big3.json", "vectors_big4.json"):
+        path = os.path.join(os.path.dirname(GOLDEN), name)
+        if os.path.exists(path):
+            with open(path) as f:
+                out += [c for c in json.load(f) if c["insize"] >= 100000000]
+    return out
+
+
+@pytest.mark.parametrize("case", _at_size_cases(), ids=_gid)
+def test_at_size_streams(gpu_lib, case):
+    """The workloads BASELINE.json names at the sizes it names — 100 MB of every class with and without block splitting,
+    200 MB of the mixed corpus at numiterations 50 — are the reference's streams: SHA-256 and length of the whole
+    gzip file (the round trip through zlib is implied by the CRC-32 / ISIZE trailer the digest covers, and checked
+    at 20 MB by test_full_size_round_trip)."""
+    data = _input(case["input"])
+    opt = ZopfliOptions(case["numiterations"], case["blocksplitting"], case["blocksplittingmax"])
+    out = api.compress(data, case["format"], opt, lib=gpu_lib)
     assert len(out) == case["outsize"]
     assert hashlib.sha256(out).hexdigest() == case["sha256"]
 

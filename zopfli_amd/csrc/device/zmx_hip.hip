@@ -70,7 +70,8 @@ struct DeviceGuard {
 constexpr int kTooLarge = -2;   // zmx_tables_build*: the batch does not fit the code budget, try fewer blocks
 constexpr u32 kMatchGrid = 1024;  // persistent workgroups: 256 CUs x 4 (LDS-limited)
 constexpr u32 kMatchGrid3 = 768;  // k_match3: 256 CUs x 3
-constexpr u32 kMatchGrid5 = 1024; // k_match5: what fits is decided by its registers; its scratch is kMatchGrid's
+constexpr int kMatchDefault = 0;   // ZOPFLI_AMD_MATCH when unset: per block, k_match5 where k_hits says the chains are long, else k_match2
+constexpr u32 kMatchGrid5 = 1536; // k_match5: 256 CUs x 6 workgroups of 4 waves (its scratch is k_match2's: 1536 x 256 <= 1024 x 512 lanes)
 constexpr size_t kInputPad = 4096;
 
 // ---------------------------------------------------------------------------------------------
@@ -109,6 +110,7 @@ struct zmx_ctx {
   size_t insize = 0, in_cap = 0;
   const unsigned char* h_in = nullptr;  // caller's buffer (borrowed until the next zmx_set_input)
   u32* d_scratch = nullptr;  // k_match2 per-lane overflow change points
+  u32* d_scratch5 = nullptr; // k_match5's (it may run beside k_match2)
   // table arrays are recycled between batches and calls: hipMalloc/hipFree of multi-GB arrays
   // cost more than the kernels that fill them
   std::unordered_map<void*, size_t> pool_live;
@@ -175,7 +177,7 @@ struct zmx_tables {
   std::vector<u32> seg_off;
   std::vector<u64> block_edges;
   std::vector<u32> tile_off;
-  u32* d_counters = nullptr;  // 24 words, see MatchParams (16 .. 21: k_match3's profile counts)
+  u32* d_counters = nullptr;  // 48 words, see MatchParams (16 .. 21: k_match3's profile counts; 24 .. 31: k_match5's tile cursors, 32 .. 39: its watchdog's dump)
   u32* d_flags = nullptr;     // 4 words
   // what a squeeze run takes and gives, each side ONE array on the device and one pinned mirror on the host, so
   // that a run has one copy down and one up (eight small copies a run were 3 ms of copy kernels per 15 runs):
@@ -285,21 +287,30 @@ bool MatchFilter() {
   return on;
 }
 
-// Which match-table kernel (ZOPFLI_AMD_MATCH): 2 = k_chain + k_match2 (prev links, a lane per position; the default:
-// still the fastest on every class measured, profiles/r03_match_ab.txt), 3 = k_bucket + k_match3 (sorted candidate
-// slices, a wave per position, 64 candidates per coalesced load), 4 = k_bucket + k_match4 (the same slices streamed
-// by a lane per position, four candidates per step).  All three produce the same records (tests).
-// 5 = k_chain + k_rank2 + k_levels + k_match5 (zmx_match5.h): the exact skip-walk — level links, hits counted from
-// ranks instead of visited.  Tables built from a parent recompute their few tiles with k_match2 either way.
+// Which match-table kernel (ZOPFLI_AMD_MATCH / zmx_set_match_kernel):
+//   0 (default) per block: k_hits estimates the hits per position of the reference's walk; blocks above
+//       ZOPFLI_AMD_MATCH_HITS (300) take the exact skip-walk k_match5 (level links + counted hits, zmx_match5.h: 5 - 9 x
+//       faster on PNG-like and two-symbol data, profiles/r04_match.txt), the others k_match2, side by side on two streams
+//   2 = k_chain + k_match2 everywhere (prev links, a lane per position)
+//   3 = k_bucket + k_match3 (sorted candidate slices, a wave per position, 64 candidates per coalesced load)
+//   4 = k_bucket + k_match4 (the same slices streamed by a lane per position, four candidates per step)
+//   5 = k_match5 everywhere
+// All produce the same records (test_match_kernels_agree).  Tables built from a parent recompute their few tiles with
+// k_match2 either way.
 std::atomic<int> g_match_kernel{-1};
 int MatchKernel() {
   int v = g_match_kernel.load(std::memory_order_relaxed);
   if (v < 0) {
     const char* e = std::getenv("ZOPFLI_AMD_MATCH");
-    const int k = e ? std::atoi(e) : 2;
-    v = k == 3 || k == 4 || k == 5 ? k : 2;
+    const int k = e ? std::atoi(e) : kMatchDefault;
+    v = k == 0 || k == 3 || k == 4 || k == 5 ? k : 2;
     g_match_kernel.store(v, std::memory_order_relaxed);
   }
+  return v;
+}
+// kernel 0: blocks whose estimated hits per position (k_hits) exceed this take k_match5 (ZOPFLI_AMD_MATCH_HITS)
+u64 MatchAutoHits() {
+  static const u64 v = [] { const char* e = std::getenv("ZOPFLI_AMD_MATCH_HITS"); return e ? static_cast<u64>(std::max<long>(0, std::atol(e))) : 300ull; }();
   return v;
 }
 
@@ -396,7 +407,7 @@ int zmx_device_count(void) {
 const char* zmx_last_error(void) { return g_err.c_str(); }
 
 int zmx_set_match_kernel(int kernel) {
-  if (kernel != 2 && kernel != 3 && kernel != 4 && kernel != 5) return FailMsg("zmx_set_match_kernel: 2, 3, 4 or 5");
+  if (kernel != 0 && kernel != 2 && kernel != 3 && kernel != 4 && kernel != 5) return FailMsg("zmx_set_match_kernel: 0, 2, 3, 4 or 5");
   g_match_kernel.store(kernel, std::memory_order_relaxed);
   return 0;
 }
@@ -734,7 +745,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   HIPCHK(PoolAlloc(c, &t->d_code_base, nb));
   HIPCHK(PoolAlloc(c, &t->d_wtab, nb * ZMX_WTAB));
   HIPCHK(PoolAlloc(c, &t->d_badcodes, nb * 40));
-  HIPCHK(PoolAlloc(c, &t->d_counters, 24));
+  HIPCHK(PoolAlloc(c, &t->d_counters, 48));
   HIPCHK(hipMemcpyAsync(t->d_blocks, t->blocks.data(), nb * sizeof(BlockDesc), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemcpyAsync(t->d_tile_off, tile_off.data(), (nb + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
   HIPCHK(hipMemsetAsync(t->d_flags, 0, 4 * sizeof(u32), c->stream));
@@ -743,7 +754,11 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   PoolScope hash_tmp(c);
   u16* d_lev = nullptr;    // k_levels / k_rank2 (ZOPFLI_AMD_MATCH=5), alive until the match kernel has run
   u16* d_tot2 = nullptr;
+  u16* d_rank2 = nullptr;
   uint4* d_xrec = nullptr;
+  unsigned long long* d_energy = nullptr;   // k_hits (kernel 0 = per block: k_match5 where the chains are long)
+  bool skip_any = false, skip_all = false;  // some / all blocks of this build take k_match5
+  bool join_stream2 = false;
   auto launch_hash = [&](const u64* d_link_lo) -> int {
     if (max_l == 0) return 0;
     const dim3 g1(static_cast<unsigned>((max_l + 256 * SAME_CH - 1) / (256 * SAME_CH)), static_cast<unsigned>(nb));
@@ -765,30 +780,61 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     } else {
       hipLaunchKernelGGL(k_chain, g2, dim3(64), CH_LDS_BYTES, c->stream, c->d_in, t->d_blocks, t->d_same16, t->d_links, d_link_lo);
       KCHK(c, "k_chain");
-      if (mk == 5 && d_link_lo == nullptr) {
-        // the skip-walk's arrays (whole blocks only: a table built from a parent recomputes a few tiles with k_match2)
-        if (!d_lev) HIPCHK(hash_tmp.AllocT(&d_lev, static_cast<size_t>(LV_N) * reg_off, "d_lev"));
-        if (!d_tot2) HIPCHK(hash_tmp.AllocT(&d_tot2, reg_off, "d_tot2"));
-        if (!d_xrec) HIPCHK(hash_tmp.AllocT(&d_xrec, 2 * reg_off, "d_xrec"));
-        LevelParams lp;
-        lp.in = c->d_in;
-        lp.blocks = t->d_blocks;
-        lp.lev = d_lev;
-        lp.total_l = reg_off;
-        const dim3 g4(static_cast<unsigned>((max_l + LV_CH - 1) / LV_CH), static_cast<unsigned>(nb), LV_N);
-        hipLaunchKernelGGL(k_levels, g4, dim3(64), 0, c->stream, lp);
-        KCHK(c, "k_levels");
-        RankParams rp;
-        rp.in = c->d_in;
-        rp.blocks = t->d_blocks;
-        rp.links = t->d_links;
-        rp.lev = d_lev;
-        rp.total_l = reg_off;
-        rp.tot2 = d_tot2;
-        rp.xrec = d_xrec;
-        const dim3 g3(static_cast<unsigned>((max_l + RK_CH - 1) / RK_CH), static_cast<unsigned>(nb));
-        hipLaunchKernelGGL(k_rank2, g3, dim3(64), 0, c->stream, rp);
-        KCHK(c, "k_rank2");
+      if ((mk == 5 || mk == 0) && d_link_lo == nullptr) {
+        // The skip-walk (k_match5) for the blocks whose chains are long: k_hits estimates the hits per position the
+        // reference's walk would make, block by block; kernel 5 forces it for every block.  (Whole blocks only: a
+        // table built from a parent recomputes a few tiles with k_match2.)
+        skip_any = mk == 5;
+        if (mk == 0) {
+          if (!d_energy) HIPCHK(hash_tmp.AllocT(&d_energy, nb, "d_energy"));
+          HIPCHK(hipMemsetAsync(d_energy, 0, nb * sizeof(unsigned long long), c->stream));
+          HitsParams hp;
+          hp.in = c->d_in;
+          hp.blocks = t->d_blocks;
+          hp.same16 = t->d_same16;
+          hp.energy = d_energy;
+          const dim3 g5(static_cast<unsigned>((max_l + RK_CH - 1) / RK_CH), static_cast<unsigned>(nb));
+          hipLaunchKernelGGL(k_hits, g5, dim3(RK_THREADS), 0, c->stream, hp);
+          KCHK(c, "k_hits");
+          std::vector<unsigned long long> energy(nb);
+          HIPCHK(hipMemcpyAsync(energy.data(), d_energy, nb * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(hipStreamSynchronize(c->stream));
+          size_t on = 0;
+          for (size_t b = 0; b < nb; ++b) on += energy[b] > MatchAutoHits() * (t->blocks[b].inend - t->blocks[b].ws) ? 1 : 0;
+          skip_any = on != 0;
+          skip_all = on == nb;
+        }
+        if (skip_any) {
+          if (!d_lev) HIPCHK(hash_tmp.AllocT(&d_lev, static_cast<size_t>(LV_N) * reg_off, "d_lev"));
+          if (!d_tot2) HIPCHK(hash_tmp.AllocT(&d_tot2, reg_off, "d_tot2"));
+          if (!d_rank2) HIPCHK(hash_tmp.AllocT(&d_rank2, reg_off, "d_rank2"));
+          if (!d_xrec) HIPCHK(hash_tmp.AllocT(&d_xrec, 2 * reg_off, "d_xrec"));
+          LevelParams lp;
+          lp.in = c->d_in;
+          lp.blocks = t->d_blocks;
+          lp.lev = d_lev;
+          lp.total_l = reg_off;
+          lp.energy = mk == 0 ? d_energy : nullptr;
+          lp.thr = MatchAutoHits();
+          const dim3 g4(static_cast<unsigned>((max_l + LV_CH - 1) / LV_CH), static_cast<unsigned>(nb), LV_N);
+          hipLaunchKernelGGL(k_levels, g4, dim3(64), 0, c->stream, lp);
+          KCHK(c, "k_levels");
+          RankParams rp;
+          rp.in = c->d_in;
+          rp.blocks = t->d_blocks;
+          rp.links = t->d_links;
+          rp.same16 = t->d_same16;
+          rp.lev = d_lev;
+          rp.total_l = reg_off;
+          rp.tot2 = d_tot2;
+          rp.rank2 = d_rank2;
+          rp.xrec = d_xrec;
+          rp.energy = lp.energy;
+          rp.thr = lp.thr;
+          const dim3 g3(static_cast<unsigned>((max_l + RK_CH - 1) / RK_CH), static_cast<unsigned>(nb));
+          hipLaunchKernelGGL(k_rank2, g3, dim3(RK_THREADS), 0, c->stream, rp);
+          KCHK(c, "k_rank2");
+        }
       }
     }
     return 0;
@@ -850,20 +896,41 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     mp.counters = t->d_counters;
     mp.scratch = c->d_scratch;
     mp.tile_list = d_tiles;
-    if (mk == 5 && d_tiles == nullptr) {
+    mp.skip_energy = nullptr;
+    mp.skip_thr = 0;
+    if ((mk == 5 || mk == 0) && d_tiles == nullptr && skip_any) {
+      if (!c->d_scratch5) HIPCHK(PoolAllocT(c, &c->d_scratch5, static_cast<size_t>(kMatchGrid5) * M5_THREADS * SCRATCH_CPS, "d_scratch5"));
       Match5Params q;
       q.m = mp;
+      q.m.scratch = c->d_scratch5;
       q.xrec = d_xrec;
-      if (prof) hipLaunchKernelGGL((k_match5<true>), dim3(kMatchGrid5), dim3(M5_THREADS), 0, c->stream, q);
-      else hipLaunchKernelGGL((k_match5<false>), dim3(kMatchGrid5), dim3(M5_THREADS), 0, c->stream, q);
-      KCHK(c, "k_match5");
-      return 0;
+      q.energy = mk == 0 ? d_energy : nullptr;
+      q.thr = MatchAutoHits();
+      if (mk == 5 || skip_all) {
+        hipLaunchKernelGGL(k_match5, dim3(kMatchGrid5), dim3(M5_THREADS), 0, c->stream, q);   // (no profile counts: tools/match_skip_model.c has the entries touched)
+        KCHK(c, "k_match5");
+        return 0;
+      }
+      // Some blocks each: k_match5 on the second stream beside k_match2 (which passes over k_match5's blocks) — the
+      // skip-walk of a few heavy blocks is a handful of long-running waves, the rest of the device is k_match2's.
+      HIPCHK(hipEventRecord(c->ev2[0], c->stream));
+      HIPCHK(hipStreamWaitEvent(c->stream2, c->ev2[0], 0));
+      hipLaunchKernelGGL(k_match5, dim3(kMatchGrid5), dim3(M5_THREADS), 0, c->stream2, q);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipEventRecord(c->ev2[1], c->stream2));
+      join_stream2 = true;
+      mp.skip_energy = d_energy;
+      mp.skip_thr = MatchAutoHits();
     }
     const bool filt = MatchFilter();
     if (prof && filt) hipLaunchKernelGGL((k_match2<true, true>), dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
     else if (prof) hipLaunchKernelGGL((k_match2<true, false>), dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
     else if (filt) hipLaunchKernelGGL((k_match2<false, true>), dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
     else hipLaunchKernelGGL((k_match2<false, false>), dim3(kMatchGrid), dim3(M2_THREADS), 0, c->stream, mp);
+    if (join_stream2) {
+      join_stream2 = false;
+      HIPCHK(hipStreamWaitEvent(c->stream, c->ev2[1], 0));
+    }
     KCHK(c, "k_match2");
     return 0;
   };
@@ -892,7 +959,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     KCHK(c, "k_copy_recs");
     HIPCHK(hipGetLastError());
     // the pool cursor continues where the parent's stopped
-    HIPCHK(hipMemsetAsync(t->d_counters, 0, 24 * sizeof(u32), c->stream));
+    HIPCHK(hipMemsetAsync(t->d_counters, 0, 48 * sizeof(u32), c->stream));
     HIPCHK(hipMemcpyAsync(t->d_counters, parent->d_counters, sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
     if (launch_match(parent->d_pool, parent->pool_cap, static_cast<u32>(tile_list.size()), d_tile_list, false) != 0) return -1;
     u32 counters[2] = {0, 0};
@@ -924,13 +991,22 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     t->d_pool = nullptr;
     HIPCHK(PoolAlloc(c, &t->d_pool, cap));
     t->pool_cap = static_cast<u32>(cap);
-    HIPCHK(hipMemsetAsync(t->d_counters, 0, 24 * sizeof(u32), c->stream));
+    HIPCHK(hipMemsetAsync(t->d_counters, 0, 48 * sizeof(u32), c->stream));
     static const bool match_prof = std::getenv("ZOPFLI_AMD_PROF") != nullptr;
     if (launch_match(t->d_pool, t->pool_cap, tile_off[nb], nullptr, match_prof) != 0) return -1;
     u32 counters[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(counters, t->d_counters, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     match_positions += static_cast<double>(pos_off);
+    if (counters[1] & 2u) {
+      u32 dbg[8] = {0};
+      HIPCHK(hipMemcpy(dbg, t->d_counters + 32, sizeof(dbg), hipMemcpyDeviceToHost));
+      char buf[320];
+      std::snprintf(buf, sizeof(buf), "zmx_tables_build: k_match5's wave loop did not end (state %08x xd %u curd %u bestlen %u limit %u nlink %u eqd %u "
+                    "li %u idx %u same %u cur %u bestdist %u)", dbg[0], dbg[1], dbg[2], dbg[3] & 0xffffu, dbg[3] >> 16, dbg[4] & 0xffffu, dbg[4] >> 16,
+                    dbg[5], dbg[6] & 0xffffu, dbg[6] >> 16, dbg[7] & 0xffffu, dbg[7] >> 16);
+      return FailMsg(buf);
+    }
     if ((counters[1] & 1u) == 0) break;
     if (per_pos >= 256) return FailMsg("zmx_tables_build: change-point pool overflow");
     per_pos *= 8;
@@ -951,7 +1027,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
       HIPCHK(hipMemcpy(hc, t->d_counters + 4, sizeof(hc), hipMemcpyDeviceToHost));
       const double pos = static_cast<double>(pos_off);
       std::fprintf(stderr, "%s: %.2f ms for %.0f positions: %.1f chain hits per "
-                   "position, %.1f of 64 lanes with a hit per wave-loop iteration; %.1f SIMD cycles per hit (2.4 GHz, 1024 SIMDs)\n", mk == 5 ? "k_match5 (hits = entries touched)" : mk == 4 ? "k_match4" : mk == 3 ? "k_match3" : "k_match2", ms_match, pos,
+                   "position, %.1f of 64 lanes with a hit per wave-loop iteration; %.1f SIMD cycles per hit (2.4 GHz, 1024 SIMDs)\n", mk == 5 || mk == 0 ? "k_match5 / k_match2 (hits = entries touched)" : mk == 4 ? "k_match4" : mk == 3 ? "k_match3" : "k_match2", ms_match, pos,
                    static_cast<double>(hc[0]) / pos, static_cast<double>(hc[0]) / static_cast<double>(hc[1] ? hc[1] : 1),
                    ms_match * 1e-3 * 2.4e9 * 1024 / static_cast<double>(hc[0] ? hc[0] : 1));
       if (mk == 3) {

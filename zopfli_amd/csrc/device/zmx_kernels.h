@@ -291,6 +291,8 @@ struct MatchParams {
   u32* counters;         // [0] pool cursor, [1] error flags, [8..15] per-XCD tile cursors
   u32* scratch;          // gridDim.x * M2_THREADS * SCRATCH_CPS
   const u32* tile_list;  // optional: the tiles to do (total_tiles entries); null = all of them
+  const unsigned long long* skip_energy;   // optional (k_hits): blocks whose estimate exceeds skip_thr x positions are k_match5's
+  u64 skip_thr;
 };
 
 // (ds_read_u8: the byte itself, no shifting around a 32-bit read)

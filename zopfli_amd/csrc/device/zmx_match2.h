@@ -65,6 +65,7 @@ __global__ __launch_bounds__(M2_THREADS, 8) void k_match2(MatchParams P) {
       if (P.tile_off[mid] <= tile) lo = mid; else hi = mid;
     }
     const BlockDesc bd = P.blocks[lo];
+    if (P.skip_energy && P.skip_energy[lo] > P.skip_thr * (bd.inend - bd.ws)) continue;   // the skip-walk's block (zmx_match5.h)
     const u64 p0 = bd.instart + (u64)(tile - P.tile_off[lo]) * MT;
     const u64 p1 = (p0 + MT < bd.inend) ? p0 + MT : bd.inend;
     const u32 ntile = (u32)(p1 - p0);

@@ -45,29 +45,6 @@ __device__ __forceinline__ int lv_level_for(u32 n) {
 //   0 prev1, 1 prev2, 2 same (k_chain's links)   3 wc2, 4 tot2 (below)   5 unused   6 .. 15 the level links
 #define XR_LV0 6u
 
-struct LvBytes { uint4 a, b; };   // 32 bytes at a position
-
-// the level's key: the first k bytes (masks m[0..6] for bytes 4.., 8.., ...) through multiply-xor rounds, top LV_HBITS bits
-__device__ __forceinline__ u32 lv_key(const LvBytes& w, const u32* m) {
-  u32 h = w.a.x * 0x9E3779B1u;
-  h = (h ^ (w.a.y & m[0])) * 0x85EBCA6Bu;
-  h = (h ^ (w.a.z & m[1])) * 0xC2B2AE35u;
-  h = (h ^ (w.a.w & m[2])) * 0x27D4EB2Fu;
-  h = (h ^ (w.b.x & m[3])) * 0x165667B1u;
-  h = (h ^ (w.b.y & m[4])) * 0xD3A2646Du;
-  h = (h ^ (w.b.z & m[5])) * 0xFD7046C5u;
-  h = (h ^ (w.b.w & m[6])) * 0xB55A4F09u;
-  h ^= h >> 15;
-  h *= 0x2C1B3C6Du;
-  return h >> (32u - LV_HBITS);
-}
-
-__device__ __forceinline__ LvBytes lv_load32(const u8* p) {
-  LvBytes x;
-  __builtin_memcpy(&x, p, 32);     // (unaligned: two global_load_dwordx4)
-  return x;
-}
-
 // wave-wide minimum (every lane gets it)
 __device__ __forceinline__ u32 wave_min_u32(u32 v) {
   const u32 m = wave_scan_max(~v);
@@ -90,59 +67,87 @@ struct LevelParams {
   const BlockDesc* blocks;
   u16* lev;
   u64 total_l;
+  const unsigned long long* energy;   // k_hits (null: every block)
+  u64 thr;
 };
 
-__global__ __launch_bounds__(64) void k_levels(LevelParams P) {
-  __shared__ u32 head[1u << LV_HBITS];
-  const BlockDesc bd = P.blocks[blockIdx.y];
-  const u32 lvl = blockIdx.z;
+// does block b get the skip-walk (k_match5) or the hit-by-hit walk (k_match2)?  k_hits' estimate of the hits per
+// position against the threshold, decided on the device by every kernel that asks
+__device__ __forceinline__ bool m5_block_on(const unsigned long long* energy, u64 thr, u32 b, u64 L) {
+  return energy == nullptr || energy[b] > thr * L;
+}
+
+// NW = dwords of a position's bytes the level's key reads (1, 2, 3, 4, 6 or 8: levels 4 / 5-8 / 10, 12 / 16 / 24 / 32)
+template <u32 NW>
+__device__ __forceinline__ void lv_load(u32 (&w)[NW], const u8* p) {
+  if (NW <= 4) {
+    uint4 x;
+    __builtin_memcpy(&x, p, 16);
+    w[0] = x.x;
+    if (NW > 1) w[1] = x.y;
+    if (NW > 2) w[2] = x.z;
+    if (NW > 3) w[3] = x.w;
+  } else {
+    uint4 x, y;
+    __builtin_memcpy(&x, p, 16);
+    __builtin_memcpy(&y, p + 16, 16);
+    w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w;
+    w[4] = y.x; w[5] = y.y;
+    if (NW > 6) { w[6] = y.z; w[7] = y.w; }
+  }
+}
+template <u32 NW>
+__device__ __forceinline__ u32 lv_key(const u32 (&w)[NW], u32 mlast) {
+  const u32 mul[8] = {0x9E3779B1u, 0x85EBCA6Bu, 0xC2B2AE35u, 0x27D4EB2Fu, 0x165667B1u, 0xD3A2646Du, 0xFD7046C5u, 0xB55A4F09u};
+  u32 h = 0;
+#pragma unroll
+  for (u32 j = 0; j < NW; ++j) h = (h ^ (j + 1 == NW ? w[j] & mlast : w[j])) * mul[j];
+  h ^= h >> 15;
+  h *= 0x2C1B3C6Du;
+  return h >> (32u - LV_HBITS);
+}
+
+template <u32 NW>
+__device__ __forceinline__ void lv_job(const LevelParams& P, const BlockDesc& bd, u32 lvl, u32* head) {
   const u64 L = bd.inend - bd.ws;
   const u64 e0 = (u64)blockIdx.x * LV_CH;
-  if (e0 >= L) return;
-  const u64 e1 = (e0 + LV_CH < L) ? e0 + LV_CH : L;
-  const u64 w0 = e0 >= ZMX_WINDOW ? e0 - ZMX_WINDOW : 0;
+  const u32 n1 = (u32)((e0 + LV_CH < L ? e0 + LV_CH : L) - e0);     // positions to emit
+  const u32 nw = e0 >= ZMX_WINDOW ? ZMX_WINDOW : 0u;                 // warm-up positions before them
   const u32 lane = threadIdx.x;
   const u64 lt_mask = (1ull << lane) - 1;
   const u32 k = kLevelK[lvl];
-  u32 m[7];
-#pragma unroll
-  for (u32 j = 0; j < 7; ++j) {
-    const u32 lo = 4u * (j + 1u);     // the word holds bytes lo .. lo + 3
-    m[j] = k >= lo + 4u ? 0xffffffffu : k > lo ? (1u << (8u * (k - lo))) - 1u : 0u;
-  }
-  for (u32 i = lane; i < (1u << LV_HBITS); i += 64) head[i] = 0;
-  __syncthreads();
-  const u8* base = P.in + bd.ws;
-  u16* out = P.lev + (u64)lvl * P.total_l + bd.reg_off;
+  const u32 mlast = (k & 3u) ? (1u << (8u * (k & 3u))) - 1u : 0xffffffffu;   // the level's last dword holds k mod 4 bytes (or 4)
+  const u8* base = P.in + bd.ws + e0 - nw;                           // job position 0 (uniform: scalar base, 32-bit offsets)
+  u16* out = P.lev + (u64)lvl * P.total_l + bd.reg_off + e0 - nw;
+  const u32 n = nw + n1;
 
-  LvBytes w[LV_U];
+  u32 w[LV_U][NW];
 #pragma unroll
-  for (u32 u = 0; u < LV_U; ++u) w[u] = lv_load32(base + w0 + 64u * u + lane);   // (the input is padded past its end)
-  for (u64 s = w0; s < e1; s += 64u * LV_U) {
+  for (u32 u = 0; u < LV_U; ++u) lv_load<NW>(w[u], base + 64u * u + lane);   // (the input is padded past its end)
+  for (u32 s = 0; s < n; s += 64u * LV_U) {
     u32 key[LV_U], ret[LV_U];
 #pragma unroll
-    for (u32 u = 0; u < LV_U; ++u) key[u] = lv_key(w[u], m);
-    if (s + 64u * LV_U < e1) {
+    for (u32 u = 0; u < LV_U; ++u) key[u] = lv_key<NW>(w[u], mlast);
+    if (s + 64u * LV_U < n) {
 #pragma unroll
-      for (u32 u = 0; u < LV_U; ++u) w[u] = lv_load32(base + s + 64u * (LV_U + u) + lane);   // the next round's bytes
+      for (u32 u = 0; u < LV_U; ++u) lv_load<NW>(w[u], base + s + 64u * (LV_U + u) + lane);   // the next round's bytes
     }
-    const bool warm = s + 64u * LV_U <= e0;      // (e0 - w0 is a multiple of 64 LV_U: a round is all warm-up or none)
+    const bool warm = s + 64u * LV_U <= nw;      // (nw is a multiple of 64 LV_U: a round is all warm-up or none)
 #pragma unroll
     for (u32 u = 0; u < LV_U; ++u) {
-      const u64 p = s + 64u * u + lane;
-      const u32 r = (u32)(p - w0) + 1u;          // 0 = no position yet
+      const u32 q = s + 64u * u + lane;
       ret[u] = 0;
-      if (p < e1) {
-        if (warm) atomicMax(&head[key[u]], r); else ret[u] = atomicMax(&head[key[u]], r);
+      if (q < n) {
+        if (warm) atomicMax(&head[key[u]], q + 1u); else ret[u] = atomicMax(&head[key[u]], q + 1u);   // 0 = no position yet
       }
     }
     if (warm) continue;
 #pragma unroll
     for (u32 u = 0; u < LV_U; ++u) {
-      const u64 p = s + 64u * u + lane;
-      const bool act = p < e1;
-      const u32 r = (u32)(p - w0) + 1u;
-      const u32 step0 = (u32)(s + 64u * u - w0) + 1u;
+      const u32 q = s + 64u * u + lane;
+      const bool act = q < n;
+      const u32 r = q + 1u;
+      const u32 step0 = s + 64u * u + 1u;
       u32 d = ret[u] ? r - ret[u] : 0u;
       u64 F = __ballot(act && ret[u] >= step0);                  // lanes that saw a position of this very step
       while (F) {
@@ -157,35 +162,42 @@ __global__ __launch_bounds__(64) void k_levels(LevelParams P) {
         F &= ~G;
       }
       if (d > 32767u) d = 0;
-      if (act && p >= e0) out[p] = (u16)d;
+      if (act) out[q] = (u16)d;
     }
   }
 }
 
-// ----------------------------------------------------------------------------
-// k_rank2: the position's record for k_match5 — k_chain's links, the level links, and the position's rank within
-// its val2 class (the second hash's chain, hash.c:129-135) per 32768-position chunk of the region:
-//   tot2 = number of positions of the chunk BEFORE the position's with its val2
-//   wc2  = tot2 + number of positions before it in its own chunk with its val2
-// so that the number of chain entries from a member c of pos's class down to a member q (both within 32767 of pos:
-// in pos's chunk or the one before) is g(c) - g(q), g(x) = x in pos's chunk ? wc2[x] : wc2[x] - tot2[x].
-// One wave per (chunk, block); 32768 16-bit counters, two to a word, in LDS (64 KB): a class has at most 32768
-// members in a chunk, so a half never carries into its neighbour.  Three passes: count the chunk before; read
-// those counts for the chunk's positions (tot2); count the chunk itself, a step at a time, the count before the
-// step being the rank of the step's first member of a class — members of one class inside a step (prev2 says so)
-// are ordered with ballots.
-// ----------------------------------------------------------------------------
-#define RK_CH 32768u
-#define RK_U 4u
+__global__ __launch_bounds__(64) void k_levels(LevelParams P) {
+  __shared__ u32 head[1u << LV_HBITS];
+  const BlockDesc bd = P.blocks[blockIdx.y];
+  const u32 lvl = blockIdx.z;
+  const u64 L = bd.inend - bd.ws;
+  if ((u64)blockIdx.x * LV_CH >= L) return;
+  if (!m5_block_on(P.energy, P.thr, blockIdx.y, L)) return;
+  for (u32 i = threadIdx.x; i < (1u << LV_HBITS); i += 64) head[i] = 0;
+  __syncthreads();
+  switch (lvl) {
+    case 0: lv_job<1>(P, bd, lvl, head); break;
+    case 1: case 2: case 3: case 4: lv_job<2>(P, bd, lvl, head); break;
+    case 5: case 6: lv_job<3>(P, bd, lvl, head); break;
+    case 7: lv_job<4>(P, bd, lvl, head); break;
+    case 8: lv_job<6>(P, bd, lvl, head); break;
+    default: lv_job<8>(P, bd, lvl, head); break;
+  }
+}
 
-struct RankParams {
+// ----------------------------------------------------------------------------
+// k_hits: what would the reference's walk cost here?  Sum over the 32768-position chunks of a block's region of the
+// squared sizes of the val2 classes (hash.c:129) = sum over positions of the number of positions of their chunk on
+// their second chain: per position that is the chain length the walk has in front of it — 100 on text, 186 on
+// markup, 2 000 on PNG-like and two-symbol data, 45 on long runs, within a few percent of the hits the
+// instrumented reference counts.  energy[b] > threshold x positions sends block b to the skip-walk.
+// ----------------------------------------------------------------------------
+struct HitsParams {
   const u8* in;
   const BlockDesc* blocks;
-  const ushort4* links;
-  const u16* lev;
-  u64 total_l;
-  u16* tot2;          // scratch, one per region position
-  uint4* xrec;        // out: two per region position
+  const u16* same16;
+  unsigned long long* energy;
 };
 
 __device__ __forceinline__ u32 rk_val2(u32 bytes, u64 p, u64 L, u32 same) {
@@ -198,51 +210,127 @@ __device__ __forceinline__ u32 rk_load_u32(const u8* p) {
   return x;
 }
 
-__global__ __launch_bounds__(64) void k_rank2(RankParams P) {
+#define RK_CH 32768u
+#define RK_THREADS 256u
+
+__global__ __launch_bounds__(RK_THREADS) void k_hits(HitsParams P) {
   __shared__ u32 cnt[16384];
   const BlockDesc bd = P.blocks[blockIdx.y];
   const u64 L = bd.inend - bd.ws;
   const u64 e0 = (u64)blockIdx.x * RK_CH;
   if (e0 >= L) return;
   const u64 e1 = (e0 + RK_CH < L) ? e0 + RK_CH : L;
-  const u32 lane = threadIdx.x;
-  const u64 lt_mask = (1ull << lane) - 1;
+  const u32 tid = threadIdx.x;
   const u8* base = P.in + bd.ws;
-  const ushort4* lk = P.links + bd.reg_off;
-  u16* tt = P.tot2 + bd.reg_off;
-  const u16* lev = P.lev + bd.reg_off;
-  uint4* xr = P.xrec + bd.reg_off * 2;
-
-  for (u32 i = lane; i < 16384; i += 64) cnt[i] = 0;
+  const u16* same = P.same16 + bd.reg_off;
+  for (u32 i = tid; i < 16384; i += RK_THREADS) cnt[i] = 0;
   __syncthreads();
-  if (e0 > 0) {
-    for (u64 s = e0 - RK_CH; s < e0; s += 64u * RK_U) {
-      u32 by[RK_U], sm[RK_U];
+  for (u64 s = e0; s < e1; s += RK_THREADS * 4u) {
+    u32 by[4], sm[4];
 #pragma unroll
-      for (u32 u = 0; u < RK_U; ++u) {
-        const u64 p = s + 64u * u + lane;
-        by[u] = rk_load_u32(base + p);
-        sm[u] = lk[p].z;
-      }
+    for (u32 u = 0; u < 4; ++u) {
+      const u64 p = s + RK_THREADS * u + tid;
+      by[u] = p < e1 ? rk_load_u32(base + p) : 0u;
+      sm[u] = p < e1 ? (u32)same[p] : 0u;
+    }
 #pragma unroll
-      for (u32 u = 0; u < RK_U; ++u) {
-        const u32 key = rk_val2(by[u], s + 64u * u + lane, L, sm[u]);
+    for (u32 u = 0; u < 4; ++u) {
+      const u64 p = s + RK_THREADS * u + tid;
+      if (p < e1) {
+        const u32 key = rk_val2(by[u], p, L, sm[u]);
         atomicAdd(&cnt[key >> 1], 1u << (16u * (key & 1u)));
       }
     }
   }
   __syncthreads();
-  for (u64 s = e0; s < e1; s += 64u * RK_U) {
+  unsigned long long sum = 0;
+  for (u32 i = tid; i < 16384; i += RK_THREADS) {
+    const u32 c = cnt[i];
+    const unsigned long long a = c & 0xffffu, b = c >> 16;
+    sum += a * a + b * b;
+  }
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+  if ((tid & 63u) == 0) atomicAdd(&P.energy[blockIdx.y], sum);
+}
+
+// ----------------------------------------------------------------------------
+// k_rank2: the position's record for k_match5 — k_chain's links, the level links, and the position's rank within
+// its val2 class (the second hash's chain, hash.c:129-135) per 32768-position chunk of the region:
+//   tot2 = number of positions of the chunk BEFORE the position's with its val2
+//   wc2  = tot2 + number of positions before it in its own chunk with its val2
+// so that the number of chain entries from a member c of pos's class down to a member q (both within 32767 of pos:
+// in pos's chunk or the one before) is g(c) - g(q), g(x) = x in pos's chunk ? wc2[x] : wc2[x] - tot2[x].
+// One workgroup per (chunk, block); 32768 16-bit counters, two to a word, in LDS (64 KB): a class has at most 32768
+// members in a chunk, so a half never carries into its neighbour.  Four passes: all waves count the chunk before;
+// all waves read those counts for the chunk's positions (tot2); ONE wave counts the chunk itself in position order,
+// a step of 64 at a time — the count before the step is the rank of the step's first member of a class, members of
+// one class inside a step (prev2 says so) are ordered with ballots; all waves put the records together.
+// ----------------------------------------------------------------------------
+#define RK_U 4u
+
+struct RankParams {
+  const u8* in;
+  const BlockDesc* blocks;
+  const ushort4* links;
+  const u16* same16;
+  const u16* lev;
+  u64 total_l;
+  u16* tot2;          // scratch, one per region position
+  u16* rank2;         // scratch, one per region position
+  uint4* xrec;        // out: two per region position
+  const unsigned long long* energy;
+  u64 thr;
+};
+
+__global__ __launch_bounds__(RK_THREADS) void k_rank2(RankParams P) {
+  __shared__ u32 cnt[16384];
+  const BlockDesc bd = P.blocks[blockIdx.y];
+  const u64 L = bd.inend - bd.ws;
+  const u64 e0 = (u64)blockIdx.x * RK_CH;
+  if (e0 >= L) return;
+  if (!m5_block_on(P.energy, P.thr, blockIdx.y, L)) return;
+  const u64 e1 = (e0 + RK_CH < L) ? e0 + RK_CH : L;
+  const u32 tid = threadIdx.x;
+  const u32 lane = tid & 63u;
+  const u64 lt_mask = (1ull << lane) - 1;
+  const u8* base = P.in + bd.ws;
+  const ushort4* lk = P.links + bd.reg_off;
+  const u16* same = P.same16 + bd.reg_off;
+  u16* tt = P.tot2 + bd.reg_off;
+  u16* rk = P.rank2 + bd.reg_off;
+  const u16* lev = P.lev + bd.reg_off;
+  uint4* xr = P.xrec + bd.reg_off * 2;
+
+  for (u32 i = tid; i < 16384; i += RK_THREADS) cnt[i] = 0;
+  __syncthreads();
+  if (e0 > 0) {
+    for (u64 s = e0 - RK_CH; s < e0; s += RK_THREADS * RK_U) {
+      u32 by[RK_U], sm[RK_U];
+#pragma unroll
+      for (u32 u = 0; u < RK_U; ++u) {
+        const u64 p = s + RK_THREADS * u + tid;
+        by[u] = rk_load_u32(base + p);
+        sm[u] = same[p];
+      }
+#pragma unroll
+      for (u32 u = 0; u < RK_U; ++u) {
+        const u32 key = rk_val2(by[u], s + RK_THREADS * u + tid, L, sm[u]);
+        atomicAdd(&cnt[key >> 1], 1u << (16u * (key & 1u)));
+      }
+    }
+  }
+  __syncthreads();
+  for (u64 s = e0; s < e1; s += RK_THREADS * RK_U) {
     u32 by[RK_U], sm[RK_U];
 #pragma unroll
     for (u32 u = 0; u < RK_U; ++u) {
-      const u64 p = s + 64u * u + lane;
+      const u64 p = s + RK_THREADS * u + tid;
       by[u] = p < e1 ? rk_load_u32(base + p) : 0u;
-      sm[u] = p < e1 ? (u32)lk[p].z : 0u;
+      sm[u] = p < e1 ? (u32)same[p] : 0u;
     }
 #pragma unroll
     for (u32 u = 0; u < RK_U; ++u) {
-      const u64 p = s + 64u * u + lane;
+      const u64 p = s + RK_THREADS * u + tid;
       if (p < e1) {
         const u32 key = rk_val2(by[u], p, L, sm[u]);
         tt[p] = (u16)(cnt[key >> 1] >> (16u * (key & 1u)));
@@ -250,48 +338,66 @@ __global__ __launch_bounds__(64) void k_rank2(RankParams P) {
     }
   }
   __syncthreads();
-  for (u32 i = lane; i < 16384; i += 64) cnt[i] = 0;
+  for (u32 i = tid; i < 16384; i += RK_THREADS) cnt[i] = 0;
   __syncthreads();
-  for (u64 s = e0; s < e1; s += 128) {
-    // two steps' loads in flight
+  if (tid < 64) {
+    for (u64 s = e0; s < e1; s += 64u * RK_U) {
+      u32 by[RK_U], sm[RK_U], d2[RK_U];
+#pragma unroll
+      for (u32 u = 0; u < RK_U; ++u) {
+        const u64 p = s + 64u * u + lane;
+        const bool act = p < e1;
+        by[u] = act ? rk_load_u32(base + p) : 0u;
+        sm[u] = act ? (u32)same[p] : 0u;
+        d2[u] = act ? (u32)lk[p].y : 0u;
+      }
+#pragma unroll
+      for (u32 u = 0; u < RK_U; ++u) {
+        const u64 p = s + 64u * u + lane;
+        const bool act = p < e1;
+        const u32 key = act ? rk_val2(by[u], p, L, sm[u]) : 0u;
+        u32 rank = act ? (cnt[key >> 1] >> (16u * (key & 1u))) & 0xffffu : 0u;   // the state before this step
+        wave_lds_sync();
+        if (act) atomicAdd(&cnt[key >> 1], 1u << (16u * (key & 1u)));
+        // positions of this step with the same key: the previous member of the class lies inside the step
+        const bool dup = act && d2[u] != 0 && d2[u] <= lane;
+        if (__any(dup)) {
+          u64 grp = __ballot(act);
+#pragma unroll
+          for (int bit = 0; bit < 15; ++bit) {
+            const bool mine = (key >> bit) & 1;
+            const u64 bm = __ballot(mine);
+            grp &= mine ? bm : ~bm;
+          }
+          rank += (u32)__popcll(grp & lt_mask);
+        }
+        wave_lds_sync();
+        if (act) rk[p] = (u16)rank;
+      }
+    }
+  }
+  __syncthreads();
+  for (u64 s = e0; s < e1; s += RK_THREADS * 2u) {
     ushort4 l4[2];
-    u32 by[2], tot[2];
+    u32 tot[2], rnk[2];
     u32 lv[2][LV_N];
 #pragma unroll
     for (u32 u = 0; u < 2; ++u) {
-      const u64 p = s + 64u * u + lane;
+      const u64 p = s + RK_THREADS * u + tid;
       const bool act = p < e1;
       l4[u] = act ? lk[p] : make_ushort4(0, 0, 0, 0);
-      by[u] = act ? rk_load_u32(base + p) : 0u;
       tot[u] = act ? (u32)tt[p] : 0u;
+      rnk[u] = act ? (u32)rk[p] : 0u;
 #pragma unroll
       for (u32 j = 0; j < LV_N; ++j) lv[u][j] = act ? (u32)lev[(u64)j * P.total_l + p] : 0u;
     }
 #pragma unroll
     for (u32 u = 0; u < 2; ++u) {
-      const u64 p = s + 64u * u + lane;
-      const bool act = p < e1;
-      const u32 key = act ? rk_val2(by[u], p, L, l4[u].z) : 0u;
-      u32 rank = act ? (cnt[key >> 1] >> (16u * (key & 1u))) & 0xffffu : 0u;   // the state before this step
-      wave_lds_sync();
-      if (act) atomicAdd(&cnt[key >> 1], 1u << (16u * (key & 1u)));
-      // positions of this step with the same key: the previous member of the class lies inside the step
-      const bool dup = act && l4[u].y != 0 && l4[u].y <= lane;
-      if (__any(dup)) {
-        u64 grp = __ballot(act);
-#pragma unroll
-        for (int bit = 0; bit < 15; ++bit) {
-          const bool mine = (key >> bit) & 1;
-          const u64 bm = __ballot(mine);
-          grp &= mine ? bm : ~bm;
-        }
-        rank += (u32)__popcll(grp & lt_mask);
-      }
-      wave_lds_sync();
-      if (act) {
+      const u64 p = s + RK_THREADS * u + tid;
+      if (p < e1) {
         uint4 a, b;
         a.x = (u32)l4[u].x | ((u32)l4[u].y << 16);
-        a.y = (u32)l4[u].z | (((tot[u] + rank) & 0xffffu) << 16);
+        a.y = (u32)l4[u].z | (((tot[u] + rnk[u]) & 0xffffu) << 16);
         a.z = tot[u];
         a.w = lv[u][0] | (lv[u][1] << 16);
         b.x = lv[u][2] | (lv[u][3] << 16);
@@ -306,18 +412,26 @@ __global__ __launch_bounds__(64) void k_rank2(RankParams P) {
 }
 
 // ----------------------------------------------------------------------------
-// k_match5
+// k_match5.  A wave owns a 2048-position tile at a time and its lanes take the tile's positions one after the other;
+// nothing is staged in LDS: a walk touches ~10 entries, the 32 KiB window of bytes k_match2 stages per tile would
+// be read ~40 times per position staged, and with it goes the tile's barrier — k_match2's lanes wait for the
+// tile's longest walk (4 positions a lane), here a lane waits only at the end of its wave's tile (32 positions a
+// lane).  Per entry the lane has in flight together: the entry's record (16 + 8 bytes), the 4 bytes the filter
+// tests and the entry's first 16 bytes; the position's own first 16 bytes stay in registers, so a common prefix
+// of up to 15 bytes — most of them — is decided in the iteration the entry arrives in.
 // ----------------------------------------------------------------------------
 struct Match5Params {
   MatchParams m;
   const uint4* xrec;     // k_rank2: two per region position
+  const unsigned long long* energy;   // k_hits (null: every block)
+  u64 thr;
 };
 
-#define M5_THREADS 512
+#define M5_THREADS 256
 #define M5_BATCH 8u     // lanes that wait for a record write / a new position before the wave serves them
 #define M5_IDLE 0u
 #define M5_WALK 1u      // the loads of the entry at distance xd are in flight
-#define M5_CMP 2u
+#define M5_CMP 2u       // 16 more bytes of both sides are in flight
 #define M5_PEND 3u
 #define M5_DONE 4u
 
@@ -326,28 +440,42 @@ __device__ __forceinline__ u32 m5_pick(uint2 v, u32 j) {
   const u32 w = j & 2u ? v.y : v.x;
   return j & 1u ? w >> 16 : w & 0xffffu;
 }
+__device__ __forceinline__ uint4 m5_load16(const u8* p) {
+  uint4 x;
+  __builtin_memcpy(&x, p, 16);
+  return x;
+}
+__device__ __forceinline__ u32 m5_load4(const u8* p) {
+  u32 x;
+  __builtin_memcpy(&x, p, 4);
+  return x;
+}
+// number of equal leading bytes of two 16-byte strings
+__device__ __forceinline__ u32 m5_lcp16(uint4 a, uint4 b) {
+  const u64 lo = ((u64)(a.y ^ b.y) << 32) | (a.x ^ b.x), hi = ((u64)(a.w ^ b.w) << 32) | (a.z ^ b.z);
+  return lo ? (u32)(__ffsll((unsigned long long)lo) - 1) >> 3 : hi ? 8u + ((u32)(__ffsll((unsigned long long)hi) - 1) >> 3) : 16u;
+}
 
-template <bool PROF>
-__global__ __launch_bounds__(M5_THREADS, 6) void k_match5(Match5Params Q) {
+__global__ __launch_bounds__(M5_THREADS, 5) void k_match5(Match5Params Q) {
   const MatchParams& P = Q.m;
-  __shared__ __align__(16) u32 win[MWIN_BYTES / 4 + 4];
   __shared__ u32 s_cp[8 * M5_THREADS];       // the first 8 change points of every lane's position (len | dist << 16), slot-major
-  __shared__ u32 s_next, s_tile;
 
   const u32 tid = threadIdx.x;
+  const u32 lane = tid & 63u;
+  const u64 lt_mask = (1ull << lane) - 1;
   const u32 xcd = blockIdx.x & 7;
   u32* my_scratch = P.scratch + ((u64)blockIdx.x * M5_THREADS + tid) * SCRATCH_CPS;
 
   for (;;) {
-    __syncthreads();
-    if (tid == 0) {
-      const u32 k = atomicAdd(&P.counters[8 + xcd], 1u);
-      s_tile = ((k / M_XCD_GROUP) * 8u + xcd) * M_XCD_GROUP + (k % M_XCD_GROUP);
-      s_next = 0;
-    }
-    __syncthreads();
-    if (s_tile >= P.total_tiles) break;
-    const u32 tile = P.tile_list ? P.tile_list[s_tile] : s_tile;
+    // a wave takes a quarter of a 2048-position tile at a time (its own cursors: k_match2 may run beside it): a tile
+    // of two-symbol data is seconds of one wave's dependent loads, and the kernel ends with its last wave
+    u32 tk = 0;
+    if (lane == 0) tk = atomicAdd(&P.counters[24 + xcd], 1u);
+    tk = (u32)__builtin_amdgcn_readfirstlane((int)tk);
+    const u32 q_idx = ((tk / (4u * M_XCD_GROUP)) * 8u + xcd) * (4u * M_XCD_GROUP) + (tk % (4u * M_XCD_GROUP));
+    const u32 t_idx = q_idx >> 2;
+    if (t_idx >= P.total_tiles) break;
+    const u32 tile = P.tile_list ? P.tile_list[t_idx] : t_idx;
 
     u32 lo = 0, hi = P.nb;
     while (hi - lo > 1) {
@@ -355,37 +483,34 @@ __global__ __launch_bounds__(M5_THREADS, 6) void k_match5(Match5Params Q) {
       if (P.tile_off[mid] <= tile) lo = mid; else hi = mid;
     }
     const BlockDesc bd = P.blocks[lo];
-    const u64 p0 = bd.instart + (u64)(tile - P.tile_off[lo]) * MT;
-    const u64 p1 = (p0 + MT < bd.inend) ? p0 + MT : bd.inend;
+    if (!m5_block_on(Q.energy, Q.thr, lo, bd.inend - bd.ws)) continue;     // k_match2's block
+    const u64 p0 = bd.instart + (u64)(tile - P.tile_off[lo]) * MT + (u64)(q_idx & 3u) * (MT / 4u);
+    if (p0 >= bd.inend) continue;
+    const u64 p1 = (p0 + MT / 4u < bd.inend) ? p0 + MT / 4u : bd.inend;
     const u32 ntile = (u32)(p1 - p0);
 
-    const long long wb = ((long long)p0 - (long long)ZMX_WINDOW) & ~15ll;
-    const u64 hi_abs = (p1 + ZMX_MAX_MATCH < bd.inend) ? p1 + ZMX_MAX_MATCH : bd.inend;
-    const u32 nvec = (u32)(((long long)hi_abs - wb + 15) >> 4);
-    for (u32 v = tid; v < nvec; v += M5_THREADS) {
-      const long long a = wb + (long long)v * 16;
-      uint4 x = make_uint4(0, 0, 0, 0);
-      if (a >= 0) x = *reinterpret_cast<const uint4*>(P.in + a);
-      reinterpret_cast<uint4*>(win)[v] = x;
-    }
-    __syncthreads();
-
-    const u8* xr;      // the records of the block's region, as bytes (scalar base, 32-bit lane offsets)
+    // scalar bases, 32-bit lane offsets: region position li -> its record, its bytes
+    const u8* xr;
+    const u8* inr;
     {
       const u64 a = reinterpret_cast<u64>(Q.xrec + bd.reg_off * 2);
       const u32 alo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)a), ahi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(a >> 32));
       xr = reinterpret_cast<const u8*>(((u64)ahi << 32) | alo);
+      const u64 b = reinterpret_cast<u64>(P.in + bd.ws);
+      const u32 blo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)b), bhi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(b >> 32));
+      inr = reinterpret_cast<const u8*>(((u64)bhi << 32) | blo);
     }
     const u32 li0 = (u32)(p0 - bd.ws);
-    const u32 lp0 = (u32)((long long)p0 - wb);
     const u32 rem0 = (u32)((bd.inend - p0 < 70000) ? bd.inend - p0 : 70000);
     u32* const rec0 = P.recs + (bd.pos_off + (p0 - bd.instart)) * 8;
+    u32 qnext = 0;                 // next position of the tile nobody has taken (wave-uniform)
 
     // ---- per-lane walk state
     u32 st = M5_IDLE;
-    u32 lp = 0, li = 0;
+    u32 li = 0, ti = 0;            // region index of the position, its index in the tile
     u32 limit = 0, bestlen = 0, bestdist = 0, ncp = 0, same_pos = 0, cur = 0, size_rem = 0;
     u32 byte0 = 0, pbyte = 0, foff = 0, fmask = 0;
+    uint4 P0 = make_uint4(0, 0, 0, 0);  // the position's first 16 bytes
     u32 chain = 1, idx = 0;        // idx: candidates the reference has visited so far (lz77.c:527-530 stops at 8192)
     u32 curd = 0;                  // distance of the last visited candidate (0: none yet)
     u32 cprev = 0;                 // its prev1 | prev2 << 16 (raw steps follow them)
@@ -397,8 +522,11 @@ __global__ __launch_bounds__(M5_THREADS, 6) void k_match5(Match5Params Q) {
     uint4 A = make_uint4(0, 0, 0, 0);   // its record: prev1 | prev2, same | wc2, tot2, (lv0 | lv1)
     uint2 V = make_uint2(0, 0);    // four of its level links, from level vb on
     u32 vb = 0;
+    u32 F = 0;                     // its bytes foff .. foff + 3
+    uint4 C0 = make_uint4(0, 0, 0, 0);  // its first 16 bytes; in M5_CMP: 16 bytes of the entry and (PA) of the position from `cur` on
+    uint4 PA = make_uint4(0, 0, 0, 0);
     u32 plv0 = 0, plv1 = 0, plv2 = 0, plv3 = 0, plv4 = 0;   // the position's own level links (lv0|lv1, lv2|lv3, ...)
-    u32 n_touch = 0, n_iter = 0;
+    u32 n_iter = 0;
 
     // the entry the walk touches next: false = the walk is over (end of the chain, window, lz77.c:464, :521-523)
     auto next_entry = [&]() -> bool {
@@ -419,9 +547,12 @@ __global__ __launch_bounds__(M5_THREADS, 6) void k_match5(Match5Params Q) {
         vb = lev_k > 6 ? 6u : (u32)lev_k;
       }
       if (xd >= ZMX_WINDOW) return false;
-      const u8* r = xr + (u64)(li - xd) * 32u;
+      const u32 e = li - xd;
+      const u8* r = xr + (u64)e * 32u;
       A = *reinterpret_cast<const uint4*>(r);
       __builtin_memcpy(&V, r + 2u * (XR_LV0 + vb), 8);
+      F = m5_load4(inr + e + foff);
+      C0 = m5_load16(inr + e);
       return true;
     };
     auto pos_link = [&](u32 k) -> u32 {
@@ -498,23 +629,26 @@ __global__ __launch_bounds__(M5_THREADS, 6) void k_match5(Match5Params Q) {
               r0.w = 0;
             }
           }
-          u32* const rec = rec0 + (u64)(lp - lp0) * 8;
+          u32* const rec = rec0 + (u64)ti * 8;
           reinterpret_cast<uint4*>(rec)[0] = r0;
           reinterpret_cast<uint4*>(rec)[1] = r1;
         }
+        // the lanes without a position take the tile's next ones, in lane order
+        const u64 m_idle = __ballot(st == M5_IDLE);
         if (st == M5_IDLE) {
-          const u32 i = atomicAdd(&s_next, 1u);
+          const u32 i = qnext + (u32)__popcll(m_idle & lt_mask);
           if (i >= ntile) {
             st = M5_DONE;
           } else {
-            lp = lp0 + i;
+            ti = i;
             li = li0 + i;
             size_rem = rem0 - i;
             u32* const rec = rec0 + (u64)i * 8;
             const uint4* rp = reinterpret_cast<const uint4*>(xr + (u64)li * 32u);
             const uint4 Ap = rp[0], Bp = rp[1];
+            P0 = m5_load16(inr + li);
             same_pos = Ap.y & 0xffffu;
-            byte0 = lds_byte(win, lp);
+            byte0 = P0.x & 255u;
             ncp = 0;
             bestlen = 1; bestdist = 0; chain = 1; idx = 0; curd = 0; lev_k = -1; need_link = false;
             if (size_rem < 3) {                      // lz77.c:440-446
@@ -528,13 +662,14 @@ __global__ __launch_bounds__(M5_THREADS, 6) void k_match5(Match5Params Q) {
                 rec[1] = same_pos | (byte0 << 16);
               } else {
                 plv0 = Ap.w; plv1 = Bp.x; plv2 = Bp.y; plv3 = Bp.z; plv4 = Bp.w;
-                pbyte = m2_lds_u32(win, lp); foff = 0; fmask = 0xffffu;   // bestlength 1: bytes 0 and 1
+                pbyte = P0.x; foff = 0; fmask = 0xffffu;   // bestlength 1: bytes 0 and 1
                 next_entry();                        // (prev1 < 32768: always an entry)
                 st = M5_WALK;
               }
             }
           }
         }
+        qnext += (u32)__popcll(m_idle);
         continue;
       }
       if (m_run == 0) {
@@ -547,93 +682,116 @@ __global__ __launch_bounds__(M5_THREADS, 6) void k_match5(Match5Params Q) {
       bool fin = false;            // the walk of this lane is over
       bool moved = false;          // this iteration ended with a decision: fetch the next entry
       bool visited = false;        // the entry is a candidate the reference visits (and it is not longer than the best)
-      bool pass = false;
-      if (PROF) { n_touch += walk ? 1u : 0u; ++n_iter; }
+      bool ended = false;          // the common prefix with the entry is known: cur
+      // A wave-loop that does not end would hang the device: far beyond what a tile can take (32 positions a lane,
+      // at most 8192 hits each), the tile is given up, the state of a running lane goes to counters[16..23] and
+      // the host fails the build.
+      if (++n_iter > (1u << 20)) {
+        atomicOr(&P.counters[1], 2u);
+        {
+          const u64 mr = __ballot(st == M5_WALK || st == M5_CMP);
+          const u32 l0 = mr ? (u32)__ffsll((unsigned long long)mr) - 1u : 0u;
+          if (lane == l0 && atomicCAS(&P.counters[32], 0u, 0x80000000u | st | (chain << 4) | ((u32)(lev_k + 1) << 8) | ((need_link ? 1u : 0u) << 12) | (vb << 16)) == 0u) {
+            P.counters[33] = xd; P.counters[34] = curd; P.counters[35] = bestlen | (limit << 16); P.counters[36] = nlink | (eqd << 16);
+            P.counters[37] = li; P.counters[38] = idx | (same_pos << 16); P.counters[39] = cur | (bestdist << 16);
+          }
+        }
+        break;
+      }
       if (walk) {
-        if (lev_k >= 0 && need_link) {               // the link of the entry point itself
-          need_link = false;
+        bool cand = true;
+        if (lev_k >= 0) {
           nlink = m5_pick(V, (u32)lev_k - vb);
-          moved = true;
-        } else {
-          bool cand = true;
-          if (lev_k >= 0) {
+          if (need_link) {                           // the link of the entry point itself
+            need_link = false;
+            cand = false; moved = true;
+          } else {
             eqd = xd;
-            nlink = m5_pick(V, (u32)lev_k - vb);
             if (xd <= curd) { cand = false; moved = true; }   // at or above the last visited candidate (entered at pos)
           }
-          if (cand) {
-            const u32 cw = m2_lds_u32(win, lp - xd + foff);
-            pass = ((cw ^ pbyte) & fmask) == 0;
-            if (!pass) {
-              if (lev_k < 0) visited = true; else moved = true;
-            }
-          }
         }
-      }
-      if (pass) {
-        cur = 0;
-        if (same_pos > 2 && lds_byte(win, lp - xd) == byte0) {     // lz77.c:481-490
-          const u32 lz = A.y & 0xffffu;
-          const u32 s = same_pos < lz ? same_pos : lz;
-          cur = s < limit ? s : limit;
-        }
-        st = M5_CMP;
-      }
-      if (st == M5_CMP) {
-        const u32 rem = limit - cur;
-        bool end = rem == 0;
-        if (!end) {
-          const u64 x = m2_lds_u64(win, lp + cur) ^ m2_lds_u64(win, lp - xd + cur);
-          u32 m = x ? (u32)(__ffsll((unsigned long long)x) - 1) >> 3 : 8u;
-          if (m > rem) m = rem;
-          cur += m;
-          end = m < 8 || cur >= limit;
-        }
-        if (end) {
-          st = M5_WALK;
-          if (cur > bestlen) {
-            // a longer match: is it a candidate the reference visits, and which one?
-            bool ok = true;
-            u32 hops = 1;
-            // g on the second chain (k_rank2): positions of pos's chunk count from the chunk before's total
-            const u32 gx = ((li - xd) >> 15 == li >> 15 ? A.y >> 16 : (A.y >> 16) - A.z) & 0xffffu;
-            if (chain == 2 && lev_k >= 0) {
-              ok = (((A.y & 0xffffu) - 3u) & 255u) == ((same_pos - 3u) & 255u);   // of the position's val2 class
-              hops = (gcur - gx) & 0xffffu;
-            }
-            if (!ok) {
-              moved = true;                        // not on the second chain: never visited
-            } else if (idx + hops > ZMX_MAX_CHAIN_HITS) {
-              fin = true;                          // beyond the 8192nd candidate (lz77.c:527-530)
-            } else {
-              idx += hops;
-              if (cur >= 3) {
-                if (ncp < 8) s_cp[ncp * M5_THREADS + tid] = cur | (xd << 16);
-                else if (ncp < SCRATCH_CPS) my_scratch[ncp] = cur | (xd << 16);
-                ++ncp;
-              }
-              bestlen = cur;
-              bestdist = xd;
-              foff = cur >= 3 ? cur - 3u : 0u;
-              fmask = cur >= 3 ? 0xffffffffu : 0xffffffu;
-              pbyte = m2_lds_u32(win, lp + foff);
-              curd = xd;
-              cprev = A.x;
-              gcur = gx;
-              if (cur >= limit) {
-                fin = true;                        // lz77.c:500-502
-              } else {
-                // lz77.c:509-519 (on chain 1 the 3-byte hashes are equal: val2 equality is equality of (same - 3) & 255)
-                if (chain == 1 && bestlen >= same_pos && (((A.y & 0xffffu) - 3u) & 255u) == ((same_pos - 3u) & 255u)) chain = 2;
-                choose_level(true);
-                moved = true;
-              }
-            }
-          } else if (lev_k < 0) {
-            visited = true;                        // compared, not longer
+        if (cand) {
+          if (((F ^ pbyte) & fmask) != 0) {          // cannot be longer than bestlength (lz77.c:478-479, 494)
+            if (lev_k < 0) visited = true; else moved = true;
           } else {
-            moved = true;
+            const u32 l16 = m5_lcp16(P0, C0);
+            if (l16 < 16u) {
+              cur = l16 < limit ? l16 : limit;
+              ended = true;
+            } else {
+              cur = 16;
+              if (same_pos > 2 && (C0.x & 255u) == byte0) {     // lz77.c:481-490
+                const u32 lz = A.y & 0xffffu;
+                const u32 sm = same_pos < lz ? same_pos : lz;
+                if (sm > cur) cur = sm;
+              }
+              if (cur >= limit) {
+                cur = limit;
+                ended = true;
+              } else {
+                PA = m5_load16(inr + li + cur);
+                C0 = m5_load16(inr + li - xd + cur);
+                st = M5_CMP;
+              }
+            }
           }
+        }
+      } else if (st == M5_CMP) {
+        const u32 rem = limit - cur;
+        u32 m = m5_lcp16(PA, C0);
+        if (m > rem) m = rem;
+        cur += m;
+        if (m < 16u || cur >= limit) {
+          ended = true;
+          st = M5_WALK;
+        } else {
+          PA = m5_load16(inr + li + cur);
+          C0 = m5_load16(inr + li - xd + cur);
+        }
+      }
+      if (ended) {
+        if (cur > bestlen) {
+          // a longer match: is it a candidate the reference visits, and which one?
+          bool ok = true;
+          u32 hops = 1;
+          // g on the second chain (k_rank2): positions of pos's chunk count from the chunk before's total
+          const u32 gx = ((li - xd) >> 15 == li >> 15 ? A.y >> 16 : (A.y >> 16) - A.z) & 0xffffu;
+          if (chain == 2 && lev_k >= 0) {
+            ok = (((A.y & 0xffffu) - 3u) & 255u) == ((same_pos - 3u) & 255u);   // of the position's val2 class
+            hops = (gcur - gx) & 0xffffu;
+          }
+          if (!ok) {
+            moved = true;                        // not on the second chain: never visited
+          } else if (idx + hops > ZMX_MAX_CHAIN_HITS) {
+            fin = true;                          // beyond the 8192nd candidate (lz77.c:527-530)
+          } else {
+            idx += hops;
+            if (cur >= 3) {
+              if (ncp < 8) s_cp[ncp * M5_THREADS + tid] = cur | (xd << 16);
+              else if (ncp < SCRATCH_CPS) my_scratch[ncp] = cur | (xd << 16);
+              ++ncp;
+            }
+            bestlen = cur;
+            bestdist = xd;
+            foff = cur >= 3 ? cur - 3u : 0u;
+            fmask = cur >= 3 ? 0xffffffffu : 0xffffffu;
+            pbyte = m5_load4(inr + li + foff);   // (arrives with the next entry)
+            curd = xd;
+            cprev = A.x;
+            gcur = gx;
+            if (cur >= limit) {
+              fin = true;                        // lz77.c:500-502
+            } else {
+              // lz77.c:509-519 (on chain 1 the 3-byte hashes are equal: val2 equality is equality of (same - 3) & 255)
+              if (chain == 1 && bestlen >= same_pos && (((A.y & 0xffffu) - 3u) & 255u) == ((same_pos - 3u) & 255u)) chain = 2;
+              choose_level(true);
+              moved = true;
+            }
+          }
+        } else if (lev_k < 0) {
+          visited = true;                        // compared, not longer
+        } else {
+          moved = true;
         }
       }
       if (visited) {
@@ -654,10 +812,6 @@ __global__ __launch_bounds__(M5_THREADS, 6) void k_match5(Match5Params Q) {
       }
       if (moved && !fin) fin = !next_entry();
       if (fin) st = M5_PEND;
-    }
-    if (PROF) {
-      atomicAdd(reinterpret_cast<unsigned long long*>(P.counters + 4), (unsigned long long)n_touch);
-      if ((tid & 63) == 0) atomicAdd(reinterpret_cast<unsigned long long*>(P.counters + 6), (unsigned long long)n_iter);
     }
   }
 }

@@ -272,7 +272,10 @@ void zmx_dist_destroy(zmx_dist* dist);
 int zmx_dist_gather(zmx_dist* dist, const unsigned char* blob, size_t size, unsigned char** gathered,
                     size_t* sizes);
 
-/* Timing breakdown of the last Zopfli* / zmx_deflate_range call on this
+/* (The kernel, match and task statistics below are process-wide sums reset when a Zopfli* / zmx_deflate_range call
+ * starts: with concurrent callers they mix the callers' numbers.)
+ *
+ * Timing breakdown of the last Zopfli* / zmx_deflate_range call on this
  * thread: seconds spent in [0] match tables [1] greedy [2] squeeze runs
  * [3] host cost model [4] block split [5] encode [6] the chain kernels of the squeeze runs (k_dp5_spec,
  * k_dpcheck, k_dpscan, k_dp4_fix: GetBestLengths; HIP events on the launch stream) [7] squeeze runs launched.
@@ -294,9 +297,21 @@ int zmx_last_host_timing(double* out2);
  * the match kernel computed (the others were copied from the parent tables). */
 int zmx_last_match_timing(double* out4);
 
+/* Several contexts on one device (the Zopfli* entry points keep up to three per device): a context's budgets — what its
+ * pool keeps cached between batches, what one batch's DP edges may take — are a third of the device's free memory at
+ * creation divided by `contexts_on_device`; zmx_ctx_trim_cache gives an IDLE context's cached arrays back to the
+ * device; the hook (one per process, may be null) is called with the device index when an allocation still fails
+ * after the failing context dropped its own cache — the owner of the contexts trims the idle ones there — and the
+ * allocation is tried once more. */
+typedef void (*zmx_oom_hook_t)(int device);
+void zmx_set_oom_hook(zmx_oom_hook_t hook);
+int zmx_ctx_set_share(zmx_ctx* ctx, unsigned contexts_on_device);
+int zmx_ctx_trim_cache(zmx_ctx* ctx);
+
 /* Which match-table kernel the table builds that START after this call use (the ZOPFLI_AMD_MATCH environment
- * variable sets the initial choice): 2 = k_chain + k_match2, 3 / 4 = k_bucket + k_match3 / k_match4, 5 = k_chain +
- * k_rank2 + k_levels + k_match5 (the exact skip-walk).  All produce the same records; an A/B and test hook. */
+ * variable sets the initial choice): 0 = per block, k_match5 where k_hits estimates long chains, k_match2 elsewhere
+ * (the default), 2 = k_chain + k_match2, 3 / 4 = k_bucket + k_match3 / k_match4, 5 = k_chain + k_levels + k_rank2 +
+ * k_match5 (the exact skip-walk) for every block.  All produce the same records; an A/B and test hook. */
 int zmx_set_match_kernel(int kernel);
 
 /* The chain's tasks (GetBestLengths cut into verified stretches, zmx_dp4.h) since the last Zopfli* /

@@ -65,6 +65,11 @@ void zmx_internal_kernel_stats(double* a, double* b, int) { a[0] = a[1] = a[2] =
 void zmx_internal_seg_stats(double* a, int) { for (int i = 0; i < 8; ++i) a[i] = 0; }
 void zmx_internal_match_stats(double* a, int) { for (int i = 0; i < 4; ++i) a[i] = 0; }
 int zmx_hash_links_download(zmx_ctx*, zmx_tables*, size_t, uint16_t*, uint16_t*, uint16_t*) { g_err = "not in the host test library"; return -1; }
+int zmx_match_digest(zmx_ctx*, zmx_tables*, uint64_t*) { g_err = "not in the host test library"; return -1; }
+int zmx_set_match_kernel(int) { return 0; }   // (no kernels here)
+void zmx_set_oom_hook(zmx_oom_hook_t) {}
+int zmx_ctx_set_share(zmx_ctx*, unsigned) { return 0; }
+int zmx_ctx_trim_cache(zmx_ctx*) { return 0; }
 // (the RCCL gather of dist.cc is not part of the host-logic test library)
 int zmx_dist_unique_id(unsigned char*) { g_err = "no RCCL in the host test library"; return -1; }
 int zmx_dist_init(zmx_ctx*, int, int, const unsigned char*, zmx_dist**) { g_err = "no RCCL in the host test library"; return -1; }

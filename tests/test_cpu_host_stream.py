@@ -301,7 +301,7 @@ def test_checksum_pieces_and_combine(host):
 
 def test_concurrent_callers():
     """The reference has no globals: concurrent calls on distinct buffers are allowed.  Here a request
-    takes one of a device's contexts (api.cc ContextPool: ZOPFLI_AMD_LANES of them per device, two by default) and
+    takes one of a device's contexts (api.cc ContextPool: ZOPFLI_AMD_LANES of them per device, three by default) and
     other callers overlap with it or wait: four threads, each with its own input, get what they get alone."""
     import threading
 

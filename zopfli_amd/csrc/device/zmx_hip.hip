@@ -125,7 +125,8 @@ struct zmx_ctx {
   struct GuardInfo { size_t bytes; const char* tag; };
   std::unordered_map<void*, GuardInfo> guard_live;
   size_t pool_keep = 0;      // what the pool may keep cached between batches, and what one batch's DP edges may take:
-  size_t code_budget = 0;    // a third of the device's memory each (hipMemGetInfo at creation), at most 96 GiB
+  size_t code_budget = 0;    // a third of the device's memory each (hipMemGetInfo at creation), at most 96 GiB,
+  size_t keep_base = 0;      // divided by the number of contexts that share the device (zmx_ctx_set_share)
   u64* d_guard_tab = nullptr;   // [kGuardMaxAllocs][2] zone pairs for k_guard_check, then 4 result words
   u64 guard_checks = 0;
 };
@@ -236,6 +237,8 @@ hipError_t GuardDress(zmx_ctx* c, void* base, size_t bytes, size_t cap, const ch
   return e;
 }
 
+std::atomic<zmx_oom_hook_t> g_oom_hook{nullptr};
+
 hipError_t PoolAllocBytes(zmx_ctx* c, void** p, size_t bytes, const char* tag) {
   if (bytes == 0) bytes = 1;
   const bool guard = GuardOn();
@@ -262,6 +265,15 @@ hipError_t PoolAllocBytes(zmx_ctx* c, void** p, size_t bytes, const char* tag) {
       c->pool_free.clear();
       c->pool_free_bytes = 0;
       e = hipMalloc(&base, want);
+    }
+    if (e != hipSuccess) {
+      // still out of memory: the idle contexts of the same device may sit on gigabytes of cached arrays (the owner
+      // of the contexts — api.cc's ContextPool — trims them through this hook)
+      if (const zmx_oom_hook_t hook = g_oom_hook.load(std::memory_order_acquire)) {
+        (void)hipGetLastError();
+        hook(c->device);
+        e = hipMalloc(&base, want);
+      }
     }
     if (e != hipSuccess) return e;
   }
@@ -350,38 +362,38 @@ void PoolFree(zmx_ctx* c, void* p) {
 int GuardVerify(zmx_ctx* c, const char* where) {
   if (hipStreamSynchronize(c->stream) != hipSuccess) return FailMsg(std::string("ZOPFLI_AMD_GUARD: the stream failed after ") + where);
   if (c->guard_live.empty()) return 0;
-  const u32 n = static_cast<u32>(std::min<size_t>(c->guard_live.size(), kGuardMaxAllocs));
-  std::vector<u64> tab(2 * static_cast<size_t>(kGuardMaxAllocs) + 2, 0);
-  std::vector<const void*> who;
-  who.reserve(n);
-  u32 i = 0;
-  for (const auto& g : c->guard_live) {
-    if (i == n) break;
-    const unsigned char* user = static_cast<const unsigned char*>(g.first);
-    tab[2 * i] = reinterpret_cast<u64>(user - kGuardBytes);
-    tab[2 * i + 1] = reinterpret_cast<u64>(user + g.second.bytes);
-    who.push_back(g.first);
-    ++i;
-  }
   // (ZOPFLI_AMD_GUARD_SELFTEST=N: the N-th check finds a byte that this function itself just broke — the test that the
   //  mode reports what it is there to report)
   static const u64 selftest = [] { const char* e = std::getenv("ZOPFLI_AMD_GUARD_SELFTEST"); return e ? static_cast<u64>(std::atoll(e)) : 0ull; }();
-  if (selftest && c->guard_checks + 1 == selftest) HIPCHK(hipMemset(reinterpret_cast<void*>(tab[1] + 100), 0x5a, 1));
-  if (!c->d_guard_tab) HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_guard_tab), tab.size() * sizeof(u64)));
-  HIPCHK(hipMemcpy(c->d_guard_tab, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice));   // (the result words zeroed with it)
-  u32* res = reinterpret_cast<u32*>(c->d_guard_tab + 2 * static_cast<size_t>(kGuardMaxAllocs));
-  hipLaunchKernelGGL(k_guard_check, dim3(2 * n), dim3(256), 0, c->stream, c->d_guard_tab, 2 * n, res);
-  HIPCHK(hipGetLastError());
-  u32 h[4] = {0, 0, 0, 0};
-  HIPCHK(hipMemcpy(h, res, sizeof(h), hipMemcpyDeviceToHost));
+  std::vector<std::pair<void*, zmx_ctx::GuardInfo>> live(c->guard_live.begin(), c->guard_live.end());
+  if (!c->d_guard_tab) HIPCHK(hipMalloc(reinterpret_cast<void**>(&c->d_guard_tab), (2 * static_cast<size_t>(kGuardMaxAllocs) + 2) * sizeof(u64)));
   ++c->guard_checks;
-  if (h[0] == 0) return 0;
-  const auto& g = c->guard_live[const_cast<void*>(who[h[1] >> 1])];
-  char buf[400];
-  std::snprintf(buf, sizeof(buf), "ZOPFLI_AMD_GUARD: after %s the red zone %s allocation '%s' (%zu bytes) changed: byte offset %u of the zone holds 0x%08x",
-                where, (h[1] & 1u) ? "behind" : "in front of", g.tag ? g.tag : "?", g.bytes, h[2], h[3]);
-  std::fprintf(stderr, "%s\n", buf);
-  return FailMsg(buf);
+  // every live allocation, kGuardMaxAllocs at a time (a context that holds parent, optimal and fixed-tree tables plus
+  // temporaries has more than one table's worth)
+  for (size_t first = 0; first < live.size(); first += kGuardMaxAllocs) {
+    const u32 n = static_cast<u32>(std::min<size_t>(live.size() - first, kGuardMaxAllocs));
+    std::vector<u64> tab(2 * static_cast<size_t>(kGuardMaxAllocs) + 2, 0);
+    for (u32 i = 0; i < n; ++i) {
+      const unsigned char* user = static_cast<const unsigned char*>(live[first + i].first);
+      tab[2 * i] = reinterpret_cast<u64>(user - kGuardBytes);
+      tab[2 * i + 1] = reinterpret_cast<u64>(user + live[first + i].second.bytes);
+    }
+    if (first == 0 && selftest && c->guard_checks == selftest) HIPCHK(hipMemset(reinterpret_cast<void*>(tab[1] + 100), 0x5a, 1));
+    HIPCHK(hipMemcpy(c->d_guard_tab, tab.data(), tab.size() * sizeof(u64), hipMemcpyHostToDevice));   // (the result words zeroed with it)
+    u32* res = reinterpret_cast<u32*>(c->d_guard_tab + 2 * static_cast<size_t>(kGuardMaxAllocs));
+    hipLaunchKernelGGL(k_guard_check, dim3(2 * n), dim3(256), 0, c->stream, c->d_guard_tab, 2 * n, res);
+    HIPCHK(hipGetLastError());
+    u32 h[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(h, res, sizeof(h), hipMemcpyDeviceToHost));
+    if (h[0] == 0) continue;
+    const auto& g = live[first + (h[1] >> 1)].second;
+    char buf[400];
+    std::snprintf(buf, sizeof(buf), "ZOPFLI_AMD_GUARD: after %s the red zone %s allocation '%s' (%zu bytes) changed: byte offset %u of the zone holds 0x%08x",
+                  where, (h[1] & 1u) ? "behind" : "in front of", g.tag ? g.tag : "?", g.bytes, h[2], h[3]);
+    std::fprintf(stderr, "%s\n", buf);
+    return FailMsg(buf);
+  }
+  return 0;
 }
 // after every kernel launch: the launch error, and in guard mode the red zones
 #define KCHK(c, name)                                            \
@@ -405,6 +417,26 @@ int zmx_device_count(void) {
 }
 
 const char* zmx_last_error(void) { return g_err.c_str(); }
+
+void zmx_set_oom_hook(zmx_oom_hook_t hook) { g_oom_hook.store(hook, std::memory_order_release); }
+
+int zmx_ctx_set_share(zmx_ctx* c, unsigned contexts_on_device) {
+  if (!c) return FailMsg("zmx_ctx_set_share: no context");
+  const size_t n = contexts_on_device ? contexts_on_device : 1;
+  c->pool_keep = c->keep_base / n;
+  c->code_budget = c->keep_base / n;
+  return 0;
+}
+
+int zmx_ctx_trim_cache(zmx_ctx* c) {
+  if (!c) return 0;
+  DeviceGuard dev_guard(c->device);
+  HIPCHK(dev_guard.err);
+  for (auto& f : c->pool_free) (void)hipFree(f.first);
+  c->pool_free.clear();
+  c->pool_free_bytes = 0;
+  return 0;
+}
 
 int zmx_set_match_kernel(int kernel) {
   if (kernel != 0 && kernel != 2 && kernel != 3 && kernel != 4 && kernel != 5) return FailMsg("zmx_set_match_kernel: 0, 2, 3, 4 or 5");
@@ -461,8 +493,9 @@ int zmx_ctx_create(int device, zmx_ctx** out) {
     // device (ZOPFLI_AMD_DEVICES=0,0), other processes may hold memory already.
     size_t mem_free = 0, mem_total = 0;
     HIPCHK(hipMemGetInfo(&mem_free, &mem_total));
-    c->pool_keep = std::min<size_t>(kPoolKeepMax, mem_free / 3);
-    c->code_budget = std::min<size_t>(kPoolKeepMax, mem_free / 3);
+    c->keep_base = std::min<size_t>(kPoolKeepMax, mem_free / 3);
+    c->pool_keep = c->keep_base;
+    c->code_budget = c->keep_base;
   }
 
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -556,6 +589,9 @@ static void ReleaseTableArrays(zmx_ctx* c, zmx_tables* t, bool keep_stores) {
 void zmx_tables_free(zmx_ctx* c, zmx_tables* t) {
   if (!t) return;
   DeviceGuard dev_guard(c ? c->device : 0);
+  // (an error return between a launch on the second stream and its join leaves that kernel in flight: nothing of
+  //  this table set may go back to the pool under it)
+  if (c && c->stream2) (void)hipStreamSynchronize(c->stream2);
   ReleaseTableArrays(c, t, false);
   delete t;
 }
@@ -570,6 +606,7 @@ int zmx_tables_trim(zmx_ctx* c, zmx_tables* t) {
   DeviceGuard dev_guard(c->device);
   HIPCHK(dev_guard.err);
   HIPCHK(hipStreamSynchronize(c->stream));      // (nothing of this table set may still be in flight)
+  HIPCHK(hipStreamSynchronize(c->stream2));
   ReleaseTableArrays(c, t, true);
   t->trimmed = true;
   return 0;

@@ -79,7 +79,6 @@ class ContextPool {
     std::unique_lock<std::mutex> lock(mu_);
     Init();
     for (;;) {
-      std::vector<zmx_ctx*> got;
       std::vector<Slot*> slots;
       size_t used_devices = 0;
       for (auto& dev : devices_) {
@@ -92,32 +91,72 @@ class ContextPool {
             if (!sl->busy && std::find(slots.begin(), slots.end(), sl.get()) == slots.end()) { s = sl.get(); break; }
           }
           if (!s && dev.slots.size() < lanes_) {
-            zmx_ctx* c = nullptr;
-            if (zmx_ctx_create(dev.index, &c) != 0) {
-              if (dev.slots.empty()) {
-                std::fprintf(stderr, "zopfli_amd: device %d is not usable: %s\n", dev.index, zmx_last_error());
-                dev.dead = true;
-              }
-              break;
-            }
-            dev.slots.emplace_back(new Slot{c, false});
+            // a new context: the slot is taken now, the context is created below without the pool's lock (HIP
+            // start-up, streams, events: up to seconds on first use, and every Release would wait behind it)
+            dev.slots.emplace_back(new Slot{nullptr, false, &dev});
             s = dev.slots.back().get();
           }
           if (!s) break;
-          got.push_back(s->ctx);
           slots.push_back(s);
           ++here;
         }
         if (here) ++used_devices;
       }
+      if (!slots.empty()) {
+        for (Slot* s : slots) s->busy = true;
+        bool need_create = false;
+        for (Slot* s : slots) need_create |= s->ctx == nullptr;
+        if (need_create) {
+          lock.unlock();
+          std::vector<std::pair<Slot*, zmx_ctx*>> made;
+          std::vector<std::pair<Slot*, std::string>> failed;
+          for (Slot* s : slots) {
+            if (s->ctx) continue;
+            zmx_ctx* c = nullptr;
+            if (zmx_ctx_create(s->dev->index, &c) != 0) failed.emplace_back(s, zmx_last_error());
+            else made.emplace_back(s, c);
+          }
+          lock.lock();
+          for (auto& m : made) {
+            m.first->ctx = m.second;
+            // budgets per DEVICE, not per context: every context of the device gets its share of what a lone
+            // context would keep cached / spend on one batch's DP edges
+            size_t same = 0;
+            for (auto& d : devices_) same += d.index == m.first->dev->index ? 1 : 0;
+            zmx_ctx_set_share(m.second, static_cast<unsigned>(lanes_ * same));
+          }
+          for (auto& f : failed) {
+            Device* dev = f.first->dev;
+            for (size_t i = 0; i < dev->slots.size(); ++i) {
+              if (dev->slots[i].get() == f.first) { dev->slots.erase(dev->slots.begin() + static_cast<long>(i)); break; }
+            }
+            slots.erase(std::find(slots.begin(), slots.end(), f.first));
+            if (dev->slots.empty()) {
+              std::fprintf(stderr, "zopfli_amd: device %d is not usable: %s\n", dev->index, f.second.c_str());
+              dev->dead = true;
+            }
+          }
+          if (!failed.empty()) cv_.notify_all();
+        }
+      }
       bool any_alive = false;
       for (auto& dev : devices_) any_alive |= !dev.dead;
       if (!any_alive) Die("no usable gfx950 device (there is no CPU fallback)");
-      if (!got.empty()) {
-        for (Slot* s : slots) s->busy = true;
+      if (!slots.empty()) {
+        std::vector<zmx_ctx*> got;
+        for (Slot* s : slots) got.push_back(s->ctx);
         return got;
       }
       cv_.wait(lock);   // every context of every device is busy
+    }
+  }
+  // zmx_set_oom_hook: a context of `device` is out of memory even after dropping its own cache — the idle contexts of
+  // that device give their cached arrays back
+  void TrimIdle(int device) {
+    std::lock_guard<std::mutex> lock(mu_);
+    for (auto& dev : devices_) {
+      if (dev.index != device) continue;
+      for (auto& sl : dev.slots) if (!sl->busy && sl->ctx) zmx_ctx_trim_cache(sl->ctx);
     }
   }
   void Release(const std::vector<zmx_ctx*>& ctxs) {
@@ -131,7 +170,8 @@ class ContextPool {
   }
 
  private:
-  struct Slot { zmx_ctx* ctx; bool busy; };
+  struct Device;
+  struct Slot { zmx_ctx* ctx; bool busy; Device* dev; };
   struct Device { int index; bool dead = false; std::vector<std::unique_ptr<Slot>> slots; };
   void Init() {
     if (!devices_.empty()) return;
@@ -156,7 +196,10 @@ class ContextPool {
     } else if (const char* e = std::getenv("ZOPFLI_AMD_DEVICE")) {
       list.push_back(std::atoi(e));
     } else if (const char* r = std::getenv("LOCAL_RANK")) {
-      list.push_back(std::atoi(r));
+      // (one process per GPU under torchrun; with HIP_VISIBLE_DEVICES set per rank every rank sees ONE device and
+      //  LOCAL_RANK = k would name a device that is not there: take it modulo what is visible)
+      const int k = std::atoi(r);
+      list.push_back(visible > 0 && k >= 0 ? k % visible : k);
     } else {
       list.push_back(0);
     }
@@ -174,7 +217,9 @@ class ContextPool {
       Die("no usable gfx950 device (there is no CPU fallback)");
     }
     if (const char* e = std::getenv("ZOPFLI_AMD_LANES")) lanes_ = static_cast<size_t>(std::max(1, std::atoi(e)));
+    zmx_set_oom_hook(&ContextPool::OomHook);
   }
+  static void OomHook(int device);
   std::mutex mu_;
   std::condition_variable cv_;
   std::vector<Device> devices_;
@@ -185,6 +230,7 @@ ContextPool& Pool() {
   static ContextPool* pool = new ContextPool();   // (never destroyed: HIP may be gone by the time statics are)
   return *pool;
 }
+void ContextPool::OomHook(int device) { Pool().TrimIdle(device); }
 
 struct Lease {
   std::vector<zmx_ctx*> ctxs;

@@ -288,4 +288,24 @@ __attribute__((visibility("default"))) size_t zamd_test_block_split(const uint16
   return pts.size();
 }
 
+// BlockSplitLz77Batch over `copies` views of the sequence cut at different lengths (n, n - n / 7, n - 2 n / 7, ...):
+// the split points of view v go to points[v * cap ..], their number to counts[v]
+__attribute__((visibility("default"))) void zamd_test_block_split_batch(const uint16_t* litlens, const uint16_t* dists, size_t n, size_t copies,
+                                                                          size_t maxblocks, size_t* points, size_t* counts, size_t cap) {
+  std::vector<zamd::Lz77Store> stores;
+  stores.reserve(copies);
+  std::vector<const zamd::Lz77Store*> ptrs;
+  for (size_t v = 0; v < copies; ++v) {
+    stores.emplace_back(nullptr);
+    stores.back().Append(litlens, dists, n - v * (n / 7), 0);
+    ptrs.push_back(&stores.back());
+  }
+  std::vector<std::vector<size_t>> pts;
+  zamd::BlockSplitLz77Batch(ptrs, maxblocks, &pts);
+  for (size_t v = 0; v < copies; ++v) {
+    counts[v] = pts[v].size();
+    for (size_t i = 0; i < pts[v].size() && i < cap; ++i) points[v * cap + i] = pts[v][i];
+  }
+}
+
 }  // extern "C"

@@ -106,5 +106,22 @@ def test_host_block_size_and_split_vs_reference(cls, n):
             pts = (sz * 64)()
             k = host.zamd_test_block_split(pl, pd, m, maxblocks, pts, 64)
             assert [pts[i] for i in range(k)] == r.block_split(maxblocks), maxblocks
+        # the round-by-round search of several sequences at once (BlockSplitLz77Batch: blocks searched before their
+        # turn, decisions in the reference's order): the sequence cut at three lengths, each against the reference
+        host.zamd_test_block_split_batch.argtypes = [u16p, u16p, sz, sz, sz, ctypes.POINTER(sz), ctypes.POINTER(sz), sz]
+        host.zamd_test_block_split_batch.restype = None
+        copies = 3
+        refs = []
+        for v in range(copies):
+            mv = m - v * (m // 7)
+            rv = ol.RefSymbols(ll[:mv], dd[:mv])
+            refs.append([rv.block_split(mb) for mb in (15, 4, 0)])
+            rv.close()
+        for j, maxblocks in enumerate((15, 4, 0)):
+            pts = (sz * (64 * copies))()
+            cnt = (sz * copies)()
+            host.zamd_test_block_split_batch(pl, pd, m, copies, maxblocks, pts, cnt, 64)
+            for v in range(copies):
+                assert [pts[v * 64 + i] for i in range(cnt[v])] == refs[v][j], (maxblocks, v)
     finally:
         r.close()

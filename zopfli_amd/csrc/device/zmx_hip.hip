@@ -638,7 +638,9 @@ static unsigned SegL(u64 total_positions) {
   // (with the tasks started at cut points, below, the warm-up is ~70 positions instead of 512 and 2048 beats 4096
   //  for a full batch too: half the positions re-run where a task crosses a binade, 4.17 -> 3.75 ms per run of 100 MB;
   //  1024 loses to the per-task set-up again: 4.2 ms)
-  return total_positions < (2u << 20) ? 1024u : 2048u;
+  // (a call of 64 KiB is 64 tasks of 1024 positions on 256 CUs: 512 halves the latency of every pass — 18.6 -> 16.8 ms
+  //  for the call —, at 1 MB 512 loses to the per-task set-up again: 39 -> 44 ms)
+  return total_positions <= (256u << 10) ? 512u : total_positions < (2u << 20) ? 1024u : 2048u;
 }
 // The first task of a block is exact by construction and runs beside the others: let it cover the
 // stretch where the costs double every few thousand positions and no guess would stay in its binade.

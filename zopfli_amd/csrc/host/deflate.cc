@@ -14,6 +14,16 @@
 namespace zamd {
 
 namespace {
+// Few enough parts that one thread per part would leave the block-split search latency-bound (block_split.cc:
+// BlockSplitLz77Batch).  ZOPFLI_AMD_BATCH_SPLIT = 0 / 1 forces the choice.
+bool BatchSplit(size_t np) {
+  static const int forced = [] { const char* e = std::getenv("ZOPFLI_AMD_BATCH_SPLIT"); return e ? std::atoi(e) : -1; }();
+  if (forced >= 0) return forced != 0;
+  return np * 2 <= WideThreads();
+}
+}  // namespace
+
+namespace {
 
 double Now() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -133,13 +143,28 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
     rc = Lz77GreedyBatch(ctx, ranges, &greedy, &split_tables);
     if (rc) return rc;
     const double t0 = Now();
-    ParallelForWide(np, [&](size_t p) {
-      Lz77Store s = StoreFromRun(greedy[p], parts[p].instart);
-      std::vector<size_t> pts;
-      BlockSplitLz77(s, static_cast<size_t>(options.blocksplittingmax), &pts);
-      if (options.verbose) st[p].log += SplitPointsLine(s, pts);   // blocksplitter.c:266-268
-      split_bytes[p] = SplitPointsToBytes(s, pts, parts[p].instart);
-    });
+    if (BatchSplit(np)) {
+      // a few parts: all their searches advance together, round by round, on the whole pool (block_split.cc)
+      std::vector<Lz77Store> stores;
+      stores.reserve(np);
+      for (size_t p = 0; p < np; ++p) stores.emplace_back(StoreFromRun(greedy[p], parts[p].instart));
+      std::vector<const Lz77Store*> ptrs(np);
+      for (size_t p = 0; p < np; ++p) ptrs[p] = &stores[p];
+      std::vector<std::vector<size_t>> pts;
+      BlockSplitLz77Batch(ptrs, static_cast<size_t>(options.blocksplittingmax), &pts);
+      for (size_t p = 0; p < np; ++p) {
+        if (options.verbose) st[p].log += SplitPointsLine(stores[p], pts[p]);   // blocksplitter.c:266-268
+        split_bytes[p] = SplitPointsToBytes(stores[p], pts[p], parts[p].instart);
+      }
+    } else {
+      ParallelForWide(np, [&](size_t p) {
+        Lz77Store s = StoreFromRun(greedy[p], parts[p].instart);
+        std::vector<size_t> pts;
+        BlockSplitLz77(s, static_cast<size_t>(options.blocksplittingmax), &pts);
+        if (options.verbose) st[p].log += SplitPointsLine(s, pts);   // blocksplitter.c:266-268
+        split_bytes[p] = SplitPointsToBytes(s, pts, parts[p].instart);
+      });
+    }
     ThreadTiming().split += Now() - t0;
   }
 
@@ -201,11 +226,11 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
       s.block_sym_end.push_back(nsym);
       s.finals.push_back(f);
     });
-  } else
+  } else {
+  std::vector<double> totalcost(np, 0.0);
   ParallelForWide(np, [&](size_t p) {
     PartState& s = st[p];
     const size_t npoints = s.blocks.size() - 1;
-    double totalcost = 0;
     {
       size_t total = 0;      // (one allocation for the part's store: appending block by block re-allocated it every time)
       for (size_t i = 0; i <= npoints; ++i) total += runs[s.first_block + i].litlens.size();
@@ -214,22 +239,39 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
     for (size_t i = 0; i <= npoints; ++i) {
       s.log += runs[s.first_block + i].log;       // "Iteration i: n bit" (squeeze.c:493), block after block
       Lz77Store bs = StoreFromRun(runs[s.first_block + i], s.blocks[i].instart);
-      totalcost += CalculateBlockSizeAutoType(bs, 0, bs.size());
+      totalcost[p] += CalculateBlockSizeAutoType(bs, 0, bs.size());
       s.lz77.Append(bs);
       s.block_sym_end.push_back(s.lz77.size());
       if (i < npoints) s.splitpoints.push_back(s.lz77.size());
     }
-    if (options.blocksplitting && npoints > 1) {  // deflate.c:872-893
-      std::vector<size_t> pts2;
-      BlockSplitLz77(s.lz77, static_cast<size_t>(options.blocksplittingmax), &pts2);
-      if (options.verbose) s.log += SplitPointsLine(s.lz77, pts2);
+  });
+  // deflate.c:872-893: the second split attempt, on the optimal parse
+  std::vector<std::vector<size_t>> pts2(np);
+  std::vector<char> tried(np, 0);
+  for (size_t p = 0; p < np; ++p) tried[p] = options.blocksplitting && st[p].blocks.size() - 1 > 1;
+  if (BatchSplit(np)) {
+    std::vector<const Lz77Store*> ptrs;
+    std::vector<size_t> owner;
+    for (size_t p = 0; p < np; ++p) if (tried[p]) { ptrs.push_back(&st[p].lz77); owner.push_back(p); }
+    std::vector<std::vector<size_t>> got;
+    BlockSplitLz77Batch(ptrs, static_cast<size_t>(options.blocksplittingmax), &got);
+    for (size_t i = 0; i < owner.size(); ++i) pts2[owner[i]].swap(got[i]);
+  } else {
+    ParallelForWide(np, [&](size_t p) {
+      if (tried[p]) BlockSplitLz77(st[p].lz77, static_cast<size_t>(options.blocksplittingmax), &pts2[p]);
+    });
+  }
+  ParallelForWide(np, [&](size_t p) {
+    PartState& s = st[p];
+    if (tried[p]) {
+      if (options.verbose) s.log += SplitPointsLine(s.lz77, pts2[p]);
       double totalcost2 = 0;
-      for (size_t i = 0; i <= pts2.size(); ++i) {
-        const size_t a = i == 0 ? 0 : pts2[i - 1];
-        const size_t b = i == pts2.size() ? s.lz77.size() : pts2[i];
+      for (size_t i = 0; i <= pts2[p].size(); ++i) {
+        const size_t a = i == 0 ? 0 : pts2[p][i - 1];
+        const size_t b = i == pts2[p].size() ? s.lz77.size() : pts2[p][i];
         totalcost2 += CalculateBlockSizeAutoType(s.lz77, a, b);
       }
-      if (totalcost2 < totalcost) s.splitpoints.swap(pts2);
+      if (totalcost2 < totalcost[p]) s.splitpoints.swap(pts2[p]);
     }
     for (size_t i = 0; i <= s.splitpoints.size(); ++i) {  // AddLZ77BlockAutoType, deflate.c:747-762
       FinalBlock f;
@@ -242,6 +284,7 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
       s.finals.push_back(f);
     }
   });
+  }
   ThreadTiming().split += Now() - t3;
 
   for (size_t p = 0; p < np; ++p) {

@@ -116,13 +116,17 @@ class WorkerPool {
       body_ = &body;
       n_ = n;
       next_.store(0, std::memory_order_relaxed);
-      pending_ = workers_.size();
-      ++generation_;
+      pending_.store(workers_.size(), std::memory_order_relaxed);
+      generation_.fetch_add(1, std::memory_order_release);
     }
     wake_.notify_all();
     Drain(body);
-    std::unique_lock<std::mutex> lock(mutex_);
-    done_.wait(lock, [&] { return pending_ == 0; });
+    // (the workers finish within microseconds of each other: look before going to sleep)
+    for (int i = 0; i < spin_ && pending_.load(std::memory_order_acquire) != 0; ++i) CpuRelax();
+    if (pending_.load(std::memory_order_acquire) != 0) {
+      std::unique_lock<std::mutex> lock(mutex_);
+      done_.wait(lock, [&] { return pending_.load(std::memory_order_acquire) == 0; });
+    }
     body_ = nullptr;
   }
 
@@ -148,13 +152,13 @@ class WorkerPool {
     if (!p) {
       static std::once_flag atfork;
       std::call_once(atfork, [] { pthread_atfork(nullptr, nullptr, &WorkerPool::ForgetInChild); });
-      p = new WorkerPool(threads);
+      p = new WorkerPool(threads, which == 0 ? kSpin : 0);   // (the wide pool's 127 workers go to sleep at once: they would burn a cgroup quota spinning)
       Slots()[which].store(p, std::memory_order_release);
     }
     return *p;
   }
 
-  explicit WorkerPool(unsigned threads) {
+  WorkerPool(unsigned threads, int spin) : spin_(spin) {
     const unsigned extra = threads > 1 ? threads - 1 : 0;
     workers_.reserve(extra);
     for (unsigned t = 0; t < extra; ++t) workers_.emplace_back([this] { Loop(); });
@@ -169,20 +173,37 @@ class WorkerPool {
     }
   }
 
+  // A fork-join of a few dozen microseconds of work follows the last one within microseconds where it matters (the
+  // rounds of the block-split search, the two cost-model steps of a squeeze run): a worker that goes to sleep on the
+  // condition variable at once pays a futex wake-up — and 31 or 127 of them a thundering herd on one mutex — per
+  // round.  Each looks at the generation counter for a few tens of microseconds first.
+  static constexpr int kSpin = 1500;
+  static void CpuRelax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+  }
+
   void Loop() {
     uint64_t seen = 0;
     for (;;) {
-      const std::function<void(size_t)>* body;
-      {
-        std::unique_lock<std::mutex> lock(mutex_);
-        wake_.wait(lock, [&] { return generation_ != seen; });
-        seen = generation_;
-        body = body_;
+      bool got = false;
+      for (int i = 0; i < spin_; ++i) {
+        if (generation_.load(std::memory_order_acquire) != seen) { got = true; break; }
+        CpuRelax();
       }
+      if (!got) {
+        std::unique_lock<std::mutex> lock(mutex_);
+        wake_.wait(lock, [&] { return generation_.load(std::memory_order_acquire) != seen; });
+      }
+      seen = generation_.load(std::memory_order_acquire);
+      const std::function<void(size_t)>* body = body_;   // (written before the generation moved)
       if (body) Drain(*body);
-      {
-        std::lock_guard<std::mutex> lock(mutex_);
-        if (--pending_ == 0) done_.notify_one();
+      if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+        std::lock_guard<std::mutex> lock(mutex_);     // (the caller may be between its check and its wait)
+        done_.notify_one();
       }
     }
   }
@@ -193,8 +214,9 @@ class WorkerPool {
   const std::function<void(size_t)>* body_ = nullptr;
   size_t n_ = 0;
   std::atomic<size_t> next_{0};
-  size_t pending_ = 0;
-  uint64_t generation_ = 0;
+  std::atomic<size_t> pending_{0};
+  const int spin_;
+  std::atomic<uint64_t> generation_{0};
 };
 
 inline thread_local bool g_inside_parallel_for = false;

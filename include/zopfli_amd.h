@@ -216,6 +216,20 @@ uint32_t zmx_checksum_combine(int kind, uint32_t a, uint32_t b, uint64_t len_b);
 int zmx_find_longest_match(zmx_ctx* ctx, zmx_tables* tables, size_t block, size_t pos,
                            uint16_t* sublen, uint16_t* distance, uint16_t* length);
 
+/* -------- zopflipng's per-row filter search
+ *
+ * The PNG filter type (0 None, 1 Sub, 2 Up, 3 Average, 4 Paeth) LodePNG's encoder picks for each of `height` scanlines
+ * of `linebytes` bytes under its LFS_MINSUM and LFS_ENTROPY strategies (lodepng.cpp:5444-5570; the search zopflipng
+ * runs per strategy trial, zopflipng_lib.cc:160-305), computed on the device from the raw (already colour-converted,
+ * non-interlaced) image; `bytewidth` = bytes per pixel, 1 below 8 bits per pixel.  Either output may be null.  The
+ * types go back to LodePNG as LFS_PREDEFINED (`predefined_filters`): the scanlines it then writes are the ones its own
+ * search would have produced.  zmx_png_filter_types_pooled is the same on one of the contexts of the Zopfli* entry
+ * points (what libzopflipng_amd.so calls). */
+int zmx_png_filter_types(zmx_ctx* ctx, const unsigned char* image, size_t linebytes, size_t height, size_t bytewidth,
+                         unsigned char* minsum_types, unsigned char* entropy_types);
+int zmx_png_filter_types_pooled(const unsigned char* image, size_t linebytes, size_t height, size_t bytewidth,
+                                unsigned char* minsum_types, unsigned char* entropy_types);
+
 /* Parity probe over whole tables: two 64-bit sums over all positions of a hash of the logical content of the match
  * records (block, position, length, distance, same, literal, every change point of sublen).  Equal digests of two
  * table sets over the same blocks = the same ZopfliFindLongestMatch results at every position. */

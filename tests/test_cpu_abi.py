@@ -17,6 +17,34 @@ def test_exports_match_header():
         assert hasattr(lib, n), f"{n} declared in include/zopfli_amd.h but not exported"
 
 
+def test_png_library_exports_the_reference_abi():
+    """libzopflipng_amd.so has the C entry points of the reference's zopflipng_lib.h (:76-85) and its defaults
+    (zopflipng_lib.cc:33-43); the C++ ones are checked by linking the reference's own command line against it
+    (_build.build_png_tests).  No device call."""
+    import pytest
+    from zopfli_amd._build import PNG_LIB
+    if not os.path.exists(PNG_LIB):
+        pytest.skip("libzopflipng_amd.so not built (LodePNG's sources were not at hand)")
+    lib = ctypes.CDLL(PNG_LIB)
+
+    class COpts(ctypes.Structure):    # zopflipng_lib.h:51-72
+        _fields_ = [("lossy_transparent", ctypes.c_int), ("lossy_8bit", ctypes.c_int), ("filter_strategies", ctypes.c_void_p),
+                    ("num_filter_strategies", ctypes.c_int), ("auto_filter_strategy", ctypes.c_int), ("keepchunks", ctypes.c_void_p),
+                    ("num_keepchunks", ctypes.c_int), ("use_zopfli", ctypes.c_int), ("num_iterations", ctypes.c_int),
+                    ("num_iterations_large", ctypes.c_int), ("block_split_strategy", ctypes.c_int)]
+    o = COpts()
+    ctypes.memset(ctypes.byref(o), 0xff, ctypes.sizeof(o))
+    lib.CZopfliPNGSetDefaults(ctypes.byref(o))
+    assert (o.lossy_transparent, o.lossy_8bit, o.num_filter_strategies, o.auto_filter_strategy, o.num_keepchunks, o.use_zopfli,
+            o.num_iterations, o.num_iterations_large, o.block_split_strategy) == (0, 0, 0, 1, 0, 1, 15, 5, 1)
+    assert o.filter_strategies is None and o.keepchunks is None
+    assert hasattr(lib, "CZopfliPNGOptimize")
+    with open(os.path.join(ROOT, "include", "zopflipng_amd.h")) as f:
+        text = f.read()
+    for name in ("CZopfliPNGSetDefaults", "CZopfliPNGOptimize", "ZopfliPNGOptimize", "kStrategyBruteForce"):
+        assert name in text
+
+
 def test_options_layout():
     from zopfli_amd import ZopfliOptions, api
     lib = api.library()

@@ -139,3 +139,49 @@ def build_zopflipng():
             objs.append(o)
         subprocess.check_call(["g++", "-O2", "-w"] + png + objs + ["-lm", "-o", PNG_REF])
     return PNG_AMD
+
+
+PNG_LIB = os.path.join(ROOT, "zopfli_amd", "libzopflipng_amd.so")
+PNG_AMD2 = os.path.join(ROOT, "tests", "_build", "zopflipng_amd2")
+PNG_FILTER_REF = os.path.join(ROOT, "tests", "_build", "libpng_filter_ref.so")
+
+
+def lodepng_dir():
+    """Where LodePNG's sources are (lodepng.cpp, lodepng_util.cpp and their headers): the third-party library
+    zopflipng is built on; the reference vendors it under src/zopflipng/lodepng."""
+    return os.environ.get("LODEPNG_DIR", "/root/reference/src/zopflipng/lodepng")
+
+
+def build_png_lib(force=False):
+    """libzopflipng_amd.so: zopflipng's optimiser library — csrc/png/zopflipng_amd.cc with the ABI of
+    the reference's zopflipng_lib.h — on top of libzopfli_amd.so, LodePNG compiled in from LODEPNG_DIR.  Skipped
+    (None) where LodePNG is not at hand; the built library travels to the GPU box."""
+    lp = lodepng_dir()
+    src = os.path.join(CSRC, "png", "zopflipng_amd.cc")
+    lode = [os.path.join(lp, f) for f in ("lodepng.cpp", "lodepng_util.cpp")]
+    if not all(os.path.exists(f) for f in lode):
+        return PNG_LIB if os.path.exists(PNG_LIB) else None
+    hdr = [os.path.join(ROOT, "include", "zopflipng_amd.h"), os.path.join(ROOT, "include", "zopfli_amd.h"), LIB]
+    if force or _newer(PNG_LIB, [src] + lode + hdr):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", src] + lode +
+                              ["-I" + os.path.join(ROOT, "include"), "-I" + lp, "-L" + os.path.dirname(LIB), "-lzopfli_amd",
+                               "-Wl,-rpath,$ORIGIN", "-lpthread", "-o", PNG_LIB])
+    return PNG_LIB
+
+
+def build_png_tests():
+    """Test infrastructure: the REFERENCE's zopflipng command line (src/zopflipng/zopflipng_bin.cc, compiled where it
+    lies) linked against libzopflipng_amd.so instead of the reference's zopflipng_lib.cc, and LodePNG's own scanline
+    filter (`filter`, a static function of lodepng.cpp) behind a C symbol — the oracle of zmx_png_filter_types."""
+    ref = "/root/reference/src/zopflipng"
+    if not os.path.isdir(ref) or not build_png_lib():
+        return None
+    os.makedirs(os.path.dirname(PNG_AMD2), exist_ok=True)
+    cli = os.path.join(ref, "zopflipng_bin.cc")
+    if _newer(PNG_AMD2, [cli, PNG_LIB]):
+        subprocess.check_call(["g++", "-O2", "-w", cli, "-I" + ref, "-L" + os.path.dirname(PNG_LIB), "-lzopflipng_amd",
+                               "-lzopfli_amd", "-Wl,-rpath," + os.path.dirname(PNG_LIB), "-o", PNG_AMD2])
+    helper = os.path.join(ROOT, "tests", "hostlib", "png_filter_ref.cc")
+    if _newer(PNG_FILTER_REF, [helper, os.path.join(ref, "lodepng", "lodepng.cpp")]):
+        subprocess.check_call(["g++", "-O2", "-w", "-fPIC", "-shared", helper, "-I" + os.path.join(ref, "lodepng"), "-o", PNG_FILTER_REF])
+    return PNG_AMD2

@@ -26,6 +26,7 @@
 #include "zmx_checksum.h"
 #include "zmx_trace.h"
 #include "zmx_greedy.h"
+#include "zmx_png.h"
 #include "zopfli_amd.h"
 #include "../host/thread_pool.h"
 
@@ -1928,6 +1929,38 @@ int zmx_encode_blocks(zmx_ctx* c, zmx_tables* t, size_t njobs, const zmx_enc_job
     const size_t nby = static_cast<size_t>((jobs[j].bit_start + jobs[j].nbits + 7) / 8);
     std::memcpy(out[j], stage + out_off[j], nby);
   });
+  return 0;
+}
+
+// PNG filter heuristics (zmx_png.h): the filter type LodePNG's MINSUM / ENTROPY strategy picks for every scanline.
+int zmx_png_filter_types(zmx_ctx* c, const unsigned char* image, size_t linebytes, size_t height, size_t bytewidth,
+                         unsigned char* minsum_types, unsigned char* entropy_types) {
+  if (!c) return FailMsg("zmx_png_filter_types: no context");
+  if (height == 0 || (!minsum_types && !entropy_types)) return 0;
+  if (linebytes == 0 || bytewidth == 0 || linebytes > 0x7fffffffu || height > 0x7fffffffu || bytewidth > 8) {
+    return FailMsg("zmx_png_filter_types: bad geometry");
+  }
+  DeviceGuard dev_guard(c->device);
+  HIPCHK(dev_guard.err);
+  PoolScope tmp(c);
+  u8* d_img = nullptr;
+  u8* d_types = nullptr;
+  const size_t bytes = linebytes * height;
+  HIPCHK(tmp.AllocT(&d_img, bytes, "d_png_image"));
+  HIPCHK(tmp.AllocT(&d_types, 2 * height, "d_png_types"));
+  HIPCHK(hipMemcpyAsync(d_img, image, bytes, hipMemcpyHostToDevice, c->stream));
+  PngFilterParams pp;
+  pp.image = d_img;
+  pp.linebytes = static_cast<u32>(linebytes);
+  pp.height = static_cast<u32>(height);
+  pp.bytewidth = static_cast<u32>(bytewidth);
+  pp.minsum = minsum_types ? d_types : nullptr;
+  pp.entropy = entropy_types ? d_types + height : nullptr;
+  hipLaunchKernelGGL(k_png_filter_types, dim3(static_cast<unsigned>(height)), dim3(PNGF_THREADS), 0, c->stream, pp);
+  KCHK(c, "k_png_filter_types");
+  if (minsum_types) HIPCHK(hipMemcpyAsync(minsum_types, d_types, height, hipMemcpyDeviceToHost, c->stream));
+  if (entropy_types) HIPCHK(hipMemcpyAsync(entropy_types, d_types + height, height, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
 

@@ -592,4 +592,11 @@ int zmx_last_host_timing(double* out2) {
   return 0;
 }
 
+// zopflipng's per-row filter search on one of the entry points' contexts (include/zopfli_amd.h)
+int zmx_png_filter_types_pooled(const unsigned char* image, size_t linebytes, size_t height, size_t bytewidth,
+                                unsigned char* minsum_types, unsigned char* entropy_types) {
+  Lease lease(1);
+  return zmx_png_filter_types(lease.ctxs[0], image, linebytes, height, bytewidth, minsum_types, entropy_types);
+}
+
 }  // extern "C"

@@ -166,7 +166,15 @@ def main():
                     help="N = 1: which way into the library is timed (default both: `value` = ZopfliCompress, "
                          "`value_resident` = resident input); N > 1 always times the sharded resident path")
     ap.add_argument("--no-blocksplitting1", action="store_true", help="skip the extra line with blocksplitting = 1")
+    ap.add_argument("--file", default=None, help="a real corpus instead of the synthetic class: the file's bytes (the first "
+                    "--size x N of them if it is longer) are the workload; `data` in the line names it")
+    ap.add_argument("--devices", default=None, help="N = 1: ZOPFLI_AMD_DEVICES for the ZopfliCompress entry (e.g. 0,0: the "
+                    "in-process multi-device path on one GPU)")
+    ap.add_argument("--no-in-process", action="store_true", help="N > 1: skip the extra measurement of the same total input "
+                    "through ZopfliCompress in rank 0's process with ZOPFLI_AMD_DEVICES = N (what a drop-in caller gets)")
     args = ap.parse_args()
+    if args.devices:
+        os.environ["ZOPFLI_AMD_DEVICES"] = args.devices
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -204,8 +212,18 @@ def main():
     #      (seed = the default), rank r taking the master blocks sharding.shard_ranges gives it.
     from zopfli_amd.datagen import DEFAULT_SEED
     seed0 = DEFAULT_SEED[args.cls]
+    corpus = None
+    if args.file:
+        with open(args.file, "rb") as f:
+            corpus = f.read()
+        per = len(corpus) // world if not (args.scaling == "strong" and world > 1) else len(corpus)
+        if world > 1:
+            per -= per % MB
+        size = min(size, per) if "--size" in sys.argv else per
+        if size <= 0:
+            raise SystemExit("--file: too short for %d ranks of whole master blocks" % world)
     if strong:
-        whole = generate(args.cls, size, seed=seed0)
+        whole = corpus[:size] if corpus is not None else generate(args.cls, size, seed=seed0)
         s0, s1 = sharding.shard_ranges(size, world)[rank]
         shard = whole[s0:s1]
         prefix = whole[max(0, s0 - WINDOW):s0]
@@ -215,10 +233,14 @@ def main():
         del whole
     else:
         assert size % MB == 0 or world == 1, "shards must be whole master blocks"
-        shard = generate(args.cls, size, seed=seed0 + rank)
-        prefix = b""
-        if rank > 0:
-            prefix = generate(args.cls, size, seed=seed0 + rank - 1)[-WINDOW:]  # tail of the previous shard = dictionary
+        if corpus is not None:
+            shard = corpus[rank * size:(rank + 1) * size]
+            prefix = corpus[max(0, rank * size - WINDOW):rank * size]
+        else:
+            shard = generate(args.cls, size, seed=seed0 + rank)
+            prefix = b""
+            if rank > 0:
+                prefix = generate(args.cls, size, seed=seed0 + rank - 1)[-WINDOW:]  # tail of the previous shard = dictionary
         total_bytes = size * world
         last_rank = world - 1
     resident = prefix + shard
@@ -370,6 +392,45 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    # ---- N > 1: the same total input through ZopfliCompress in ONE process that holds all N devices
+    #      (ZOPFLI_AMD_DEVICES = N: api.cc RunPartsSharded deals the master blocks over them and merges) — what a
+    #      program that links libzopfli.so.1 gets on a multi-GPU node without any launcher.  Rank 0 runs it after the
+    #      RCCL measurement while the other ranks wait; its stream must equal the gathered one.
+    in_process = None
+    if world > 1 and not args.no_in_process:
+        if rank == 0:
+            try:
+                os.environ["ZOPFLI_AMD_DEVICES"] = str(world)    # (this process has not used the entry points yet)
+                if strong:
+                    whole_in = corpus[:size] if corpus is not None else generate(args.cls, size, seed=seed0)
+                elif corpus is not None:
+                    whole_in = corpus[:size * world]
+                else:
+                    whole_in = b"".join(generate(args.cls, size, seed=seed0 + r) for r in range(world))
+                k = max(1, min(args.steps, 3))
+
+                def whole_step():
+                    outp, outsize = ctypes.POINTER(ctypes.c_ubyte)(), ctypes.c_size_t(0)
+                    lib.ZopfliCompress(ctypes.byref(options), api.FORMAT_GZIP, whole_in, len(whole_in), ctypes.byref(outp), ctypes.byref(outsize))
+                    return outp, outsize.value
+                o, n = whole_step()
+                libc.free(o)
+                t0 = time.perf_counter()
+                for _ in range(k):
+                    o, n = whole_step()
+                    if _ + 1 < k:
+                        libc.free(o)
+                dti = (time.perf_counter() - t0) / k
+                got = ctypes.string_at(o, n)
+                libc.free(o)
+                in_process = {"value": round(len(whole_in) / MB / dti, 4), "unit": "MB/s", "ms_per_step": round(dti * 1e3, 2), "steps": k,
+                              "devices": world, "same_stream_as_gathered": (got == out.tobytes()) if out is not None else None,
+                              "entry": "ZopfliCompress in rank 0's process with ZOPFLI_AMD_DEVICES=%d (host buffer in, stream out; "
+                                       "the other ranks idle)" % world}
+            except Exception as e:    # (reported, not fatal: the RCCL line stands on its own)
+                in_process = {"error": str(e)[:300]}
+        dist.barrier()
+
     if rank == 0:
         total = total_bytes
         resident_out = out.tobytes() if out is not None else None   # outside the timed region
@@ -397,11 +458,11 @@ def main():
                 dd = zlib.decompressobj(31)
                 roundtrip = (len(dd.decompress(out)) + len(dd.flush())) == total
             sha = hashlib.sha256(out).hexdigest()
-            for name in ("vectors_big.json", "vectors_big2.json", "vectors_big3.json", "vectors.json"):
+            for name in ("vectors_big.json", "vectors_big2.json", "vectors_big3.json", "vectors_big4.json", "vectors.json"):
                 p = os.path.join(ROOT, "tests", "golden", name)
                 if os.path.exists(p):
                     for c in json.load(open(p)):
-                        if (c["input"].get("cls") == args.cls and c["input"].get("seed") in (None, seed0)
+                        if (corpus is None and c["input"].get("cls") == args.cls and c["input"].get("seed") in (None, seed0)
                                 and c["insize"] == size and c["format"] == 0
                                 and c["numiterations"] == args.numiterations
                                 and c["blocksplitting"] == args.blocksplitting and c["blocksplittingmax"] == 15):
@@ -462,7 +523,7 @@ def main():
         roofline_match = None
         if msec > 0 and mpos > 0:
             ach = 29.0 * mpos / msec / 1e9
-            roofline_match = {"bound": "hbm", "kernel": "k_match2 (prev links; ZOPFLI_AMD_MATCH selects k_match3 / k_match4)", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
+            roofline_match = {"bound": "hbm", "kernel": "the match-table kernel(s): per block k_match5 (exact skip-walk) where k_hits estimates more than 300 hits per position, else k_match2 (ZOPFLI_AMD_MATCH forces one)", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
                               "frac": round(ach / 8000.0, 6), "seconds_per_step": round(msec / args.steps, 5),
                               "positions_per_step": mpos / args.steps,
                               "ns_per_position": round(msec / mpos * 1e9, 4),
@@ -477,8 +538,9 @@ def main():
             "value_resident": None if value_resident is None else round(value_resident, 4),
             "ms_per_step_resident": None if ms_resident is None else round(ms_resident, 2),
             "vs_baseline": None,
-            "dtype": "u8 (f32/f64 cost DP)", "data": "synthetic",
-            "config": {"workload": f"class-{args.cls} synthetic {size} B {'in total' if strong else 'per GPU'} "
+            "dtype": "u8 (f32/f64 cost DP)", "data": "synthetic" if corpus is None else "file:" + os.path.basename(args.file),
+            "config": {"workload": (f"class-{args.cls} synthetic" if corpus is None else "file " + os.path.basename(args.file)) +
+                                   f" {size} B {'in total' if strong else 'per GPU'} "
                                    f"(T = text-like enwik8 stand-in), numiterations="
                                    f"{args.numiterations}, blocksplitting={args.blocksplitting}, gzip, "
                                    f"{'configs[1]' if args.blocksplitting == 0 else 'configs[2]'}",
@@ -491,7 +553,19 @@ def main():
             "chain_tasks_per_step": {k: round(v / args.steps, 1) for k, v in seg_acc.items()},
             "breakdown_s_per_step": {k: round(v / args.steps, 4) for k, v in timing_acc.items()
                                      if k not in ("squeeze_launches", "table_builds", "positions_matched")},
+            "breakdown_note": ("of the run `value` comes from.  Through ZopfliCompress a call of 32 master blocks or more is "
+                               "dealt over three contexts of the device: dp_kernel / match_kernel / hash_kernels / "
+                               "trace_kernel / wtab_kernel are then SUMS over those contexts of kernels that interleave on "
+                               "the device (each stretched by the others); the host phases are the slowest context's.  "
+                               "`breakdown_s_per_step_resident` is the same work on ONE context, one stream: the kernel "
+                               "durations the roofline objects are computed from."),
+            "breakdown_s_per_step_resident": None if resident_timing is None else {
+                k: round(v / args.steps, 4) for k, v in resident_timing.items()
+                if k not in ("squeeze_launches", "table_builds", "positions_matched")},
         }
+        if roofline is not None and entry_dt is not None and timing_acc.get("squeeze_launches"):
+            roofline["avg_launch_ms_entry_summed_over_contexts"] = round(
+                timing_acc.get("dp_kernel", 0.0) / timing_acc["squeeze_launches"] * 1e3, 3)
         tasks_per_launch = k_seg.get("tasks", 0.0) / launches if launches else 0.0
         if world == 1 and tasks_per_launch and ksec > 0:
             # Predicted strong-scaling ceiling from the chain's latency: a squeeze run cannot take less than one
@@ -511,11 +585,11 @@ def main():
             n1 = max(1, min(args.steps, 2))
             bit1 = None
             sha1 = hashlib.sha256(out1).hexdigest()
-            for name in ("vectors_big.json", "vectors_big2.json", "vectors_big3.json", "vectors.json"):
+            for name in ("vectors_big.json", "vectors_big2.json", "vectors_big3.json", "vectors_big4.json", "vectors.json"):
                 pth = os.path.join(ROOT, "tests", "golden", name)
                 if os.path.exists(pth):
                     for c in json.load(open(pth)):
-                        if (c["input"].get("cls") == args.cls and c["input"].get("seed") in (None, seed0)
+                        if (corpus is None and c["input"].get("cls") == args.cls and c["input"].get("seed") in (None, seed0)
                                 and c["insize"] == size and c["format"] == 0 and c["numiterations"] == args.numiterations
                                 and c["blocksplitting"] == 1 and c["blocksplittingmax"] == 15):
                             bit1 = (sha1 == c["sha256"])
@@ -526,6 +600,8 @@ def main():
                                          if k in ("tables", "greedy", "squeeze", "cost_model", "split", "encode", "dp_kernel", "match_kernel")},
                 "config": "the same input through ZopfliCompress with the reference's default options: blocksplitting=1, "
                           "blocksplittingmax=15 (configs[2] on one GPU)"}
+        if in_process is not None:
+            line["in_process"] = in_process
         if world == 1 and not args.no_cpu_baseline:
             sample = shard[:min(args.cpu_sample, size)]
             res = cpu_baseline(sample, options)

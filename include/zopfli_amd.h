@@ -94,6 +94,30 @@ void ZopfliZlibCompress(const ZopfliOptions* options,
                         const unsigned char* in, size_t insize,
                         unsigned char** out, size_t* outsize);
 
+/* reference: src/zopfli/lz77.h:44-62 — the LZ77 symbol sequence of the reference's own API, as far as the two
+ * functions below read it: litlens / dists (lz77.c:98: a literal is (byte, 0), a match (length, distance)), their
+ * number, and pos (the byte position of every symbol in the input).  The cumulative histograms the reference keeps
+ * beside them (ll_symbol ... d_counts) are not read here. */
+typedef struct ZopfliLZ77Store {
+  unsigned short* litlens;
+  unsigned short* dists;
+  size_t size;
+  const unsigned char* data;
+  size_t* pos;
+  unsigned short* ll_symbol;
+  unsigned short* d_symbol;
+  size_t* ll_counts;
+  size_t* d_counts;
+} ZopfliLZ77Store;
+
+/* reference: src/zopfli/deflate.c:584-608 (deflate.h:79).  Size in bits of symbols [lstart, lend) as one block of
+ * type `btype` (0 stored, 1 fixed, 2 dynamic: tree included).  Host arithmetic (the block-cost code the block
+ * splitter and the iteration driver use: host/block_cost.cc); no device call. */
+double ZopfliCalculateBlockSize(const ZopfliLZ77Store* lz77, size_t lstart, size_t lend, int btype);
+
+/* reference: src/zopfli/deflate.c:610-621 (deflate.h:85): the smallest of the three. */
+double ZopfliCalculateBlockSizeAutoType(const ZopfliLZ77Store* lz77, size_t lstart, size_t lend);
+
 /* ------------------------------------------------------------------ Part 2 */
 
 typedef struct zmx_ctx zmx_ctx;       /* one HIP device + stream + resident input */

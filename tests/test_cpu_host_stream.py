@@ -236,6 +236,33 @@ def test_multi_device_sharding_through_the_c_entry_point():
     assert res["3"][0] == hashlib.sha256(ol.ref_compress(data, 0, 1)).hexdigest()
 
 
+@pytest.mark.parametrize("fail", [0, 1, 2])
+def test_failed_shard_is_done_again_on_another_context(fail):
+    """A shard of a request that fails (ZOPFLI_AMD_TEST_FAIL_SHARD: its first attempt returns an error before it does
+    anything — a device out of memory, a broken context) is computed again on a context that finished its own shard
+    (api.cc RunPartsSharded) and the stream is the one-device stream; three pretend devices, each shard failing in turn."""
+    import subprocess
+    import sys
+    code = (
+        "import hashlib, sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import oracle_lib as ol\n"
+        "from zopfli_amd import ZopfliOptions, api, generate\n"
+        "host = ol.hosttest_library()\n"
+        "data = generate('M', 2300000) + generate('R', 400000)\n"
+        "print(hashlib.sha256(api.compress(data, 0, ZopfliOptions(1), lib=host)).hexdigest())\n"
+        % (os.path.dirname(os.path.dirname(__file__)), os.path.dirname(__file__)))
+    res = {}
+    for name, extra in (("plain", {}), ("failing", {"ZOPFLI_AMD_TEST_FAIL_SHARD": str(fail)})):
+        env = dict(os.environ, ZOPFLI_HOSTTEST_DEVICES="3", ZOPFLI_AMD_DEVICES="all", **extra)
+        env.pop("LOCAL_RANK", None)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[name] = (r.stdout.split(), r.stderr)
+    assert res["plain"][0] == res["failing"][0]
+    assert "done again on another context" in res["failing"][1]
+
+
 @pytest.mark.parametrize("more", [0, 1])
 def test_verbose_text_equals_the_references(more):
     """ZopfliOptions::verbose / verbose_more: the library prints the reference's stderr text — block split

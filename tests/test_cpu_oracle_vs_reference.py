@@ -125,3 +125,35 @@ def test_host_block_size_and_split_vs_reference(cls, n):
                 assert [pts[v * 64 + i] for i in range(cnt[v])] == refs[v][j], (maxblocks, v)
     finally:
         r.close()
+
+
+def test_exported_block_size_functions_vs_reference():
+    """ZopfliCalculateBlockSize / ZopfliCalculateBlockSizeAutoType as libzopfli_amd.so exports them (deflate.h:79,85), on
+    the REFERENCE's own ZopfliLZ77Store (filled by the reference's ZopfliStoreLitLenDist): the same doubles as the
+    reference's functions for every block type, on ranges below and above the 1000-symbol switch of deflate.c:614."""
+    import ctypes
+    from zopfli_amd import api
+    mine = api.library()
+    r = ol.ref()
+    sz = ctypes.c_size_t
+    for lib in (mine, r):
+        lib.ZopfliCalculateBlockSize.argtypes = [ctypes.c_void_p, sz, sz, ctypes.c_int]
+        lib.ZopfliCalculateBlockSize.restype = ctypes.c_double
+        lib.ZopfliCalculateBlockSizeAutoType.argtypes = [ctypes.c_void_p, sz, sz]
+        lib.ZopfliCalculateBlockSizeAutoType.restype = ctypes.c_double
+    rng = np.random.default_rng(3)
+    for cls, n in (("T", 30000), ("R", 3000), ("Z", 20000), ("T", 2500)):
+        data = generate(cls, n)
+        ll, dd = ol.OracleTable(data, 0, n).greedy()
+        rs = ol.RefSymbols(np.ascontiguousarray(ll, dtype=np.uint16), np.ascontiguousarray(dd, dtype=np.uint16))
+        try:
+            m = len(ll)
+            p = ctypes.addressof(rs.store)
+            ranges = [(0, m), (0, 1), (m - 1, m), (0, min(m, 900)), (5, 5)] + [tuple(sorted(rng.integers(0, m + 1, 2).tolist())) for _ in range(40)]
+            for a, b in ranges:
+                for btype in (0, 1, 2):
+                    assert mine.ZopfliCalculateBlockSize(p, a, b, btype) == r.ZopfliCalculateBlockSize(p, a, b, btype), (cls, a, b, btype)
+                if a != b:
+                    assert mine.ZopfliCalculateBlockSizeAutoType(p, a, b) == r.ZopfliCalculateBlockSizeAutoType(p, a, b), (cls, a, b)
+        finally:
+            rs.close()

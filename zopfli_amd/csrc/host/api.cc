@@ -15,6 +15,7 @@
 #include <thread>
 #include <vector>
 
+#include "block_cost.h"
 #include "deflate.h"
 #include "lz77_optimal.h"
 #include "symbols.h"
@@ -338,24 +339,39 @@ int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char
     zamd::Timing timing;
     uint32_t sum = 0;
     size_t sum_bytes = 0;
+    bool redone = false;
   };
   std::vector<Shard> shards(ndev);
   for (size_t d = 0; d < ndev; ++d) {
     shards[d].first = parts.size() * d / ndev;
     shards[d].last = parts.size() * (d + 1) / ndev;
   }
-  auto work = [&](size_t d) {
+  // (ZOPFLI_AMD_TEST_FAIL_SHARD=k: the k-th shard's first attempt fails before it does anything — the test of the
+  //  re-queue below)
+  const char* fail_env = std::getenv("ZOPFLI_AMD_TEST_FAIL_SHARD");
+  const long fail_shard = fail_env ? std::atol(fail_env) : -1;
+  auto work = [&](size_t d, zmx_ctx* ctx, bool retry) {
     Shard& sh = shards[d];
+    sh.rc = 0;
+    sh.err.clear();
+    sh.chunks.clear();
+    sh.sum = 0;
+    sh.sum_bytes = 0;
+    if (!retry && fail_shard == static_cast<long>(d)) {
+      sh.rc = -1;
+      sh.err = "injected failure (ZOPFLI_AMD_TEST_FAIL_SHARD)";
+      return;
+    }
     const size_t start = parts[sh.first].instart, end = parts[sh.last - 1].inend;
     sh.base = start > zamd::kWindow ? start - zamd::kWindow : 0;
-    if (zmx_set_input(ctxs[d], in + sh.base, end - sh.base) != 0) {
+    if (zmx_set_input(ctx, in + sh.base, end - sh.base) != 0) {
       sh.rc = -1;
       sh.err = zmx_last_error();
       return;
     }
     if (sum && start < sum->limit) {
       sh.sum_bytes = std::min(end, sum->limit) - start;
-      if (zmx_checksum(ctxs[d], sum->kind, start - sh.base, start - sh.base + sh.sum_bytes, &sh.sum) != 0) {
+      if (zmx_checksum(ctx, sum->kind, start - sh.base, start - sh.base + sh.sum_bytes, &sh.sum) != 0) {
         sh.rc = -1;
         sh.err = zmx_last_error();
         return;
@@ -363,7 +379,7 @@ int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char
     }
     std::vector<zamd::Part> mine(parts.begin() + static_cast<long>(sh.first), parts.begin() + static_cast<long>(sh.last));
     for (auto& p : mine) { p.instart -= sh.base; p.inend -= sh.base; }
-    sh.rc = RunParts(ctxs[d], options, btype, mine, &sh.chunks);
+    sh.rc = RunParts(ctx, options, btype, mine, &sh.chunks);
     if (sh.rc) sh.err = zmx_last_error();
     for (auto& c : sh.chunks) {
       if (c.kind == zamd::Chunk::kStored) { c.start += sh.base; c.end += sh.base; }
@@ -371,11 +387,11 @@ int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char
     sh.timing = zamd::ThreadTiming();
   };
   if (ndev == 1) {
-    work(0);
+    work(0, ctxs[0], false);
   } else {
     std::vector<std::thread> threads;
-    for (size_t d = 1; d < ndev; ++d) threads.emplace_back(work, d);
-    work(0);
+    for (size_t d = 1; d < ndev; ++d) threads.emplace_back(work, d, ctxs[d], false);
+    work(0, ctxs[0], false);
     for (auto& t : threads) t.join();
     // the slowest device's breakdown stands for the request (zmx_last_timing)
     for (size_t d = 1; d < ndev; ++d) {
@@ -384,6 +400,18 @@ int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char
       if (a.tables + a.greedy + a.squeeze + a.cost_model + a.split + a.encode >
           t.tables + t.greedy + t.squeeze + t.cost_model + t.split + t.encode) t = a;
     }
+  }
+  // A shard that failed (its device ran out of memory, its context is broken) is done again on a context that just
+  // finished its own shard without error — another device's where there is one — before the request gives up: the
+  // parts are independent (deflate.c:916-923), whoever computes them computes the same bits.
+  for (size_t d = 0; d < ndev; ++d) {
+    if (!shards[d].rc) continue;
+    zmx_ctx* other = nullptr;
+    for (size_t e = 0; e < ndev && !other; ++e) if (e != d && !shards[e].rc && !shards[e].redone) other = ctxs[e];
+    if (!other) break;
+    std::fprintf(stderr, "zopfli_amd: a shard failed (%s): done again on another context\n", shards[d].err.c_str());
+    work(d, other, true);
+    shards[d].redone = true;
   }
   for (auto& sh : shards) {
     if (sh.rc) {
@@ -590,6 +618,47 @@ int zmx_last_host_timing(double* out2) {
   out2[0] = zamd::ThreadTiming().download;
   out2[1] = zamd::ThreadTiming().serialize;
   return 0;
+}
+
+// deflate.h:79,85 on the reference's own store type (lz77.h:44-62): the histogram of the range from litlens / dists,
+// its byte length from pos (lz77.c:160-166), then the block-cost code of the library (host/block_cost.cc)
+namespace {
+zamd::Histogram RangeHistogram(const ZopfliLZ77Store* lz77, size_t lstart, size_t lend) {
+  zamd::Histogram h;
+  h.Clear();
+  for (size_t i = lstart; i < lend; ++i) {
+    if (lz77->dists[i] == 0) {
+      h.ll[lz77->litlens[i]]++;
+    } else {
+      h.ll[zamd::LengthSymbol(lz77->litlens[i])]++;
+      h.d[zamd::DistSymbol(lz77->dists[i])]++;
+    }
+  }
+  return h;
+}
+double StoredSize(const ZopfliLZ77Store* lz77, size_t lstart, size_t lend) {
+  size_t length = 0;
+  if (lstart != lend) {
+    const size_t l = lend - 1;
+    length = lz77->pos[l] + (lz77->dists[l] == 0 ? 1 : lz77->litlens[l]) - lz77->pos[lstart];
+  }
+  const size_t rem = length % 65535;
+  const size_t blocks = length / 65535 + (rem ? 1 : 0);
+  return static_cast<double>(blocks * 5 * 8 + length * 8);      // deflate.c:591-597
+}
+}  // namespace
+
+double ZopfliCalculateBlockSize(const ZopfliLZ77Store* lz77, size_t lstart, size_t lend, int btype) {
+  if (btype == 0) return StoredSize(lz77, lstart, lend);
+  return zamd::BlockSizeFromHistogram(RangeHistogram(lz77, lstart, lend), btype);
+}
+
+double ZopfliCalculateBlockSizeAutoType(const ZopfliLZ77Store* lz77, size_t lstart, size_t lend) {
+  const double stored = StoredSize(lz77, lstart, lend);
+  const zamd::Histogram h = RangeHistogram(lz77, lstart, lend);
+  const double fixed = lz77->size > 1000 ? stored : zamd::BlockSizeFromHistogram(h, 1);   // deflate.c:614-616
+  const double dynamic = zamd::BlockSizeFromHistogram(h, 2);
+  return (stored < fixed && stored < dynamic) ? stored : (fixed < dynamic ? fixed : dynamic);
 }
 
 // zopflipng's per-row filter search on one of the entry points' contexts (include/zopfli_amd.h)

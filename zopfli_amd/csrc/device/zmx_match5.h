@@ -107,6 +107,46 @@ __device__ __forceinline__ u32 lv_key(const u32 (&w)[NW], u32 mlast) {
   return h >> (32u - LV_HBITS);
 }
 
+// one round of LV_U steps of 64 positions from job position s on; GUARD: the round may reach beyond the job's end n
+template <u32 NW, bool GUARD>
+__device__ __forceinline__ void lv_round(u32 (&w)[LV_U][NW], const u8* base, u16* out, u32* head, u32 s, u32 n, u32 mlast, u32 lane, u64 lt_mask) {
+  u32 key[LV_U], ret[LV_U];
+#pragma unroll
+  for (u32 u = 0; u < LV_U; ++u) key[u] = lv_key<NW>(w[u], mlast);
+  if (s + 64u * LV_U < n) {
+#pragma unroll
+    for (u32 u = 0; u < LV_U; ++u) lv_load<NW>(w[u], base + s + 64u * (LV_U + u) + lane);   // the next round's bytes
+  }
+#pragma unroll
+  for (u32 u = 0; u < LV_U; ++u) {
+    const u32 q = s + 64u * u + lane;
+    ret[u] = 0;
+    if (!GUARD || q < n) ret[u] = atomicMax(&head[key[u]], q + 1u);     // 0 = no position yet
+  }
+#pragma unroll
+  for (u32 u = 0; u < LV_U; ++u) {
+    const u32 q = s + 64u * u + lane;
+    const bool act = !GUARD || q < n;
+    const u32 r = q + 1u;
+    const u32 step0 = s + 64u * u + 1u;
+    u32 d = ret[u] ? r - ret[u] : 0u;
+    u64 F = __ballot(act && ret[u] >= step0);                  // lanes that saw a position of this very step
+    while (F) {
+      const u32 l0 = (u32)__ffsll((unsigned long long)F) - 1u;
+      const u32 k0 = rdlane_u32(key[u], l0);
+      const u64 G = __ballot(act && key[u] == k0);
+      const u32 old = wave_min_u32((G >> lane) & 1 ? ret[u] : 0xffffffffu);   // what the table held before the step
+      if ((G >> lane) & 1) {
+        const u64 lower = G & lt_mask;
+        d = lower ? lane - (63u - (u32)__clzll((long long)lower)) : (old ? r - old : 0u);
+      }
+      F &= ~G;
+    }
+    if (d > 32767u) d = 0;
+    if (act) out[q] = (u16)d;
+  }
+}
+
 template <u32 NW>
 __device__ __forceinline__ void lv_job(const LevelParams& P, const BlockDesc& bd, u32 lvl, u32* head) {
   const u64 L = bd.inend - bd.ws;
@@ -124,47 +164,19 @@ __device__ __forceinline__ void lv_job(const LevelParams& P, const BlockDesc& bd
   u32 w[LV_U][NW];
 #pragma unroll
   for (u32 u = 0; u < LV_U; ++u) lv_load<NW>(w[u], base + 64u * u + lane);   // (the input is padded past its end)
-  for (u32 s = 0; s < n; s += 64u * LV_U) {
-    u32 key[LV_U], ret[LV_U];
+  u32 s = 0;
+  // warm-up (a multiple of 64 LV_U positions): only the table matters — atomics whose results nobody waits for
+  for (; s < nw; s += 64u * LV_U) {
+    u32 key[LV_U];
 #pragma unroll
     for (u32 u = 0; u < LV_U; ++u) key[u] = lv_key<NW>(w[u], mlast);
-    if (s + 64u * LV_U < n) {
 #pragma unroll
-      for (u32 u = 0; u < LV_U; ++u) lv_load<NW>(w[u], base + s + 64u * (LV_U + u) + lane);   // the next round's bytes
-    }
-    const bool warm = s + 64u * LV_U <= nw;      // (nw is a multiple of 64 LV_U: a round is all warm-up or none)
+    for (u32 u = 0; u < LV_U; ++u) lv_load<NW>(w[u], base + s + 64u * (LV_U + u) + lane);   // (n > nw: there is a next round)
 #pragma unroll
-    for (u32 u = 0; u < LV_U; ++u) {
-      const u32 q = s + 64u * u + lane;
-      ret[u] = 0;
-      if (q < n) {
-        if (warm) atomicMax(&head[key[u]], q + 1u); else ret[u] = atomicMax(&head[key[u]], q + 1u);   // 0 = no position yet
-      }
-    }
-    if (warm) continue;
-#pragma unroll
-    for (u32 u = 0; u < LV_U; ++u) {
-      const u32 q = s + 64u * u + lane;
-      const bool act = q < n;
-      const u32 r = q + 1u;
-      const u32 step0 = s + 64u * u + 1u;
-      u32 d = ret[u] ? r - ret[u] : 0u;
-      u64 F = __ballot(act && ret[u] >= step0);                  // lanes that saw a position of this very step
-      while (F) {
-        const u32 l0 = (u32)__ffsll((unsigned long long)F) - 1u;
-        const u32 k0 = rdlane_u32(key[u], l0);
-        const u64 G = __ballot(act && key[u] == k0);
-        const u32 old = wave_min_u32((G >> lane) & 1 ? ret[u] : 0xffffffffu);   // what the table held before the step
-        if ((G >> lane) & 1) {
-          const u64 lower = G & lt_mask;
-          d = lower ? lane - (63u - (u32)__clzll((long long)lower)) : (old ? r - old : 0u);
-        }
-        F &= ~G;
-      }
-      if (d > 32767u) d = 0;
-      if (act) out[q] = (u16)d;
-    }
+    for (u32 u = 0; u < LV_U; ++u) atomicMax(&head[key[u]], s + 64u * u + lane + 1u);
   }
+  for (; s + 64u * LV_U <= n; s += 64u * LV_U) lv_round<NW, false>(w, base, out, head, s, n, mlast, lane, lt_mask);
+  if (s < n) lv_round<NW, true>(w, base, out, head, s, n, mlast, lane, lt_mask);
 }
 
 __global__ __launch_bounds__(64) void k_levels(LevelParams P) {
@@ -282,6 +294,25 @@ struct RankParams {
   u64 thr;
 };
 
+// val2 of 8 consecutive positions p .. p + 7 from the 16 bytes at p and their 8 run lengths
+__device__ __forceinline__ void rk_keys8(uint4 by, uint4 sm, u64 p, u64 L, u32 (&key)[8]) {
+  const u32 b[4] = {by.x, by.y, by.z, by.w};
+  const u32 m[4] = {sm.x, sm.y, sm.z, sm.w};
+#pragma unroll
+  for (u32 i = 0; i < 8; ++i) {
+    const u32 w0 = b[i >> 2], w1 = b[(i >> 2) + 1];           // (i + 2 <= 9: dword (i >> 2) + 1 <= 2)
+    const u32 sh = 8u * (i & 3u);
+    const u32 three = sh ? (w0 >> sh) | (w1 << (32u - sh)) : w0;
+    const u32 same = (i & 1u) ? m[i >> 1] >> 16 : m[i >> 1] & 0xffffu;
+    key[i] = rk_val2(three, p + i, L, same);
+  }
+}
+__device__ __forceinline__ uint4 rk_load16u(const u8* p) {
+  uint4 x;
+  __builtin_memcpy(&x, p, 16);
+  return x;
+}
+
 __global__ __launch_bounds__(RK_THREADS) void k_rank2(RankParams P) {
   __shared__ u32 cnt[16384];
   const BlockDesc bd = P.blocks[blockIdx.y];
@@ -295,7 +326,7 @@ __global__ __launch_bounds__(RK_THREADS) void k_rank2(RankParams P) {
   const u64 lt_mask = (1ull << lane) - 1;
   const u8* base = P.in + bd.ws;
   const ushort4* lk = P.links + bd.reg_off;
-  const u16* same = P.same16 + bd.reg_off;
+  const u16* same = P.same16 + bd.reg_off;      // (reg_off is a multiple of 8 entries: 16-byte loads of 8 are aligned)
   u16* tt = P.tot2 + bd.reg_off;
   u16* rk = P.rank2 + bd.reg_off;
   const u16* lev = P.lev + bd.reg_off;
@@ -303,65 +334,57 @@ __global__ __launch_bounds__(RK_THREADS) void k_rank2(RankParams P) {
 
   for (u32 i = tid; i < 16384; i += RK_THREADS) cnt[i] = 0;
   __syncthreads();
+  // 1. the class sizes of the chunk before (a whole chunk: 8 positions a thread and turn)
   if (e0 > 0) {
-    for (u64 s = e0 - RK_CH; s < e0; s += RK_THREADS * RK_U) {
-      u32 by[RK_U], sm[RK_U];
+    for (u64 s = e0 - RK_CH + 8u * tid; s < e0; s += 8u * RK_THREADS) {
+      u32 key[8];
+      rk_keys8(rk_load16u(base + s), *reinterpret_cast<const uint4*>(same + s), s, L, key);
 #pragma unroll
-      for (u32 u = 0; u < RK_U; ++u) {
-        const u64 p = s + RK_THREADS * u + tid;
-        by[u] = rk_load_u32(base + p);
-        sm[u] = same[p];
-      }
-#pragma unroll
-      for (u32 u = 0; u < RK_U; ++u) {
-        const u32 key = rk_val2(by[u], s + RK_THREADS * u + tid, L, sm[u]);
-        atomicAdd(&cnt[key >> 1], 1u << (16u * (key & 1u)));
-      }
+      for (u32 i = 0; i < 8; ++i) atomicAdd(&cnt[key[i] >> 1], 1u << (16u * (key[i] & 1u)));
     }
   }
   __syncthreads();
-  for (u64 s = e0; s < e1; s += RK_THREADS * RK_U) {
-    u32 by[RK_U], sm[RK_U];
+  // 2. tot2 of the chunk's positions (the arrays are padded to a multiple of 8 entries per block: whole groups), and
+  //    what pass 3 needs of a position in ONE 16-bit word: its key, and (bit 15) whether the previous member of its
+  //    class lies inside its step of 64 — prev2 says so
+  for (u64 s = e0 + 8u * tid; s < e1; s += 8u * RK_THREADS) {
+    u32 key[8];
+    rk_keys8(rk_load16u(base + s), *reinterpret_cast<const uint4*>(same + s), s, L, key);
+    uint4 l4[4];
 #pragma unroll
-    for (u32 u = 0; u < RK_U; ++u) {
-      const u64 p = s + RK_THREADS * u + tid;
-      by[u] = p < e1 ? rk_load_u32(base + p) : 0u;
-      sm[u] = p < e1 ? (u32)same[p] : 0u;
-    }
+    for (u32 i = 0; i < 4; ++i) l4[i] = reinterpret_cast<const uint4*>(lk + s)[i];
+    u32 t[8], kd[8];
 #pragma unroll
-    for (u32 u = 0; u < RK_U; ++u) {
-      const u64 p = s + RK_THREADS * u + tid;
-      if (p < e1) {
-        const u32 key = rk_val2(by[u], p, L, sm[u]);
-        tt[p] = (u16)(cnt[key >> 1] >> (16u * (key & 1u)));
-      }
+    for (u32 i = 0; i < 8; ++i) {
+      t[i] = (cnt[key[i] >> 1] >> (16u * (key[i] & 1u))) & 0xffffu;
+      const u32 d2 = ((i & 1u) ? l4[i >> 1].z : l4[i >> 1].x) >> 16;        // prev2 of position s + i
+      const u32 in_step = (u32)(s + i - e0) & 63u;
+      kd[i] = key[i] | ((d2 != 0 && d2 <= in_step) ? 0x8000u : 0u);
     }
+    *reinterpret_cast<uint4*>(tt + s) = make_uint4(t[0] | (t[1] << 16), t[2] | (t[3] << 16), t[4] | (t[5] << 16), t[6] | (t[7] << 16));
+    *reinterpret_cast<uint4*>(rk + s) = make_uint4(kd[0] | (kd[1] << 16), kd[2] | (kd[3] << 16), kd[4] | (kd[5] << 16), kd[6] | (kd[7] << 16));
   }
   __syncthreads();
   for (u32 i = tid; i < 16384; i += RK_THREADS) cnt[i] = 0;
   __syncthreads();
+  // 3. ranks within the chunk: one wave, in position order, eight steps' words in flight
   if (tid < 64) {
-    for (u64 s = e0; s < e1; s += 64u * RK_U) {
-      u32 by[RK_U], sm[RK_U], d2[RK_U];
+    for (u64 s = e0; s < e1; s += 64u * 8u) {
+      u32 kd[8];
 #pragma unroll
-      for (u32 u = 0; u < RK_U; ++u) {
+      for (u32 u = 0; u < 8; ++u) {
         const u64 p = s + 64u * u + lane;
-        const bool act = p < e1;
-        by[u] = act ? rk_load_u32(base + p) : 0u;
-        sm[u] = act ? (u32)same[p] : 0u;
-        d2[u] = act ? (u32)lk[p].y : 0u;
+        kd[u] = p < e1 ? (u32)rk[p] : 0xffffffffu;
       }
 #pragma unroll
-      for (u32 u = 0; u < RK_U; ++u) {
+      for (u32 u = 0; u < 8; ++u) {
         const u64 p = s + 64u * u + lane;
-        const bool act = p < e1;
-        const u32 key = act ? rk_val2(by[u], p, L, sm[u]) : 0u;
+        const bool act = kd[u] != 0xffffffffu;
+        const u32 key = kd[u] & 0x7fffu;
         u32 rank = act ? (cnt[key >> 1] >> (16u * (key & 1u))) & 0xffffu : 0u;   // the state before this step
         wave_lds_sync();
         if (act) atomicAdd(&cnt[key >> 1], 1u << (16u * (key & 1u)));
-        // positions of this step with the same key: the previous member of the class lies inside the step
-        const bool dup = act && d2[u] != 0 && d2[u] <= lane;
-        if (__any(dup)) {
+        if (__any(act && (kd[u] & 0x8000u))) {     // members of one class inside the step: in lane order
           u64 grp = __ballot(act);
 #pragma unroll
           for (int bit = 0; bit < 15; ++bit) {
@@ -377,36 +400,38 @@ __global__ __launch_bounds__(RK_THREADS) void k_rank2(RankParams P) {
     }
   }
   __syncthreads();
-  for (u64 s = e0; s < e1; s += RK_THREADS * 2u) {
-    ushort4 l4[2];
-    u32 tot[2], rnk[2];
-    u32 lv[2][LV_N];
+  // 4. the records: 8 positions a thread and turn, every array in 16-byte pieces
+  for (u64 s = e0 + 8u * tid; s < e1; s += 8u * RK_THREADS) {
+    uint4 l4[4], lv[LV_N];
 #pragma unroll
-    for (u32 u = 0; u < 2; ++u) {
-      const u64 p = s + RK_THREADS * u + tid;
-      const bool act = p < e1;
-      l4[u] = act ? lk[p] : make_ushort4(0, 0, 0, 0);
-      tot[u] = act ? (u32)tt[p] : 0u;
-      rnk[u] = act ? (u32)rk[p] : 0u;
+    for (u32 i = 0; i < 4; ++i) l4[i] = reinterpret_cast<const uint4*>(lk + s)[i];
+    const uint4 t4 = *reinterpret_cast<const uint4*>(tt + s), r4 = *reinterpret_cast<const uint4*>(rk + s);
 #pragma unroll
-      for (u32 j = 0; j < LV_N; ++j) lv[u][j] = act ? (u32)lev[(u64)j * P.total_l + p] : 0u;
-    }
+    for (u32 j = 0; j < LV_N; ++j) lv[j] = *reinterpret_cast<const uint4*>(lev + (u64)j * P.total_l + s);
+    const u32 tw[4] = {t4.x, t4.y, t4.z, t4.w}, rw[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
-    for (u32 u = 0; u < 2; ++u) {
-      const u64 p = s + RK_THREADS * u + tid;
-      if (p < e1) {
-        uint4 a, b;
-        a.x = (u32)l4[u].x | ((u32)l4[u].y << 16);
-        a.y = (u32)l4[u].z | (((tot[u] + rnk[u]) & 0xffffu) << 16);
-        a.z = tot[u];
-        a.w = lv[u][0] | (lv[u][1] << 16);
-        b.x = lv[u][2] | (lv[u][3] << 16);
-        b.y = lv[u][4] | (lv[u][5] << 16);
-        b.z = lv[u][6] | (lv[u][7] << 16);
-        b.w = lv[u][8] | (lv[u][9] << 16);
-        xr[2 * p] = a;
-        xr[2 * p + 1] = b;
+    for (u32 i = 0; i < 8; ++i) {
+      if (s + i >= e1) break;
+      const u32 lx = (i & 1u) ? l4[i >> 1].z : l4[i >> 1].x, ly = (i & 1u) ? l4[i >> 1].w : l4[i >> 1].y;   // links[s + i] as two dwords
+      const u32 tot = (i & 1u) ? tw[i >> 1] >> 16 : tw[i >> 1] & 0xffffu;
+      const u32 rnk = (i & 1u) ? rw[i >> 1] >> 16 : rw[i >> 1] & 0xffffu;
+      u32 l[LV_N];
+#pragma unroll
+      for (u32 j = 0; j < LV_N; ++j) {
+        const u32 wsel = (i >> 1) == 0 ? lv[j].x : (i >> 1) == 1 ? lv[j].y : (i >> 1) == 2 ? lv[j].z : lv[j].w;
+        l[j] = (i & 1u) ? wsel >> 16 : wsel & 0xffffu;
       }
+      uint4 a, b;
+      a.x = lx;                                        // prev1 | prev2 << 16
+      a.y = (ly & 0xffffu) | (((tot + rnk) & 0xffffu) << 16);   // same | wc2 << 16
+      a.z = tot;
+      a.w = l[0] | (l[1] << 16);
+      b.x = l[2] | (l[3] << 16);
+      b.y = l[4] | (l[5] << 16);
+      b.z = l[6] | (l[7] << 16);
+      b.w = l[8] | (l[9] << 16);
+      xr[2 * (s + i)] = a;
+      xr[2 * (s + i) + 1] = b;
     }
   }
 }

@@ -335,12 +335,13 @@ int zmx_last_host_timing(double* out2);
  * the match kernel computed (the others were copied from the parent tables). */
 int zmx_last_match_timing(double* out4);
 
-/* Several contexts on one device (the Zopfli* entry points keep up to three per device): a context's budgets — what its
- * pool keeps cached between batches, what one batch's DP edges may take — are a third of the device's free memory at
- * creation divided by `contexts_on_device`; zmx_ctx_trim_cache gives an IDLE context's cached arrays back to the
- * device; the hook (one per process, may be null) is called with the device index when an allocation still fails
- * after the failing context dropped its own cache — the owner of the contexts trims the idle ones there — and the
- * allocation is tried once more. */
+/* Several contexts on one device (the Zopfli* entry points keep up to three per device).  The budgets are the DEVICE's,
+ * not a context's: what the pools of all its contexts keep cached between batches counts against one third of its memory
+ * together, what one batch's DP edges may take is a third; a table build that cannot allocate (the other contexts are
+ * busy) returns -2, "come back with fewer blocks", like one beyond that budget.  zmx_ctx_trim_cache gives an IDLE
+ * context's cached arrays back to the device; the hook (one per process, may be null) is called with the device index when
+ * an allocation still fails after the failing context dropped its own cache — the owner of the contexts trims the idle
+ * ones there — and the allocation is tried once more.  zmx_ctx_set_share tells a context how many share its device. */
 typedef void (*zmx_oom_hook_t)(int device);
 void zmx_set_oom_hook(zmx_oom_hook_t hook);
 int zmx_ctx_set_share(zmx_ctx* ctx, unsigned contexts_on_device);

@@ -39,10 +39,14 @@ double g_squeeze_launches = 0;
 double g_match_stats[4] = {0, 0, 0, 0};  // k_match2 seconds, k_same + k_chain seconds, table builds, positions matched
 double g_seg_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // tasks, accepted, re-run: state / level / tie, positions re-run, re-run: values, positions
 
+thread_local bool g_last_oom = false;   // the last failure of this thread was an allocation the device could not serve
+
 int Fail(const char* what, hipError_t e, const char* file, int line) {
   char buf[512];
   std::snprintf(buf, sizeof(buf), "%s: %s (%s:%d)", what, hipGetErrorString(e), file, line);
   g_err = buf;
+  g_last_oom = e == hipErrorOutOfMemory;
+  if (g_last_oom) (void)hipGetLastError();
   return -1;
 }
 int FailMsg(const std::string& m) {
@@ -127,7 +131,8 @@ struct zmx_ctx {
   std::unordered_map<void*, GuardInfo> guard_live;
   size_t pool_keep = 0;      // what the pool may keep cached between batches, and what one batch's DP edges may take:
   size_t code_budget = 0;    // a third of the device's memory each (hipMemGetInfo at creation), at most 96 GiB,
-  size_t keep_base = 0;      // divided by the number of contexts that share the device (zmx_ctx_set_share)
+  size_t keep_base = 0;
+  unsigned shares = 1;       // contexts on this device (zmx_ctx_set_share)
   u64* d_guard_tab = nullptr;   // [kGuardMaxAllocs][2] zone pairs for k_guard_check, then 4 result words
   u64 guard_checks = 0;
 };
@@ -239,6 +244,15 @@ hipError_t GuardDress(zmx_ctx* c, void* base, size_t bytes, size_t cap, const ch
 }
 
 std::atomic<zmx_oom_hook_t> g_oom_hook{nullptr};
+// What the pools of ALL contexts of a device keep cached between batches, against ONE budget per device (a third of its
+// memory): a lone busy context may cache all of it (100 MB of long runs are 52 GB of DP codes per batch; with a
+// per-context third of a third they were hipFree'd and hipMalloc'ed every step: class Z 132 -> 49 MB/s), three busy
+// ones share it, and idle ones are trimmed when another runs out (zmx_set_oom_hook).
+constexpr int kMaxDevices = 64;
+std::atomic<size_t> g_dev_cached[kMaxDevices];
+inline std::atomic<size_t>& DevCached(const zmx_ctx* c);
+
+inline std::atomic<size_t>& DevCached(const zmx_ctx* c) { return g_dev_cached[c->device >= 0 && c->device < kMaxDevices ? c->device : 0]; }
 
 hipError_t PoolAllocBytes(zmx_ctx* c, void** p, size_t bytes, const char* tag) {
   if (bytes == 0) bytes = 1;
@@ -257,6 +271,7 @@ hipError_t PoolAllocBytes(zmx_ctx* c, void** p, size_t bytes, const char* tag) {
     base = c->pool_free[best].first;
     cap = c->pool_free[best].second;
     c->pool_free_bytes -= cap;
+    DevCached(c).fetch_sub(cap, std::memory_order_relaxed);
     c->pool_free.erase(c->pool_free.begin() + static_cast<long>(best));
   } else {
     hipError_t e = hipMalloc(&base, want);
@@ -264,6 +279,7 @@ hipError_t PoolAllocBytes(zmx_ctx* c, void** p, size_t bytes, const char* tag) {
       (void)hipGetLastError();
       for (auto& f : c->pool_free) (void)hipFree(f.first);
       c->pool_free.clear();
+      DevCached(c).fetch_sub(c->pool_free_bytes, std::memory_order_relaxed);
       c->pool_free_bytes = 0;
       e = hipMalloc(&base, want);
     }
@@ -349,9 +365,15 @@ void PoolFree(zmx_ctx* c, void* p) {
       const size_t cap = it->second;
       c->pool_live.erase(it);
       if (c->guard_live.erase(p)) base = static_cast<unsigned char*>(p) - kGuardBytes;
-      if (c->pool_free_bytes + cap <= c->pool_keep) {
+      if (DevCached(c).load(std::memory_order_relaxed) + cap > c->pool_keep) {
+        // the device's cache budget is used up: the idle contexts' caches go first — the context that is working
+        // is the one whose arrays will be asked for again
+        if (const zmx_oom_hook_t hook = g_oom_hook.load(std::memory_order_acquire)) hook(c->device);
+      }
+      if (DevCached(c).load(std::memory_order_relaxed) + cap <= c->pool_keep) {
         c->pool_free.emplace_back(base, cap);
         c->pool_free_bytes += cap;
+        DevCached(c).fetch_add(cap, std::memory_order_relaxed);
         return;
       }
     }
@@ -423,9 +445,11 @@ void zmx_set_oom_hook(zmx_oom_hook_t hook) { g_oom_hook.store(hook, std::memory_
 
 int zmx_ctx_set_share(zmx_ctx* c, unsigned contexts_on_device) {
   if (!c) return FailMsg("zmx_ctx_set_share: no context");
-  const size_t n = contexts_on_device ? contexts_on_device : 1;
-  c->pool_keep = c->keep_base / n;
-  c->code_budget = c->keep_base / n;
+  // (The budgets are per DEVICE now, whoever uses them: the cache of all its contexts together against one third of its
+  //  memory — g_dev_cached —, one batch's DP edges against one third.  The number of contexts that share the device is
+  //  kept for the record; a build that cannot allocate because the others are busy comes back as "too large" and the
+  //  caller halves the batch.)
+  c->shares = contexts_on_device ? contexts_on_device : 1;
   return 0;
 }
 
@@ -435,6 +459,7 @@ int zmx_ctx_trim_cache(zmx_ctx* c) {
   HIPCHK(dev_guard.err);
   for (auto& f : c->pool_free) (void)hipFree(f.first);
   c->pool_free.clear();
+  DevCached(c).fetch_sub(c->pool_free_bytes, std::memory_order_relaxed);
   c->pool_free_bytes = 0;
   return 0;
 }
@@ -512,6 +537,7 @@ void zmx_ctx_destroy(zmx_ctx* c) {
   DeviceGuard dev_guard(c->device);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   for (auto& f : c->pool_free) (void)hipFree(f.first);
+  DevCached(c).fetch_sub(c->pool_free_bytes, std::memory_order_relaxed);
   // (the input and k_match2's scratch are pooled allocations too; in guard mode the caller's pointer lies behind a red zone)
   for (auto& f : c->pool_live) (void)hipFree(c->guard_live.count(f.first) ? static_cast<unsigned char*>(f.first) - kGuardBytes : f.first);
   (void)hipFree(c->d_guard_tab);
@@ -1318,10 +1344,13 @@ int zmx_tables_build_matches(zmx_ctx* c, const zmx_block* blocks, size_t nblocks
   DeviceGuard dev_guard(c->device);
   HIPCHK(dev_guard.err);
   zmx_tables* t = new zmx_tables();
+  g_last_oom = false;
   const int rc = BuildTables(c, blocks, nblocks, t, nullptr, false);
   if (rc) {
     zmx_tables_free(c, t);
-    return rc;
+    // out of device memory (other contexts of the device hold theirs): the caller may come back with fewer blocks,
+    // as for a batch beyond the code budget
+    return rc == -1 && g_last_oom && nblocks > 1 ? kTooLarge : rc;
   }
   *out = t;
   return 0;
@@ -1332,10 +1361,11 @@ int zmx_tables_build_from(zmx_ctx* c, zmx_tables* parent, const zmx_block* block
   DeviceGuard dev_guard(c->device);
   HIPCHK(dev_guard.err);
   zmx_tables* t = new zmx_tables();
+  g_last_oom = false;
   const int rc = BuildTables(c, blocks, nblocks, t, parent);
   if (rc) {
     zmx_tables_free(c, t);
-    return rc;
+    return rc == -1 && g_last_oom && nblocks > 1 ? kTooLarge : rc;
   }
   *out = t;
   return 0;

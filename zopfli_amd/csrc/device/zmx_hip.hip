@@ -822,6 +822,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   u16* d_tot2 = nullptr;
   u16* d_rank2 = nullptr;
   uint4* d_xrec = nullptr;
+  u32* d_tot12 = nullptr;
   unsigned long long* d_energy = nullptr;   // k_hits (kernel 0 = per block: k_match5 where the chains are long)
   bool skip_any = false, skip_all = false;  // some / all blocks of this build take k_match5
   bool join_stream2 = false;
@@ -872,8 +873,9 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
         }
         if (skip_any) {
           if (!d_lev) HIPCHK(hash_tmp.AllocT(&d_lev, static_cast<size_t>(LV_N) * reg_off, "d_lev"));
-          if (!d_tot2) HIPCHK(hash_tmp.AllocT(&d_tot2, reg_off, "d_tot2"));
-          if (!d_rank2) HIPCHK(hash_tmp.AllocT(&d_rank2, reg_off, "d_rank2"));
+          if (!d_tot2) HIPCHK(hash_tmp.AllocT(&d_tot2, 2 * reg_off, "d_tot"));
+          if (!d_rank2) HIPCHK(hash_tmp.AllocT(&d_rank2, 2 * reg_off, "d_rank"));
+          if (!d_tot12) HIPCHK(hash_tmp.AllocT(&d_tot12, reg_off, "d_tot12"));
           if (!d_xrec) HIPCHK(hash_tmp.AllocT(&d_xrec, 2 * reg_off, "d_xrec"));
           LevelParams lp;
           lp.in = c->d_in;
@@ -892,9 +894,10 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
           rp.same16 = t->d_same16;
           rp.lev = d_lev;
           rp.total_l = reg_off;
-          rp.tot2 = d_tot2;
-          rp.rank2 = d_rank2;
+          rp.tot = d_tot2;
+          rp.rank = d_rank2;
           rp.xrec = d_xrec;
+          rp.tot12 = d_tot12;
           rp.energy = lp.energy;
           rp.thr = lp.thr;
           const dim3 g3(static_cast<unsigned>((max_l + RK_CH - 1) / RK_CH), static_cast<unsigned>(nb));
@@ -970,6 +973,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
       q.m = mp;
       q.m.scratch = c->d_scratch5;
       q.xrec = d_xrec;
+      q.tot12 = d_tot12;
       q.energy = mk == 0 ? d_energy : nullptr;
       q.thr = MatchAutoHits();
       if (mk == 5 || skip_all) {

@@ -42,7 +42,7 @@ __device__ __forceinline__ int lv_level_for(u32 n) {
 }
 
 // One 32-byte record per region position for k_match5 (k_rank2 writes it), as 16-bit fields:
-//   0 prev1, 1 prev2, 2 same (k_chain's links)   3 wc2, 4 tot2 (below)   5 unused   6 .. 15 the level links
+//   0 prev1, 1 prev2, 2 same (k_chain's links)   3 rank1, 4 rank2 (k_rank2)   5 unused   6 .. 15 the level links
 #define XR_LV0 6u
 
 // wave-wide minimum (every lane gets it)
@@ -266,17 +266,19 @@ __global__ __launch_bounds__(RK_THREADS) void k_hits(HitsParams P) {
 }
 
 // ----------------------------------------------------------------------------
-// k_rank2: the position's record for k_match5 — k_chain's links, the level links, and the position's rank within
-// its val2 class (the second hash's chain, hash.c:129-135) per 32768-position chunk of the region:
-//   tot2 = number of positions of the chunk BEFORE the position's with its val2
-//   wc2  = tot2 + number of positions before it in its own chunk with its val2
+// k_rank2: the position's record for k_match5 — k_chain's links, the level links, and the position's RANK within each
+// of its two classes — positions of its 3-byte hash (the first chain, hash.c:110-114), positions of its val2 (the
+// second chain, hash.c:129-135) — per 32768-position chunk of the region:
+//   rank = number of positions before it in its own chunk with its hash value        (in the record)
+//   tot  = number of positions of the chunk BEFORE its own with that hash value       (tot12[]: asked for pos only)
 // so that the number of chain entries from a member c of pos's class down to a member q (both within 32767 of pos:
-// in pos's chunk or the one before) is g(c) - g(q), g(x) = x in pos's chunk ? wc2[x] : wc2[x] - tot2[x].
+// in pos's chunk or the one before) is g(c) - g(q), g(x) = rank[x] + (x in pos's chunk ? tot[pos] : 0).
 // One workgroup per (chunk, block); 32768 16-bit counters, two to a word, in LDS (64 KB): a class has at most 32768
-// members in a chunk, so a half never carries into its neighbour.  Four passes: all waves count the chunk before;
-// all waves read those counts for the chunk's positions (tot2); ONE wave counts the chunk itself in position order,
-// a step of 64 at a time — the count before the step is the rank of the step's first member of a class, members of
-// one class inside a step (prev2 says so) are ordered with ballots; all waves put the records together.
+// members in a chunk, so a half never carries into its neighbour.  Per class three passes: all waves count the chunk
+// before; all waves read those counts for the chunk's positions (tot); ONE wave counts the chunk itself in position
+// order, a step of 64 at a time — the count before the step is the rank of the step's first member of a class,
+// members of one class inside a step (the chain's link says so) are ordered with ballots.  Then all waves put the
+// records together.
 // ----------------------------------------------------------------------------
 #define RK_U 4u
 
@@ -287,9 +289,10 @@ struct RankParams {
   const u16* same16;
   const u16* lev;
   u64 total_l;
-  u16* tot2;          // scratch, one per region position
-  u16* rank2;         // scratch, one per region position
+  u16* tot;           // scratch, two per region position (class-major: [cls * total_l + position])
+  u16* rank;          // scratch, likewise
   uint4* xrec;        // out: two per region position
+  u32* tot12;         // out: one per region position
   const unsigned long long* energy;
   u64 thr;
 };
@@ -327,104 +330,117 @@ __global__ __launch_bounds__(RK_THREADS) void k_rank2(RankParams P) {
   const u8* base = P.in + bd.ws;
   const ushort4* lk = P.links + bd.reg_off;
   const u16* same = P.same16 + bd.reg_off;      // (reg_off is a multiple of 8 entries: 16-byte loads of 8 are aligned)
-  u16* tt = P.tot2 + bd.reg_off;
-  u16* rk = P.rank2 + bd.reg_off;
   const u16* lev = P.lev + bd.reg_off;
   uint4* xr = P.xrec + bd.reg_off * 2;
+  u32* t12 = P.tot12 + bd.reg_off;
 
-  for (u32 i = tid; i < 16384; i += RK_THREADS) cnt[i] = 0;
-  __syncthreads();
-  // 1. the class sizes of the chunk before (a whole chunk: 8 positions a thread and turn)
-  if (e0 > 0) {
-    for (u64 s = e0 - RK_CH + 8u * tid; s < e0; s += 8u * RK_THREADS) {
-      u32 key[8];
-      rk_keys8(rk_load16u(base + s), *reinterpret_cast<const uint4*>(same + s), s, L, key);
+  // the two classes in turn: cls 0 = the 3-byte hash (val: the first chain), cls 1 = val2 (the second chain)
+  for (u32 cls = 0; cls < 2; ++cls) {
+    u16* tt = P.tot + cls * P.total_l + bd.reg_off;
+    u16* rk = P.rank + cls * P.total_l + bd.reg_off;
+    __syncthreads();
+    for (u32 i = tid; i < 16384; i += RK_THREADS) cnt[i] = 0;
+    __syncthreads();
+    // 1. the class sizes of the chunk before (a whole chunk: 8 positions a thread and turn)
+    if (e0 > 0) {
+      for (u64 s = e0 - RK_CH + 8u * tid; s < e0; s += 8u * RK_THREADS) {
+        u32 key[8];
+        rk_keys8(rk_load16u(base + s), cls ? *reinterpret_cast<const uint4*>(same + s) : make_uint4(0x00030003u, 0x00030003u, 0x00030003u, 0x00030003u), s, L, key);
 #pragma unroll
-      for (u32 i = 0; i < 8; ++i) atomicAdd(&cnt[key[i] >> 1], 1u << (16u * (key[i] & 1u)));
-    }
-  }
-  __syncthreads();
-  // 2. tot2 of the chunk's positions (the arrays are padded to a multiple of 8 entries per block: whole groups), and
-  //    what pass 3 needs of a position in ONE 16-bit word: its key, and (bit 15) whether the previous member of its
-  //    class lies inside its step of 64 — prev2 says so
-  for (u64 s = e0 + 8u * tid; s < e1; s += 8u * RK_THREADS) {
-    u32 key[8];
-    rk_keys8(rk_load16u(base + s), *reinterpret_cast<const uint4*>(same + s), s, L, key);
-    uint4 l4[4];
-#pragma unroll
-    for (u32 i = 0; i < 4; ++i) l4[i] = reinterpret_cast<const uint4*>(lk + s)[i];
-    u32 t[8], kd[8];
-#pragma unroll
-    for (u32 i = 0; i < 8; ++i) {
-      t[i] = (cnt[key[i] >> 1] >> (16u * (key[i] & 1u))) & 0xffffu;
-      const u32 d2 = ((i & 1u) ? l4[i >> 1].z : l4[i >> 1].x) >> 16;        // prev2 of position s + i
-      const u32 in_step = (u32)(s + i - e0) & 63u;
-      kd[i] = key[i] | ((d2 != 0 && d2 <= in_step) ? 0x8000u : 0u);
-    }
-    *reinterpret_cast<uint4*>(tt + s) = make_uint4(t[0] | (t[1] << 16), t[2] | (t[3] << 16), t[4] | (t[5] << 16), t[6] | (t[7] << 16));
-    *reinterpret_cast<uint4*>(rk + s) = make_uint4(kd[0] | (kd[1] << 16), kd[2] | (kd[3] << 16), kd[4] | (kd[5] << 16), kd[6] | (kd[7] << 16));
-  }
-  __syncthreads();
-  for (u32 i = tid; i < 16384; i += RK_THREADS) cnt[i] = 0;
-  __syncthreads();
-  // 3. ranks within the chunk: one wave, in position order, eight steps' words in flight
-  if (tid < 64) {
-    for (u64 s = e0; s < e1; s += 64u * 8u) {
-      u32 kd[8];
-#pragma unroll
-      for (u32 u = 0; u < 8; ++u) {
-        const u64 p = s + 64u * u + lane;
-        kd[u] = p < e1 ? (u32)rk[p] : 0xffffffffu;
+        for (u32 i = 0; i < 8; ++i) atomicAdd(&cnt[key[i] >> 1], 1u << (16u * (key[i] & 1u)));
       }
+    }
+    __syncthreads();
+    // 2. the class sizes for the chunk's positions (the arrays are padded to a multiple of 8 entries per block: whole
+    //    groups), and what pass 3 needs of a position in ONE 16-bit word: its key, and (bit 15) whether the previous member
+    //    of its class lies inside its step of 64 — the chain's link says so
+    for (u64 s = e0 + 8u * tid; s < e1; s += 8u * RK_THREADS) {
+      u32 key[8];
+      rk_keys8(rk_load16u(base + s), cls ? *reinterpret_cast<const uint4*>(same + s) : make_uint4(0x00030003u, 0x00030003u, 0x00030003u, 0x00030003u), s, L, key);
+      uint4 l4[4];
 #pragma unroll
-      for (u32 u = 0; u < 8; ++u) {
-        const u64 p = s + 64u * u + lane;
-        const bool act = kd[u] != 0xffffffffu;
-        const u32 key = kd[u] & 0x7fffu;
-        u32 rank = act ? (cnt[key >> 1] >> (16u * (key & 1u))) & 0xffffu : 0u;   // the state before this step
-        wave_lds_sync();
-        if (act) atomicAdd(&cnt[key >> 1], 1u << (16u * (key & 1u)));
-        if (__any(act && (kd[u] & 0x8000u))) {     // members of one class inside the step: in lane order
-          u64 grp = __ballot(act);
+      for (u32 i = 0; i < 4; ++i) l4[i] = reinterpret_cast<const uint4*>(lk + s)[i];
+      u32 t[8], kd[8];
 #pragma unroll
-          for (int bit = 0; bit < 15; ++bit) {
-            const bool mine = (key >> bit) & 1;
-            const u64 bm = __ballot(mine);
-            grp &= mine ? bm : ~bm;
-          }
-          rank += (u32)__popcll(grp & lt_mask);
+      for (u32 i = 0; i < 8; ++i) {
+        t[i] = (cnt[key[i] >> 1] >> (16u * (key[i] & 1u))) & 0xffffu;
+        const u32 l01 = (i & 1u) ? l4[i >> 1].z : l4[i >> 1].x;                  // prev1 | prev2 << 16 of position s + i
+        const u32 d = cls ? l01 >> 16 : l01 & 0xffffu;
+        const u32 in_step = (u32)(s + i - e0) & 63u;
+        kd[i] = key[i] | ((d != 0 && d <= in_step) ? 0x8000u : 0u);
+      }
+      *reinterpret_cast<uint4*>(tt + s) = make_uint4(t[0] | (t[1] << 16), t[2] | (t[3] << 16), t[4] | (t[5] << 16), t[6] | (t[7] << 16));
+      *reinterpret_cast<uint4*>(rk + s) = make_uint4(kd[0] | (kd[1] << 16), kd[2] | (kd[3] << 16), kd[4] | (kd[5] << 16), kd[6] | (kd[7] << 16));
+    }
+    __syncthreads();
+    for (u32 i = tid; i < 16384; i += RK_THREADS) cnt[i] = 0;
+    __syncthreads();
+    // 3. ranks within the chunk: one wave, in position order, eight steps' words in flight
+    if (tid < 64) {
+      for (u64 s = e0; s < e1; s += 64u * 8u) {
+        u32 kd[8];
+#pragma unroll
+        for (u32 u = 0; u < 8; ++u) {
+          const u64 p = s + 64u * u + lane;
+          kd[u] = p < e1 ? (u32)rk[p] : 0xffffffffu;
         }
-        wave_lds_sync();
-        if (act) rk[p] = (u16)rank;
+#pragma unroll
+        for (u32 u = 0; u < 8; ++u) {
+          const u64 p = s + 64u * u + lane;
+          const bool act = kd[u] != 0xffffffffu;
+          const u32 key = kd[u] & 0x7fffu;
+          u32 rank = act ? (cnt[key >> 1] >> (16u * (key & 1u))) & 0xffffu : 0u;   // the state before this step
+          wave_lds_sync();
+          if (act) atomicAdd(&cnt[key >> 1], 1u << (16u * (key & 1u)));
+          if (__any(act && (kd[u] & 0x8000u))) {     // members of one class inside the step: in lane order
+            u64 grp = __ballot(act);
+#pragma unroll
+            for (int bit = 0; bit < 15; ++bit) {
+              const bool mine = (key >> bit) & 1;
+              const u64 bm = __ballot(mine);
+              grp &= mine ? bm : ~bm;
+            }
+            rank += (u32)__popcll(grp & lt_mask);
+          }
+          wave_lds_sync();
+          if (act) rk[p] = (u16)rank;
+        }
       }
     }
   }
   __syncthreads();
   // 4. the records: 8 positions a thread and turn, every array in 16-byte pieces
+  const u16* tt1 = P.tot + bd.reg_off;
+  const u16* tt2 = P.tot + P.total_l + bd.reg_off;
+  const u16* rk1 = P.rank + bd.reg_off;
+  const u16* rk2 = P.rank + P.total_l + bd.reg_off;
   for (u64 s = e0 + 8u * tid; s < e1; s += 8u * RK_THREADS) {
     uint4 l4[4], lv[LV_N];
 #pragma unroll
     for (u32 i = 0; i < 4; ++i) l4[i] = reinterpret_cast<const uint4*>(lk + s)[i];
-    const uint4 t4 = *reinterpret_cast<const uint4*>(tt + s), r4 = *reinterpret_cast<const uint4*>(rk + s);
+    const uint4 ta = *reinterpret_cast<const uint4*>(tt1 + s), tb = *reinterpret_cast<const uint4*>(tt2 + s);
+    const uint4 ra = *reinterpret_cast<const uint4*>(rk1 + s), rb = *reinterpret_cast<const uint4*>(rk2 + s);
 #pragma unroll
     for (u32 j = 0; j < LV_N; ++j) lv[j] = *reinterpret_cast<const uint4*>(lev + (u64)j * P.total_l + s);
-    const u32 tw[4] = {t4.x, t4.y, t4.z, t4.w}, rw[4] = {r4.x, r4.y, r4.z, r4.w};
+    const u32 taw[4] = {ta.x, ta.y, ta.z, ta.w}, tbw[4] = {tb.x, tb.y, tb.z, tb.w};
+    const u32 raw[4] = {ra.x, ra.y, ra.z, ra.w}, rbw[4] = {rb.x, rb.y, rb.z, rb.w};
 #pragma unroll
     for (u32 i = 0; i < 8; ++i) {
       if (s + i >= e1) break;
       const u32 lx = (i & 1u) ? l4[i >> 1].z : l4[i >> 1].x, ly = (i & 1u) ? l4[i >> 1].w : l4[i >> 1].y;   // links[s + i] as two dwords
-      const u32 tot = (i & 1u) ? tw[i >> 1] >> 16 : tw[i >> 1] & 0xffffu;
-      const u32 rnk = (i & 1u) ? rw[i >> 1] >> 16 : rw[i >> 1] & 0xffffu;
+      const u32 sh = 16u * (i & 1u);
+      const u32 tot1 = (taw[i >> 1] >> sh) & 0xffffu, tot2 = (tbw[i >> 1] >> sh) & 0xffffu;
+      const u32 r1 = (raw[i >> 1] >> sh) & 0xffffu, r2 = (rbw[i >> 1] >> sh) & 0xffffu;
       u32 l[LV_N];
 #pragma unroll
       for (u32 j = 0; j < LV_N; ++j) {
         const u32 wsel = (i >> 1) == 0 ? lv[j].x : (i >> 1) == 1 ? lv[j].y : (i >> 1) == 2 ? lv[j].z : lv[j].w;
-        l[j] = (i & 1u) ? wsel >> 16 : wsel & 0xffffu;
+        l[j] = (wsel >> sh) & 0xffffu;
       }
       uint4 a, b;
       a.x = lx;                                        // prev1 | prev2 << 16
-      a.y = (ly & 0xffffu) | (((tot + rnk) & 0xffffu) << 16);   // same | wc2 << 16
-      a.z = tot;
+      a.y = (ly & 0xffffu) | (r1 << 16);               // same | rank within its 3-byte-hash class (in its chunk)
+      a.z = r2;                                        // rank within its val2 class
       a.w = l[0] | (l[1] << 16);
       b.x = l[2] | (l[3] << 16);
       b.y = l[4] | (l[5] << 16);
@@ -432,6 +448,7 @@ __global__ __launch_bounds__(RK_THREADS) void k_rank2(RankParams P) {
       b.w = l[8] | (l[9] << 16);
       xr[2 * (s + i)] = a;
       xr[2 * (s + i) + 1] = b;
+      t12[s + i] = tot1 | (tot2 << 16);
     }
   }
 }
@@ -448,6 +465,7 @@ __global__ __launch_bounds__(RK_THREADS) void k_rank2(RankParams P) {
 struct Match5Params {
   MatchParams m;
   const uint4* xrec;     // k_rank2: two per region position
+  const u32* tot12;      // k_rank2: the sizes of a position's two classes in the chunk before its own
   const unsigned long long* energy;   // k_hits (null: every block)
   u64 thr;
 };
@@ -481,7 +499,7 @@ __device__ __forceinline__ u32 m5_lcp16(uint4 a, uint4 b) {
   return lo ? (u32)(__ffsll((unsigned long long)lo) - 1) >> 3 : hi ? 8u + ((u32)(__ffsll((unsigned long long)hi) - 1) >> 3) : 16u;
 }
 
-__global__ __launch_bounds__(M5_THREADS, 5) void k_match5(Match5Params Q) {
+__global__ __launch_bounds__(M5_THREADS, 4) void k_match5(Match5Params Q) {
   const MatchParams& P = Q.m;
   __shared__ u32 s_cp[8 * M5_THREADS];       // the first 8 change points of every lane's position (len | dist << 16), slot-major
 
@@ -528,6 +546,7 @@ __global__ __launch_bounds__(M5_THREADS, 5) void k_match5(Match5Params Q) {
     const u32 li0 = (u32)(p0 - bd.ws);
     const u32 rem0 = (u32)((bd.inend - p0 < 70000) ? bd.inend - p0 : 70000);
     u32* const rec0 = P.recs + (bd.pos_off + (p0 - bd.instart)) * 8;
+    const u32* const tot12 = Q.tot12 + bd.reg_off;
     u32 qnext = 0;                 // next position of the tile nobody has taken (wave-uniform)
 
     // ---- per-lane walk state
@@ -536,15 +555,21 @@ __global__ __launch_bounds__(M5_THREADS, 5) void k_match5(Match5Params Q) {
     u32 limit = 0, bestlen = 0, bestdist = 0, ncp = 0, same_pos = 0, cur = 0, size_rem = 0;
     u32 byte0 = 0, pbyte = 0, foff = 0, fmask = 0;
     uint4 P0 = make_uint4(0, 0, 0, 0);  // the position's first 16 bytes
+    u32 vpos = 0;                  // its 3-byte hash (hash.c:96-98)
+    u32 totpos = 0;                // the sizes of its two classes in the chunk before its own (k_rank2): tot1 | tot2 << 16
     u32 chain = 1, idx = 0;        // idx: candidates the reference has visited so far (lz77.c:527-530 stops at 8192)
     u32 curd = 0;                  // distance of the last visited candidate (0: none yet)
     u32 cprev = 0;                 // its prev1 | prev2 << 16 (raw steps follow them)
-    u32 gcur = 0;                  // its g value on the second chain
+    u32 gcur1 = 0, gcur2 = 0;      // its g value on the first / second chain
     int lev_k = -1;                // level the walk follows, -1 = the reference's own chain
     u32 eqd = 0, nlink = 0;        // level walk: distance of the last entry and its link
     bool need_link = false;        // the link of (lev_k, eqd) has to be fetched first
-    u32 xd = 0;                    // the entry being fetched
-    uint4 A = make_uint4(0, 0, 0, 0);   // its record: prev1 | prev2, same | wc2, tot2, (lv0 | lv1)
+    u32 scd = 0, scp2 = 0;         // the search for the switch point (first chain): a member of pos's second chain and its prev2
+    u32 sc_st = 0;                 // 0 searching, 1 scd is the nearest member of both of pos's classes below the last visited, 2 none
+    u32 fk = 0;                    // what is being fetched: 0 the reference's next hit, 1 a level entry, 2 a level link,
+                                   // 3 the next member of pos's second chain (switch-point search), 4 the switch point, to visit it
+    u32 xd = 0;                    // its distance
+    uint4 A = make_uint4(0, 0, 0, 0);   // its record: prev1 | prev2, same | rank1, rank2, (lv0 | lv1)
     uint2 V = make_uint2(0, 0);    // four of its level links, from level vb on
     u32 vb = 0;
     u32 F = 0;                     // its bytes foff .. foff + 3
@@ -553,31 +578,55 @@ __global__ __launch_bounds__(M5_THREADS, 5) void k_match5(Match5Params Q) {
     u32 plv0 = 0, plv1 = 0, plv2 = 0, plv3 = 0, plv4 = 0;   // the position's own level links (lv0|lv1, lv2|lv3, ...)
     u32 n_iter = 0;
 
-    // the entry the walk touches next: false = the walk is over (end of the chain, window, lz77.c:464, :521-523)
-    auto next_entry = [&]() -> bool {
-      if (lev_k < 0) {
-        const u32 step = chain == 1 ? (cprev & 0xffffu) : (cprev >> 16);
-        if (step == 0) return false;
-        xd = curd + step;
+    auto fetch = [&](u32 d, u32 kind) {
+      xd = d;
+      fk = kind;
+      if (kind == 1u || kind == 2u) {
+        vb = lev_k > 6 ? 6u : (u32)lev_k;
+      } else {
         const u32 n = (bestlen < 3 ? 3u : bestlen) + 1u;
         const int g = lv_level_for(n > 32u ? 32u : n);     // the level an improvement here most likely asks for
         vb = g > 6 ? 6u : (u32)g;
-      } else {
-        if (need_link) {
-          xd = eqd;
-        } else {
-          if (nlink == 0) return false;
-          xd = eqd + nlink;
-        }
-        vb = lev_k > 6 ? 6u : (u32)lev_k;
       }
-      if (xd >= ZMX_WINDOW) return false;
-      const u32 e = li - xd;
+      const u32 e = li - d;
       const u8* r = xr + (u64)e * 32u;
       A = *reinterpret_cast<const uint4*>(r);
       __builtin_memcpy(&V, r + 2u * (XR_LV0 + vb), 8);
       F = m5_load4(inr + e + foff);
       C0 = m5_load16(inr + e);
+    };
+    // the entry the walk touches next: false = the walk is over (end of the chain, window, lz77.c:464, :521-523)
+    auto next_entry = [&]() -> bool {
+      if (chain == 1 && bestlen >= 3) {
+        // The FIRST chain with level links.  The reference walks every position of pos's 3-byte hash until one of pos's
+        // val2 class comes by at a time when bestlength >= same (lz77.c:509-519).  Of those only two kinds matter:
+        // candidates that beat bestlength — entries of the level chain, while bestlength <= same; beyond that a longer
+        // match has exactly pos's run length, i.e. is of pos's val2 class, and the nearest member of that class ends
+        // this chain anyway — and that nearest member of both classes, the switch point: the next position on pos's
+        // SECOND chain (below the last visited candidate) whose 3-byte hash is pos's.  Everything in between is
+        // counted from the ranks.
+        const bool can_switch = bestlen >= same_pos;
+        if (can_switch && sc_st == 0) {
+          if (scp2 == 0 || scd + scp2 >= ZMX_WINDOW) sc_st = 2;
+          else { fetch(scd + scp2, 3u); return true; }
+        }
+        const u32 swd = can_switch && sc_st == 1 ? scd : 0xffffffffu;
+        if (bestlen <= same_pos) {
+          if (need_link) { fetch(eqd, 2u); return true; }
+          if (nlink != 0 && eqd + nlink < ZMX_WINDOW && eqd + nlink <= swd) { fetch(eqd + nlink, 1u); return true; }
+        }
+        if (swd != 0xffffffffu) { fetch(swd, 4u); return true; }
+        return false;
+      }
+      if (lev_k < 0 || chain == 1) {
+        const u32 step = chain == 1 ? (cprev & 0xffffu) : (cprev >> 16);
+        if (step == 0 || curd + step >= ZMX_WINDOW) return false;
+        fetch(curd + step, 0u);
+        return true;
+      }
+      if (need_link) { fetch(eqd, 2u); return true; }
+      if (nlink == 0 || eqd + nlink >= ZMX_WINDOW) return false;
+      fetch(eqd + nlink, 1u);
       return true;
     };
     auto pos_link = [&](u32 k) -> u32 {
@@ -587,9 +636,9 @@ __global__ __launch_bounds__(M5_THREADS, 5) void k_match5(Match5Params Q) {
     // level for the walk after bestlength or the chain changed; `at_x`: bestlength was just set by the entry (xd, V)
     auto choose_level = [&](bool at_x) {
       int k = -1;
-      if (chain == 2 && bestlen >= 3) {
+      if (bestlen >= 3) {
         k = lv_level_for(bestlen + 1 > 32 ? 32u : bestlen + 1);
-        if (same_pos + 2 > kLevelK[k]) k = -1;       // the second chain is the more selective list
+        if (chain == 2 && same_pos + 2 > kLevelK[k]) k = -1;       // the second chain is the more selective list
       }
       if (k != lev_k) {
         lev_k = k;
@@ -610,9 +659,12 @@ __global__ __launch_bounds__(M5_THREADS, 5) void k_match5(Match5Params Q) {
             need_link = true;
           }
         }
-      } else if (k >= 0 && at_x) {
+      } else if (k >= 0 && at_x && (u32)k >= vb && (u32)k < vb + 4u) {
         eqd = xd;
-        nlink = m5_pick(V, (u32)k - vb);     // (k = lev_k lies in V's range: vb = min(lev_k, 6))
+        nlink = m5_pick(V, (u32)k - vb);
+      } else if (k >= 0 && at_x) {
+        eqd = xd;                              // (the entry was not fetched as a level entry: its link of level k is not in V)
+        need_link = true;
       }
     };
 
@@ -688,6 +740,10 @@ __global__ __launch_bounds__(M5_THREADS, 5) void k_match5(Match5Params Q) {
               } else {
                 plv0 = Ap.w; plv1 = Bp.x; plv2 = Bp.y; plv3 = Bp.z; plv4 = Bp.w;
                 pbyte = P0.x; foff = 0; fmask = 0xffffu;   // bestlength 1: bytes 0 and 1
+                vpos = (((P0.x & 255u) << 10) ^ (((P0.x >> 8) & 255u) << 5) ^ ((P0.x >> 16) & 255u)) & 32767u;   // (size_rem >= 3: real bytes)
+                totpos = tot12[li];
+                gcur1 = (Ap.y >> 16) + (totpos & 0xffffu);
+                scd = 0; scp2 = Ap.x >> 16; sc_st = 0;
                 next_entry();                        // (prev1 < 32768: always an entry)
                 st = M5_WALK;
               }
@@ -708,36 +764,49 @@ __global__ __launch_bounds__(M5_THREADS, 5) void k_match5(Match5Params Q) {
       bool moved = false;          // this iteration ended with a decision: fetch the next entry
       bool visited = false;        // the entry is a candidate the reference visits (and it is not longer than the best)
       bool ended = false;          // the common prefix with the entry is known: cur
-      // A wave-loop that does not end would hang the device: far beyond what a tile can take (32 positions a lane,
-      // at most 8192 hits each), the tile is given up, the state of a running lane goes to counters[16..23] and
+      // A wave-loop that does not end would hang the device: far beyond what a tile can take (8 positions a lane,
+      // at most 8192 hits each), the tile is given up, the state of a running lane goes to counters[32..39] and
       // the host fails the build.
       if (++n_iter > (1u << 20)) {
         atomicOr(&P.counters[1], 2u);
         {
           const u64 mr = __ballot(st == M5_WALK || st == M5_CMP);
           const u32 l0 = mr ? (u32)__ffsll((unsigned long long)mr) - 1u : 0u;
-          if (lane == l0 && atomicCAS(&P.counters[32], 0u, 0x80000000u | st | (chain << 4) | ((u32)(lev_k + 1) << 8) | ((need_link ? 1u : 0u) << 12) | (vb << 16)) == 0u) {
+          if (lane == l0 && atomicCAS(&P.counters[32], 0u, 0x80000000u | st | (chain << 4) | ((u32)(lev_k + 1) << 8) | ((need_link ? 1u : 0u) << 12) | (fk << 13) | (vb << 16) | (sc_st << 20)) == 0u) {
             P.counters[33] = xd; P.counters[34] = curd; P.counters[35] = bestlen | (limit << 16); P.counters[36] = nlink | (eqd << 16);
-            P.counters[37] = li; P.counters[38] = idx | (same_pos << 16); P.counters[39] = cur | (bestdist << 16);
+            P.counters[37] = li; P.counters[38] = idx | (same_pos << 16); P.counters[39] = scd | (bestdist << 16);
           }
         }
         break;
       }
+      // is the entry the switch point of the first chain (visited whatever its bytes)?  and is it a level entry, which
+      // only counts when it beats bestlength?
+      const bool same_chunk = (li - xd) >> 15 == li >> 15;
       if (walk) {
         bool cand = true;
-        if (lev_k >= 0) {
+        if (fk == 2u) {                                  // the link of the level walk's entry point
+          need_link = false;
           nlink = m5_pick(V, (u32)lev_k - vb);
-          if (need_link) {                           // the link of the entry point itself
-            need_link = false;
-            cand = false; moved = true;
+          cand = false; moved = true;
+        } else if (fk == 1u) {
+          eqd = xd;
+          nlink = m5_pick(V, (u32)lev_k - vb);
+          if (xd <= curd) { cand = false; moved = true; }     // at or above the last visited candidate (entered at pos)
+        } else if (fk == 3u) {                           // the next member of pos's second chain: of pos's 3-byte hash too?
+          scd = xd;
+          scp2 = A.x >> 16;
+          const u32 v = (((C0.x & 255u) << 10) ^ (((C0.x >> 8) & 255u) << 5) ^ ((C0.x >> 16) & 255u)) & 32767u;
+          if (xd > curd && v == vpos) {
+            sc_st = 1;
+            if (bestlen <= same_pos) { cand = false; moved = true; }   // level entries may come before it: not its turn yet
           } else {
-            eqd = xd;
-            if (xd <= curd) { cand = false; moved = true; }   // at or above the last visited candidate (entered at pos)
+            cand = false; moved = true;
           }
         }
         if (cand) {
+          const bool is_sw = chain == 1 && bestlen >= 3 && sc_st == 1 && xd == scd;
           if (((F ^ pbyte) & fmask) != 0) {          // cannot be longer than bestlength (lz77.c:478-479, 494)
-            if (lev_k < 0) visited = true; else moved = true;
+            if (fk == 0u || is_sw) visited = true; else moved = true;
           } else {
             const u32 l16 = m5_lcp16(P0, C0);
             if (l16 < 16u) {
@@ -774,16 +843,22 @@ __global__ __launch_bounds__(M5_THREADS, 5) void k_match5(Match5Params Q) {
           C0 = m5_load16(inr + li - xd + cur);
         }
       }
+      // the candidate's g values (k_rank2): positions of pos's chunk count from the chunk before's totals
+      const u32 gx1 = ((A.y >> 16) + (same_chunk ? totpos & 0xffffu : 0u)) & 0xffffu;
+      const u32 gx2 = ((A.z & 0xffffu) + (same_chunk ? totpos >> 16 : 0u)) & 0xffffu;
       if (ended) {
+        const bool is_sw = chain == 1 && bestlen >= 3 && sc_st == 1 && xd == scd;
         if (cur > bestlen) {
           // a longer match: is it a candidate the reference visits, and which one?
           bool ok = true;
           u32 hops = 1;
-          // g on the second chain (k_rank2): positions of pos's chunk count from the chunk before's total
-          const u32 gx = ((li - xd) >> 15 == li >> 15 ? A.y >> 16 : (A.y >> 16) - A.z) & 0xffffu;
-          if (chain == 2 && lev_k >= 0) {
-            ok = (((A.y & 0xffffu) - 3u) & 255u) == ((same_pos - 3u) & 255u);   // of the position's val2 class
-            hops = (gcur - gx) & 0xffffu;
+          if (fk != 0u) {
+            if (chain == 2) {
+              ok = (((A.y & 0xffffu) - 3u) & 255u) == ((same_pos - 3u) & 255u);   // of the position's val2 class
+              hops = (gcur2 - gx2) & 0xffffu;
+            } else {
+              hops = (gcur1 - gx1) & 0xffffu;      // (it shares >= 4 bytes: of pos's 3-byte hash)
+            }
           }
           if (!ok) {
             moved = true;                        // not on the second chain: never visited
@@ -803,7 +878,8 @@ __global__ __launch_bounds__(M5_THREADS, 5) void k_match5(Match5Params Q) {
             pbyte = m5_load4(inr + li + foff);   // (arrives with the next entry)
             curd = xd;
             cprev = A.x;
-            gcur = gx;
+            gcur1 = gx1;
+            gcur2 = gx2;
             if (cur >= limit) {
               fin = true;                        // lz77.c:500-502
             } else {
@@ -813,21 +889,24 @@ __global__ __launch_bounds__(M5_THREADS, 5) void k_match5(Match5Params Q) {
               moved = true;
             }
           }
-        } else if (lev_k < 0) {
+        } else if (fk == 0u || is_sw) {
           visited = true;                        // compared, not longer
         } else {
           moved = true;
         }
       }
       if (visited) {
-        // a candidate of the reference's own chain that does not beat bestlength: count it, test the switch rule
-        if (idx + 1 > ZMX_MAX_CHAIN_HITS) {
+        // a candidate the reference visits that does not beat bestlength — its own chain's next hit, or the switch
+        // point: count it (and what lies between), test the switch rule
+        const u32 hops = fk == 0u ? 1u : (gcur1 - gx1) & 0xffffu;
+        if (idx + hops > ZMX_MAX_CHAIN_HITS) {
           fin = true;
         } else {
-          ++idx;
+          idx += hops;
           curd = xd;
           cprev = A.x;
-          gcur = ((li - xd) >> 15 == li >> 15 ? A.y >> 16 : (A.y >> 16) - A.z) & 0xffffu;
+          gcur1 = gx1;
+          gcur2 = gx2;
           if (chain == 1 && bestlen >= same_pos && (((A.y & 0xffffu) - 3u) & 255u) == ((same_pos - 3u) & 255u)) {
             chain = 2;
             choose_level(false);

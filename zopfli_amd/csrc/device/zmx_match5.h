@@ -117,11 +117,18 @@ __device__ __forceinline__ void lv_round(u32 (&w)[LV_U][NW], const u8* base, u16
 #pragma unroll
     for (u32 u = 0; u < LV_U; ++u) lv_load<NW>(w[u], base + s + 64u * (LV_U + u) + lane);   // the next round's bytes
   }
+  // what the table holds BEFORE each step (the LDS queue is in order: the read of step u comes after the atomic of
+  // step u - 1), then the atomic, whose returned value only says whether two lanes of the step share a key
+  u32 old[LV_U];
 #pragma unroll
   for (u32 u = 0; u < LV_U; ++u) {
     const u32 q = s + 64u * u + lane;
     ret[u] = 0;
-    if (!GUARD || q < n) ret[u] = atomicMax(&head[key[u]], q + 1u);     // 0 = no position yet
+    old[u] = 0;
+    if (!GUARD || q < n) {
+      old[u] = head[key[u]];                          // (program order: after step u - 1's atomic, before this one's)
+      ret[u] = atomicMax(&head[key[u]], q + 1u);     // 0 = no position yet
+    }
   }
 #pragma unroll
   for (u32 u = 0; u < LV_U; ++u) {
@@ -129,17 +136,14 @@ __device__ __forceinline__ void lv_round(u32 (&w)[LV_U][NW], const u8* base, u16
     const bool act = !GUARD || q < n;
     const u32 r = q + 1u;
     const u32 step0 = s + 64u * u + 1u;
-    u32 d = ret[u] ? r - ret[u] : 0u;
+    u32 d = old[u] ? r - old[u] : 0u;
     u64 F = __ballot(act && ret[u] >= step0);                  // lanes that saw a position of this very step
     while (F) {
       const u32 l0 = (u32)__ffsll((unsigned long long)F) - 1u;
       const u32 k0 = rdlane_u32(key[u], l0);
       const u64 G = __ballot(act && key[u] == k0);
-      const u32 old = wave_min_u32((G >> lane) & 1 ? ret[u] : 0xffffffffu);   // what the table held before the step
-      if ((G >> lane) & 1) {
-        const u64 lower = G & lt_mask;
-        d = lower ? lane - (63u - (u32)__clzll((long long)lower)) : (old ? r - old : 0u);
-      }
+      const u64 lower = G & lt_mask;
+      if (((G >> lane) & 1) && lower) d = lane - (63u - (u32)__clzll((long long)lower));   // the nearest lower lane of the key
       F &= ~G;
     }
     if (d > 32767u) d = 0;

@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 
 MB = 1000000
 WINDOW = 32768
-PMC_PROFILE = "r03_bench100MB_pmc.json"
+PMC_PROFILE = "r04_bench100MB_pmc.json"
 SHADER_CLOCK_HZ = 2.4e9   # MI355X peak engine clock; s_memtime counts at this rate (measured)
 
 

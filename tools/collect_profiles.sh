@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="${BENCH_ARGS:---steps 1 --warmup 0 --no-cpu-baseline}"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- python $REPO/bench.py $ARGS > $OUT/stats.log 2>&1
-tail -1 $OUT/stats.log > $OUT/bench_line.json
+grep '^{"metric"' $OUT/stats.log | tail -1 > $OUT/bench_line.json
 i=0
 for set in "SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM" "FETCH_SIZE" "WRITE_SIZE" ${EXTRA_SETS:-}; do
   i=$((i+1))

@@ -19,6 +19,7 @@
 #include "deflate.h"
 #include "lz77_optimal.h"
 #include "symbols.h"
+#include "thread_pool.h"
 #include "zopfli_amd.h"
 
 // implemented by the device layer: kernel-only seconds / launches of the squeeze kernel
@@ -76,7 +77,7 @@ class ContextPool {
   // one free context on each of up to `want` devices (at least one), in device order; with `per_device` > 1 up to
   // that many free contexts of every device it uses (a large request on one device is dealt over two of its
   // contexts: one half's host phases run beside the other half's kernels)
-  std::vector<zmx_ctx*> Acquire(size_t want, size_t per_device = 1) {
+  std::vector<zmx_ctx*> Acquire(size_t want, size_t per_device = 1, std::vector<int>* device_of = nullptr) {
     std::unique_lock<std::mutex> lock(mu_);
     Init();
     for (;;) {
@@ -146,6 +147,10 @@ class ContextPool {
       if (!slots.empty()) {
         std::vector<zmx_ctx*> got;
         for (Slot* s : slots) got.push_back(s->ctx);
+        if (device_of) {
+          device_of->clear();
+          for (Slot* s : slots) device_of->push_back(s->dev->index);
+        }
         return got;
       }
       cv_.wait(lock);   // every context of every device is busy
@@ -234,8 +239,9 @@ ContextPool& Pool() {
 void ContextPool::OomHook(int device) { Pool().TrimIdle(device); }
 
 struct Lease {
+  std::vector<int> device_of;      // HIP device index of ctxs[i]
   std::vector<zmx_ctx*> ctxs;
-  explicit Lease(size_t want, size_t per_device = 1) : ctxs(Pool().Acquire(want, per_device)) {}
+  explicit Lease(size_t want, size_t per_device = 1) : ctxs(Pool().Acquire(want, per_device, &device_of)) {}
   ~Lease() { Pool().Release(ctxs); }
 };
 
@@ -346,12 +352,75 @@ int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char
     shards[d].first = parts.size() * d / ndev;
     shards[d].last = parts.size() * (d + 1) / ndev;
   }
+  // (ZOPFLI_AMD_SHARD_WEIGHTS="28,36,36": the shares of the shards, for measuring)
+  if (const char* e = std::getenv("ZOPFLI_AMD_SHARD_WEIGHTS")) {
+    std::vector<double> w;
+    for (const char* q = e; *q;) {
+      char* end = nullptr;
+      const double v = std::strtod(q, &end);
+      if (end == q) break;
+      w.push_back(v > 0 ? v : 0);
+      q = *end == ',' ? end + 1 : end;
+    }
+    double total = 0;
+    for (size_t d = 0; d < ndev && d < w.size(); ++d) total += w[d];
+    if (w.size() >= ndev && total > 0) {
+      double acc = 0;
+      size_t at = 0;
+      for (size_t d = 0; d < ndev; ++d) {
+        acc += w[d];
+        size_t to = d + 1 == ndev ? parts.size() : static_cast<size_t>(parts.size() * acc / total + 0.5);
+        to = std::max(to, at + 1);                       // no empty shard
+        to = std::min(to, parts.size() - (ndev - 1 - d));
+        shards[d].first = at;
+        shards[d].last = to;
+        at = to;
+      }
+    }
+  }
+  // The contexts of ONE device take their bytes over the same link: asked for at once, three uploads end together and
+  // the device has nothing to do until then (12 ms of a 122 ms call on 100 MB; the kernel timeline of
+  // tools/r04_timeline.sh).  One after the other, in stream order, the first context computes while the second's bytes
+  // travel — and the contexts stay out of step from there on: their host phases (block split, cost models) fall
+  // beside the others' kernels instead of beside each other.
+  struct UploadOrder {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<char> done;
+    std::vector<long> after;     // the shard whose upload this one waits for, -1 = none
+  } order;
+  order.done.assign(ndev, 0);
+  order.after.assign(ndev, -1);
+  // (ZOPFLI_AMD_UPLOAD_ORDER=0: all at once, as before — for measuring)
+  static const bool ordered_uploads = [] { const char* e = std::getenv("ZOPFLI_AMD_UPLOAD_ORDER"); return !e || std::atoi(e) != 0; }();
+  for (size_t d = 1; d < ndev && ordered_uploads; ++d) {
+    for (size_t e = d; e-- > 0;) {
+      if (lease.device_of[e] == lease.device_of[d]) { order.after[d] = static_cast<long>(e); break; }
+    }
+  }
+  struct UploadTurn {     // marks a shard's upload as over, however its attempt ends
+    UploadOrder& o; size_t d; bool released = false;
+    void Wait() {
+      if (o.after[d] < 0) return;
+      std::unique_lock<std::mutex> lock(o.mu);
+      o.cv.wait(lock, [&] { return o.done[static_cast<size_t>(o.after[d])] != 0; });
+    }
+    void Release() {
+      if (released) return;
+      released = true;
+      { std::lock_guard<std::mutex> lock(o.mu); o.done[d] = 1; }
+      o.cv.notify_all();
+    }
+    ~UploadTurn() { Release(); }
+  };
   // (ZOPFLI_AMD_TEST_FAIL_SHARD=k: the k-th shard's first attempt fails before it does anything — the test of the
   //  re-queue below)
   const char* fail_env = std::getenv("ZOPFLI_AMD_TEST_FAIL_SHARD");
   const long fail_shard = fail_env ? std::atol(fail_env) : -1;
   auto work = [&](size_t d, zmx_ctx* ctx, bool retry) {
     Shard& sh = shards[d];
+    UploadTurn turn{order, d};
+    zamd::g_wide_lane = static_cast<int>(d % static_cast<size_t>(zamd::kWideLanes));   // (thread_pool.h: a wide pool per shard thread)
     sh.rc = 0;
     sh.err.clear();
     sh.chunks.clear();
@@ -364,7 +433,10 @@ int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char
     }
     const size_t start = parts[sh.first].instart, end = parts[sh.last - 1].inend;
     sh.base = start > zamd::kWindow ? start - zamd::kWindow : 0;
-    if (zmx_set_input(ctx, in + sh.base, end - sh.base) != 0) {
+    if (!retry) turn.Wait();
+    const int up = zmx_set_input(ctx, in + sh.base, end - sh.base);
+    turn.Release();
+    if (up != 0) {
       sh.rc = -1;
       sh.err = zmx_last_error();
       return;

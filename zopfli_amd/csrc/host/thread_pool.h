@@ -88,6 +88,10 @@ inline unsigned HostThreads() {
 // and the wake-up cost is paid three times per call, not twice per squeeze run.
 inline unsigned WideThreads() {
   static const unsigned n = [] {
+    if (const char* e = std::getenv("ZOPFLI_AMD_WIDE_THREADS")) {    // (for measuring)
+      const int v = std::atoi(e);
+      if (v > 0) return static_cast<unsigned>(v);
+    }
     if (std::getenv("ZOPFLI_AMD_THREADS")) return HostThreads();   // an explicit budget covers both pools
     const unsigned hc = UsableCpus();
     const unsigned cap = 128;
@@ -97,14 +101,22 @@ inline unsigned WideThreads() {
   return n;
 }
 
+// Which of the wide pools the calling thread's ParallelForWide goes to.  A request that is dealt over several contexts of a
+// device runs one host thread per context (api.cc), and a pool takes one job at a time: with one wide pool the block-split
+// searches of three contexts — 33 master blocks each, ten milliseconds a search, half the pool idle — stood in line,
+// 30 ms with nothing on the device.  Each of those threads has its own (the threads sleep when there is no job).
+constexpr int kWideLanes = 4;
+inline thread_local int g_wide_lane = 0;
+
 class WorkerPool {
  public:
   // The pools are created on first use and leaked on purpose (no join at exit).  A forked child has
   // none of the worker threads: it forgets the parent's pools and makes its own on first use.
   static WorkerPool& Get() { return Instance(0, HostThreads()); }
   static WorkerPool& Wide() {
-    if (WideThreads() == HostThreads()) return Get();
-    return Instance(1, WideThreads());
+    const int lane = g_wide_lane < 0 ? 0 : g_wide_lane % kWideLanes;
+    if (WideThreads() == HostThreads() && lane == 0) return Get();
+    return Instance(1 + lane, WideThreads());
   }
 
   // Runs body(i) for i in [0, n) on the workers and the calling thread; returns
@@ -132,7 +144,7 @@ class WorkerPool {
 
  private:
   static std::atomic<WorkerPool*>* Slots() {
-    static std::atomic<WorkerPool*> slots[2];
+    static std::atomic<WorkerPool*> slots[1 + kWideLanes];
     return slots;
   }
   static std::mutex& CreateMutex() {
@@ -140,8 +152,7 @@ class WorkerPool {
     return *m;
   }
   static void ForgetInChild() {
-    Slots()[0].store(nullptr);
-    Slots()[1].store(nullptr);
+    for (int i = 0; i < 1 + kWideLanes; ++i) Slots()[i].store(nullptr);
     new (&CreateMutex()) std::mutex();         // the parent may have forked while holding it
   }
   static WorkerPool& Instance(int which, unsigned threads) {

@@ -238,6 +238,15 @@ ContextPool& Pool() {
 }
 void ContextPool::OomHook(int device) { Pool().TrimIdle(device); }
 
+// ZOPFLI_AMD_TRACE_CALL=1: where a Zopfli* call's wall time goes, per shard and for the call (stderr)
+bool TraceCall() {
+  static const bool on = [] { const char* e = std::getenv("ZOPFLI_AMD_TRACE_CALL"); return e && std::atoi(e) != 0; }();
+  return on;
+}
+double WallMs() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 struct Lease {
   std::vector<int> device_of;      // HIP device index of ctxs[i]
   std::vector<zmx_ctx*> ctxs;
@@ -334,7 +343,9 @@ int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char
     static const bool split_runs = [] { const char* e = std::getenv("ZOPFLI_AMD_SPLIT_RUNS"); return e && std::atoi(e) != 0; }();
     if (split_runs) runs = false;      // (ZOPFLI_AMD_SPLIT_RUNS=1: deal such data over two contexts all the same — for measuring)
   }
+  const double tr_begin = WallMs();
   const Lease lease(parts.size(), split_from && parts.size() >= split_from && !runs ? split_ways : 1);
+  const double tr_lease = WallMs();
   const std::vector<zmx_ctx*>& ctxs = lease.ctxs;
   const size_t ndev = std::min(ctxs.size(), parts.size());
   struct Shard {
@@ -433,9 +444,12 @@ int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char
     }
     const size_t start = parts[sh.first].instart, end = parts[sh.last - 1].inend;
     sh.base = start > zamd::kWindow ? start - zamd::kWindow : 0;
+    const double tr0 = WallMs();
     if (!retry) turn.Wait();
+    const double tr1 = WallMs();
     const int up = zmx_set_input(ctx, in + sh.base, end - sh.base);
     turn.Release();
+    const double tr2 = WallMs();
     if (up != 0) {
       sh.rc = -1;
       sh.err = zmx_last_error();
@@ -451,8 +465,13 @@ int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char
     }
     std::vector<zamd::Part> mine(parts.begin() + static_cast<long>(sh.first), parts.begin() + static_cast<long>(sh.last));
     for (auto& p : mine) { p.instart -= sh.base; p.inend -= sh.base; }
+    const double tr3 = WallMs();
     sh.rc = RunParts(ctx, options, btype, mine, &sh.chunks);
     if (sh.rc) sh.err = zmx_last_error();
+    if (TraceCall()) {
+      std::fprintf(stderr, "  shard %zu (%zu parts): start +%.2f ms, wait for turn %.2f, upload %.2f, checksum %.2f, parts %.2f, end +%.2f\n",
+                   d, sh.last - sh.first, tr0 - tr_begin, tr1 - tr0, tr2 - tr1, tr3 - tr2, WallMs() - tr3, WallMs() - tr_begin);
+    }
     for (auto& c : sh.chunks) {
       if (c.kind == zamd::Chunk::kStored) { c.start += sh.base; c.end += sh.base; }
     }
@@ -485,12 +504,17 @@ int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char
     work(d, other, true);
     shards[d].redone = true;
   }
+  const double tr_joined = WallMs();
   for (auto& sh : shards) {
     if (sh.rc) {
       std::fprintf(stderr, "zopfli_amd: device error: %s\n", sh.err.c_str());
       return sh.rc;
     }
     for (auto& c : sh.chunks) chunks->push_back(std::move(c));
+  }
+  if (TraceCall()) {
+    std::fprintf(stderr, "RunPartsSharded: lease %.2f ms, shards done +%.2f, chunks moved +%.2f\n", tr_lease - tr_begin,
+                 tr_joined - tr_begin, WallMs() - tr_begin);
   }
   if (sum) {
     sum->value = sum->kind == ZMX_ADLER32 ? 1u : 0u;   // of no bytes
@@ -550,11 +574,21 @@ void DeflateWhole(const ZopfliOptions* options, int btype, int final, const unsi
                   unsigned char* bp, unsigned char** out, size_t* outsize, ChecksumRequest* sum) {
   const size_t offset = *outsize;
   {
+    const double tr0 = WallMs();
     ResetTiming();
     const std::vector<zamd::Part> parts = MasterBlocks(insize, final != 0);
     std::vector<zamd::Chunk> chunks;
+    const double tr1 = WallMs();
     if (RunPartsSharded(*options, btype, in, parts, &chunks, sum) != 0) Die("device error");
+    const double tr2 = WallMs();
     EmitChunks(chunks, in, bp, out, outsize, options->verbose != 0);
+    const double tr3 = WallMs();
+    chunks.clear();
+    chunks.shrink_to_fit();
+    if (TraceCall()) {
+      std::fprintf(stderr, "DeflateWhole: set-up %.2f ms, parts %.2f, merge %.2f, chunks freed %.2f\n", tr1 - tr0, tr2 - tr1,
+                   tr3 - tr2, WallMs() - tr3);
+    }
   }
   if (options->verbose) {
     std::fprintf(stderr, "Original Size: %lu, Deflate: %lu, Compression: %f%% Removed\n",

@@ -11,22 +11,29 @@
 // k_match2 emulates the visit sequence hit by hit.  Here only the candidates that can matter are touched:
 //   * A candidate that beats bestlength shares bestlength + 1 bytes with the position.  Beside the reference's two
 //     chains (k_chain) every position has LEVEL links (k_levels): the nearest earlier position whose first k bytes
-//     hash alike, k = 4, 5, 6, 7, 8, 10, 12, 16.  The walk follows the level k <= bestlength + 1: a superset of the
-//     candidates that can beat bestlength (hash collisions only add entries; every entry is compared with the
+//     hash alike, k = 4, 5, 6, 7, 8, 10, 12, 16, 24, 32.  The walk follows the level k <= bestlength + 1: a superset
+//     of the candidates that can beat bestlength (hash collisions only add entries; every entry is compared with the
 //     position's bytes before it counts), an order of magnitude shorter than the 3-byte chain.
-//   * The first chain (before the hash switch) is walked hit by hit as the reference does: on text it is one
-//     candidate long (same <= 1: the first candidate of the val2 class switches), on runs it is the reference's walk.
+//   * On the FIRST chain (before the hash switch, lz77.c:509-519) two kinds of candidates matter: level entries
+//     that beat bestlength, while bestlength <= same, and the SWITCH POINT — the nearest position below the last
+//     visited candidate that is of both of pos's classes (its 3-byte hash and its val2): found by walking pos's
+//     second chain for a member with pos's 3-byte hash.  Once bestlength >= same + 1 a longer match has exactly pos's
+//     run length, so it is of pos's val2 class and the switch point comes first anyway: the walk goes there
+//     directly.
 //   * On the second chain a visited candidate must be of the position's val2 class (lz77.c:521: the walk follows
 //     hashval2's chain): a level entry that shares >= 3 bytes has the position's val, so the class test is
 //     (same - 3) & 255 (hash.c:129).  Where the run length makes the second chain itself the more selective list
 //     (same + 2 > k: inside runs a level chain links every position of every run of the byte), it is walked instead.
-//   * The hits the walk jumped over are COUNTED, not visited: k_rank2 gives every position its rank within its val2
-//     class (per 32768-position chunk of the region, plus the class's size in the chunk before), so the number of
-//     chain entries between two members of the class is a subtraction, the 8192-candidate cap fires at the same
-//     candidate as in the reference, and a candidate beyond it is never looked at.
+//   * The hits the walk jumped over are COUNTED, not visited: k_rank2 gives every position its rank within each of
+//     its two classes (per 32768-position chunk of the region, plus the class's size in the chunk before), so the
+//     number of chain entries between two members of a class is a subtraction, the 8192-candidate cap fires at the
+//     same candidate as in the reference, and a candidate beyond it is never looked at.
+// Which blocks: k_hits estimates the hits per position the reference's walk would make (sum over 32768-position
+// chunks of the squared val2 class sizes / positions); a block above ZOPFLI_AMD_MATCH_HITS (300) takes this kernel,
+// the others k_match2, side by side on two streams (zmx_hip.hip: BuildTables).
 // tools/match_skip_model.c is the CPU model of this walk (checked against the oracle's hit-by-hit walk on every
 // position of every class, with the cap and the switch rule binding on classes B, Z and P); the kernels are checked
-// against k_match2 and the oracle in tests/test_gpu_parity.py.
+// against k_match2 and the oracle in tests/test_gpu_parity.py and tests/test_gpu_match_adversarial.py.
 #pragma once
 
 #define LV_N 10u
@@ -458,11 +465,10 @@ __global__ __launch_bounds__(RK_THREADS) void k_rank2(RankParams P) {
 }
 
 // ----------------------------------------------------------------------------
-// k_match5.  A wave owns a 2048-position tile at a time and its lanes take the tile's positions one after the other;
-// nothing is staged in LDS: a walk touches ~10 entries, the 32 KiB window of bytes k_match2 stages per tile would
-// be read ~40 times per position staged, and with it goes the tile's barrier — k_match2's lanes wait for the
-// tile's longest walk (4 positions a lane), here a lane waits only at the end of its wave's tile (32 positions a
-// lane).  Per entry the lane has in flight together: the entry's record (16 + 8 bytes), the 4 bytes the filter
+// k_match5.  A wave owns a quarter of a 2048-position tile at a time (512 positions, 8 a lane) and its lanes take the
+// quarter's positions one after the other; nothing is staged in LDS: a walk touches ~10 entries, the 32 KiB window of
+// bytes k_match2 stages per tile would be read ~40 times per position staged, and with it goes the tile's barrier —
+// k_match2's lanes wait for the tile's longest walk, here a lane waits only at the end of its wave's quarter.  Per entry the lane has in flight together: the entry's record (16 + 8 bytes), the 4 bytes the filter
 // tests and the entry's first 16 bytes; the position's own first 16 bytes stay in registers, so a common prefix
 // of up to 15 bytes — most of them — is decided in the iteration the entry arrives in.
 // ----------------------------------------------------------------------------

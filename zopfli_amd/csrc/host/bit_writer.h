@@ -15,14 +15,18 @@ class BitWriter {
  public:
   void Reserve(size_t bytes) { buf_.reserve(bytes); }
 
-  // `nbits` <= 32 low bits of `value`, least significant bit first.
+  // `nbits` <= 32 low bits of `value`, least significant bit first.  (Fewer than 32 bits wait in the accumulator:
+  // 32 more always fit; four bytes leave at a time.)
   void AddBits(uint32_t value, unsigned nbits) {
     acc_ |= static_cast<uint64_t>(value & ((nbits >= 32) ? 0xffffffffu : ((1u << nbits) - 1))) << fill_;
     fill_ += nbits;
-    while (fill_ >= 8) {
-      buf_.push_back(static_cast<uint8_t>(acc_));
-      acc_ >>= 8;
-      fill_ -= 8;
+    if (fill_ >= 32) {
+      const uint32_t low = static_cast<uint32_t>(acc_);
+      const size_t at = buf_.size();
+      buf_.resize(at + 4);
+      std::memcpy(buf_.data() + at, &low, 4);     // (little endian: the stream's byte order)
+      acc_ >>= 32;
+      fill_ -= 32;
     }
   }
 
@@ -34,7 +38,7 @@ class BitWriter {
   // Returns the bytes (last one zero-padded) and leaves the writer empty.
   std::vector<uint8_t> Finish(size_t* nbits) {
     *nbits = BitCount();
-    if (fill_) buf_.push_back(static_cast<uint8_t>(acc_));
+    for (unsigned done = 0; done < fill_; done += 8) buf_.push_back(static_cast<uint8_t>(acc_ >> done));
     acc_ = 0;
     fill_ = 0;
     return std::move(buf_);

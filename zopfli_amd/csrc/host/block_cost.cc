@@ -361,19 +361,30 @@ void EncodeBlock(const Lz77Store& lz77, size_t lstart, size_t lend, int btype, b
   LengthsToSymbols(ll_lengths, kNumLL, 15, ll_codes);
   LengthsToSymbols(d_lengths, kNumD, 15, d_codes);
 
+  // The codes bit-reversed once (RFC 1951 3.1.1: Huffman codes go most significant bit first), a symbol's code and
+  // its extra bits in one piece (15 + 5 and 15 + 13 bits): this loop is what a block costs whose symbols the device
+  // cannot write (deflate.cc), 16 ns a symbol with a reversal and up to four pieces per symbol.
+  auto rev = [](unsigned v, unsigned len) {
+    unsigned r = 0;
+    for (unsigned i = 0; i < len; ++i) r |= ((v >> i) & 1u) << (len - 1 - i);
+    return r;
+  };
+  for (int k = 0; k < kNumLL; ++k) ll_codes[k] = rev(ll_codes[k], ll_lengths[k]);
+  for (int k = 0; k < kNumD; ++k) d_codes[k] = rev(d_codes[k], d_lengths[k]);
+  out->Reserve((out->BitCount() + 7) / 8 + (lend - lstart) * 2 + 16);
   for (size_t i = lstart; i < lend; ++i) {
     const unsigned litlen = lz77.litlen(i), dist = lz77.dist(i);
     if (dist == 0) {
-      out->AddHuffmanBits(ll_codes[litlen], ll_lengths[litlen]);
+      out->AddBits(ll_codes[litlen], ll_lengths[litlen]);
     } else {
       const int ls = LengthSymbol(litlen), ds = DistSymbol(dist);
-      out->AddHuffmanBits(ll_codes[ls], ll_lengths[ls]);
-      out->AddBits(LengthExtraValue(litlen), LengthExtraBits(litlen));
-      out->AddHuffmanBits(d_codes[ds], d_lengths[ds]);
-      out->AddBits(DistExtraValue(dist), DistExtraBits(dist));
+      out->AddBits(ll_codes[ls] | (static_cast<uint32_t>(LengthExtraValue(litlen)) << ll_lengths[ls]),
+                   ll_lengths[ls] + static_cast<unsigned>(LengthExtraBits(litlen)));
+      out->AddBits(d_codes[ds] | (static_cast<uint32_t>(DistExtraValue(dist)) << d_lengths[ds]),
+                   d_lengths[ds] + static_cast<unsigned>(DistExtraBits(dist)));
     }
   }
-  out->AddHuffmanBits(ll_codes[256], ll_lengths[256]);
+  out->AddBits(ll_codes[256], ll_lengths[256]);
 }
 
 size_t EncodeBlockHeader(const Histogram& h, int btype, bool final_block, BitWriter* out, size_t* tree_bits,

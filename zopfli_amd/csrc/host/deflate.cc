@@ -38,6 +38,7 @@ struct FinalBlock {
 
 // A compressed block whose symbols the device writes (zmx_encode_blocks): it is a whole block of the optimal batch.
 struct DeviceEncode {
+  bool used = false;                 // (a slot per final block while the blocks are encoded side by side; the unused go)
   size_t chunk = 0;                  // index in the part's chunks
   size_t block = 0;                  // index in the batched block list (or in the fixed-tree re-parse batch)
   bool from_fixed = false;           // its symbols are the fixed-tree re-parse's
@@ -319,88 +320,102 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
 
   // ---- 5. pick the block type and encode
   const double t5 = Now();
-  ParallelForWide(np, [&](size_t p) {
+  // One task per final BLOCK, not per part: a block the device cannot write (the second split attempt moved its
+  // ends: its symbols are a stretch of several device blocks) has its bits made here, symbol by symbol — 4 ms for the
+  // 250 000 symbols of one master block, a tenth of a 1 MB call when its blocks took turns on one thread.
+  struct BlockTask { size_t p, i; };
+  std::vector<BlockTask> block_tasks;
+  for (size_t p = 0; p < np; ++p) {
+    st[p].chunks.assign(st[p].finals.size(), Chunk());
+    st[p].enc.assign(st[p].finals.size(), DeviceEncode());
+    for (size_t i = 0; i < st[p].finals.size(); ++i) block_tasks.push_back({p, i});
+  }
+  ParallelForWide(block_tasks.size(), [&](size_t task) {
+    const size_t p = block_tasks[task].p, i = block_tasks[task].i;
     PartState& s = st[p];
-    for (size_t i = 0; i < s.finals.size(); ++i) {
-      const FinalBlock& f = s.finals[i];
-      const bool final_block = (i + 1 == s.finals.size()) && s.part.final_part;
-      BitWriter w;
-      if (f.lstart == f.lend) {  // smallest empty block: fixed, end symbol only
-        w.AddBits(final_block ? 1 : 0, 1);
-        w.AddBits(1, 2);
-        w.AddBits(0, 7);
-        s.chunks.push_back(BitsChunk(&w));
-        continue;
-      }
-      double fixedcost = f.fixed;
-      Lz77Store fixedstore;
-      Histogram fixedhist;
-      if (f.expensive_fixed) {
-        if (fkeep.tables) {
-          const uint32_t* c = &fkeep.hist[static_cast<size_t>(f.fixed_request) * ZMX_HIST];
-          for (int k = 0; k < kNumLL; ++k) fixedhist.ll[k] = c[k];
-          for (int k = 0; k < kNumD; ++k) fixedhist.d[k] = c[kNumLL + k];
-          fixedcost = BlockSizeFromHistogram(fixedhist, 1);
-        } else {
-          fixedstore = StoreFromRun(fixed_runs[f.fixed_request], fixed_requests[f.fixed_request].instart);
-          fixedcost = CalculateBlockSize(fixedstore, 0, fixedstore.size(), 1);
-        }
-      }
-      if (f.stored < fixedcost && f.stored < f.dynamic) {
-        Chunk c;
-        c.kind = Chunk::kStored;
-        c.start = no_symbols ? s.blocks[0].instart : s.lz77.pos(f.lstart);
-        c.end = no_symbols ? s.blocks[0].inend : c.start + s.lz77.ByteRange(f.lstart, f.lend);
-        c.final_block = final_block;
-        s.chunks.push_back(std::move(c));
-        continue;
-      }
-      size_t tree_bits = 0;
-      const int used_btype = fixedcost < f.dynamic ? 1 : 2;
-      // the symbols of a block that is a whole block of the optimal batch are still on the device: it writes them
-      long dev_block = -1;
-      const bool fixed_on_device = used_btype == 1 && f.expensive_fixed && fkeep.tables != nullptr;
-      if (fixed_on_device) dev_block = f.fixed_request;
-      if (keep.tables && !(used_btype == 1 && f.expensive_fixed)) {
-        for (size_t k = 0; k < s.block_sym_end.size(); ++k) {
-          if (s.block_sym_end[k] == f.lend && (k == 0 ? 0 : s.block_sym_end[k - 1]) == f.lstart) dev_block = static_cast<long>(s.first_block + k);
-        }
-      }
-      Chunk c;
-      if (dev_block >= 0) {
-        DeviceEncode e;
-        e.from_fixed = fixed_on_device;
-        Histogram h;
-        if (fixed_on_device) h = fixedhist;          // (not read for btype 1)
-        else if (no_symbols) h = block_hist(s.first_block);
-        else s.lz77.GetHistogram(f.lstart, f.lend, &h);
-        e.data_bits = EncodeBlockHeader(h, used_btype, final_block, &w, &tree_bits, e.codes);
-        e.header = w.Finish(&e.header_bits);
-        e.block = static_cast<size_t>(dev_block);
-        e.chunk = s.chunks.size();
-        c.kind = Chunk::kBits;
-        c.nbits = e.header_bits + e.data_bits;
-        s.enc.push_back(std::move(e));
-      } else {
-        if (used_btype == 1) {
-          if (f.expensive_fixed) {
-            EncodeBlock(fixedstore, 0, fixedstore.size(), 1, final_block, &w);
-          } else {
-            EncodeBlock(s.lz77, f.lstart, f.lend, 1, final_block, &w);
-          }
-        } else {
-          EncodeBlock(s.lz77, f.lstart, f.lend, 2, final_block, &w, &tree_bits);
-        }
-        c = BitsChunk(&w);
-      }
-      c.log_block = true;
-      c.log_btype = used_btype;
-      c.log_tree_bits = tree_bits;
-      c.log_unc = no_symbols ? s.blocks[0].inend - s.blocks[0].instart : s.lz77.ByteRange(f.lstart, f.lend);
-      s.chunks.push_back(std::move(c));
+    const FinalBlock& f = s.finals[i];
+    const bool final_block = (i + 1 == s.finals.size()) && s.part.final_part;
+    BitWriter w;
+    if (f.lstart == f.lend) {  // smallest empty block: fixed, end symbol only
+      w.AddBits(final_block ? 1 : 0, 1);
+      w.AddBits(1, 2);
+      w.AddBits(0, 7);
+      s.chunks[i] = BitsChunk(&w);
+      return;
     }
-    if (options.verbose && !s.chunks.empty()) s.chunks.front().log_pre = std::move(s.log);
+    double fixedcost = f.fixed;
+    Lz77Store fixedstore;
+    Histogram fixedhist;
+    if (f.expensive_fixed) {
+      if (fkeep.tables) {
+        const uint32_t* c = &fkeep.hist[static_cast<size_t>(f.fixed_request) * ZMX_HIST];
+        for (int k = 0; k < kNumLL; ++k) fixedhist.ll[k] = c[k];
+        for (int k = 0; k < kNumD; ++k) fixedhist.d[k] = c[kNumLL + k];
+        fixedcost = BlockSizeFromHistogram(fixedhist, 1);
+      } else {
+        fixedstore = StoreFromRun(fixed_runs[f.fixed_request], fixed_requests[f.fixed_request].instart);
+        fixedcost = CalculateBlockSize(fixedstore, 0, fixedstore.size(), 1);
+      }
+    }
+    if (f.stored < fixedcost && f.stored < f.dynamic) {
+      Chunk c;
+      c.kind = Chunk::kStored;
+      c.start = no_symbols ? s.blocks[0].instart : s.lz77.pos(f.lstart);
+      c.end = no_symbols ? s.blocks[0].inend : c.start + s.lz77.ByteRange(f.lstart, f.lend);
+      c.final_block = final_block;
+      s.chunks[i] = std::move(c);
+      return;
+    }
+    size_t tree_bits = 0;
+    const int used_btype = fixedcost < f.dynamic ? 1 : 2;
+    // the symbols of a block that is a whole block of the optimal batch are still on the device: it writes them
+    long dev_block = -1;
+    const bool fixed_on_device = used_btype == 1 && f.expensive_fixed && fkeep.tables != nullptr;
+    if (fixed_on_device) dev_block = f.fixed_request;
+    if (keep.tables && !(used_btype == 1 && f.expensive_fixed)) {
+      for (size_t k = 0; k < s.block_sym_end.size(); ++k) {
+        if (s.block_sym_end[k] == f.lend && (k == 0 ? 0 : s.block_sym_end[k - 1]) == f.lstart) dev_block = static_cast<long>(s.first_block + k);
+      }
+    }
+    Chunk c;
+    if (dev_block >= 0) {
+      DeviceEncode e;
+      e.from_fixed = fixed_on_device;
+      Histogram h;
+      if (fixed_on_device) h = fixedhist;          // (not read for btype 1)
+      else if (no_symbols) h = block_hist(s.first_block);
+      else s.lz77.GetHistogram(f.lstart, f.lend, &h);
+      e.data_bits = EncodeBlockHeader(h, used_btype, final_block, &w, &tree_bits, e.codes);
+      e.header = w.Finish(&e.header_bits);
+      e.block = static_cast<size_t>(dev_block);
+      e.chunk = i;
+      e.used = true;
+      c.kind = Chunk::kBits;
+      c.nbits = e.header_bits + e.data_bits;
+      s.enc[i] = std::move(e);
+    } else {
+      if (used_btype == 1) {
+        if (f.expensive_fixed) {
+          EncodeBlock(fixedstore, 0, fixedstore.size(), 1, final_block, &w);
+        } else {
+          EncodeBlock(s.lz77, f.lstart, f.lend, 1, final_block, &w);
+        }
+      } else {
+        EncodeBlock(s.lz77, f.lstart, f.lend, 2, final_block, &w, &tree_bits);
+      }
+      c = BitsChunk(&w);
+    }
+    c.log_block = true;
+    c.log_btype = used_btype;
+    c.log_tree_bits = tree_bits;
+    c.log_unc = no_symbols ? s.blocks[0].inend - s.blocks[0].instart : s.lz77.ByteRange(f.lstart, f.lend);
+    s.chunks[i] = std::move(c);
   });
+  for (size_t p = 0; p < np; ++p) {
+    PartState& s = st[p];
+    s.enc.erase(std::remove_if(s.enc.begin(), s.enc.end(), [](const DeviceEncode& e) { return !e.used; }), s.enc.end());
+    if (options.verbose && !s.chunks.empty()) s.chunks.front().log_pre = std::move(s.log);
+  }
   // ---- 5b. the device writes the symbols of its blocks behind the headers (the blocks of the optimal batch, then
   //          those of the fixed-tree re-parses)
   for (int pass = 0; pass < 2; ++pass) {

@@ -331,11 +331,15 @@ double CalculateBlockSize(const Lz77Store& lz77, size_t lstart, size_t lend, int
 }
 
 double CalculateBlockSizeAutoType(const Lz77Store& lz77, size_t lstart, size_t lend) {
+  return CalculateBlockSizeAutoTypeOf(lz77, lstart, lend, lz77.size());
+}
+
+double CalculateBlockSizeAutoTypeOf(const Lz77Store& lz77, size_t lstart, size_t lend, size_t store_size) {
   const double stored = CalculateBlockSize(lz77, lstart, lend, 0);
   Histogram h;
   lz77.GetHistogram(lstart, lend, &h);
   // fixed-tree size is only evaluated for small stores (deflate.c:615)
-  const double fixed = lz77.size() > 1000 ? stored : BlockSizeFromHistogram(h, 1);
+  const double fixed = store_size > 1000 ? stored : BlockSizeFromHistogram(h, 1);
   const double dynamic = BlockSizeFromHistogram(h, 2);
   return (stored < fixed && stored < dynamic) ? stored : (fixed < dynamic ? fixed : dynamic);
 }

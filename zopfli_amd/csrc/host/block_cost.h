@@ -26,6 +26,9 @@ double CalculateBlockSize(const Lz77Store& lz77, size_t lstart, size_t lend, int
 
 // ZopfliCalculateBlockSizeAutoType (deflate.c:610).
 double CalculateBlockSizeAutoType(const Lz77Store& lz77, size_t lstart, size_t lend);
+// the same for symbols [lstart, lend) of a store that holds more than the store the reference would pass:
+// `store_size` = the size of that store (deflate.c:615 looks at it)
+double CalculateBlockSizeAutoTypeOf(const Lz77Store& lz77, size_t lstart, size_t lend, size_t store_size);
 
 // OptimizeHuffmanForRle (deflate.c:434); exposed for unit tests.
 void OptimizeCountsForRle(int length, size_t* counts);

@@ -1,5 +1,7 @@
 #include "deflate.h"
 
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -83,6 +85,12 @@ Lz77Store StoreFromRun(const SymbolRun& run, size_t pos) {
   return s;
 }
 
+// ZOPFLI_AMD_TRACE_CALL=1 (api.cc prints the call's shards): the phases of DeflateParts on stderr
+bool TraceCallEnv() {
+  static const bool on = [] { const char* e = std::getenv("ZOPFLI_AMD_TRACE_CALL"); return e && std::atoi(e) != 0; }();
+  return on;
+}
+
 Chunk BitsChunk(BitWriter* w) {
   Chunk c;
   c.kind = Chunk::kBits;
@@ -141,9 +149,11 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
     std::vector<zmx_block> ranges(np);
     for (size_t p = 0; p < np; ++p) ranges[p] = {parts[p].instart, parts[p].inend};
     std::vector<SymbolRun> greedy;
+    const double tg0 = Now();
     rc = Lz77GreedyBatch(ctx, ranges, &greedy, &split_tables);
     if (rc) return rc;
     const double t0 = Now();
+    std::atomic<uint64_t> ns_store{0}, ns_search{0};
     if (BatchSplit(np)) {
       // a few parts: all their searches advance together, round by round, on the whole pool (block_split.cc)
       std::vector<Lz77Store> stores;
@@ -159,14 +169,22 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
       }
     } else {
       ParallelForWide(np, [&](size_t p) {
+        const double a = Now();
         Lz77Store s = StoreFromRun(greedy[p], parts[p].instart);
+        const double b = Now();
         std::vector<size_t> pts;
         BlockSplitLz77(s, static_cast<size_t>(options.blocksplittingmax), &pts);
         if (options.verbose) st[p].log += SplitPointsLine(s, pts);   // blocksplitter.c:266-268
         split_bytes[p] = SplitPointsToBytes(s, pts, parts[p].instart);
+        ns_store.fetch_add(static_cast<uint64_t>((b - a) * 1e9), std::memory_order_relaxed);
+        ns_search.fetch_add(static_cast<uint64_t>((Now() - b) * 1e9), std::memory_order_relaxed);
       });
     }
     ThreadTiming().split += Now() - t0;
+    if (TraceCallEnv()) {
+      std::fprintf(stderr, "    DeflateParts(%zu parts): greedy batch %.2f ms, first split %.2f ms (per part: store %.2f, search %.2f)\n", np,
+                   (t0 - tg0) * 1e3, (Now() - t0) * 1e3, ns_store.load() / 1e6 / np, ns_search.load() / 1e6 / np);
+    }
   }
 
   // ---- 2. optimal parse of every block of every part, one batch (deflate.c:854-869)
@@ -181,7 +199,7 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
       all_blocks.push_back({s, e});
     }
   }
-  static const bool trace_phases = std::getenv("ZOPFLI_AMD_PROF") != nullptr;
+  static const bool trace_phases = std::getenv("ZOPFLI_AMD_PROF") != nullptr || TraceCallEnv();
   const double tp0 = Now();
   std::vector<SymbolRun> runs;
   // (ZOPFLI_AMD_DEVICE_ENCODE=0: every block's bits on the host, as in round 1)
@@ -238,14 +256,18 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
       s.lz77.Reserve(total);
     }
     for (size_t i = 0; i <= npoints; ++i) {
-      s.log += runs[s.first_block + i].log;       // "Iteration i: n bit" (squeeze.c:493), block after block
-      Lz77Store bs = StoreFromRun(runs[s.first_block + i], s.blocks[i].instart);
-      totalcost[p] += CalculateBlockSizeAutoType(bs, 0, bs.size());
-      s.lz77.Append(bs);
+      const SymbolRun& run = runs[s.first_block + i];
+      s.log += run.log;       // "Iteration i: n bit" (squeeze.c:493), block after block
+      // (the block's symbols straight into the part's store; the reference prices the block's own store,
+      //  deflate.c:866: its size is what the fixed-tree rule of :615 looks at)
+      const size_t lstart = s.lz77.size();
+      s.lz77.Append(run.litlens.data(), run.dists.data(), run.litlens.size(), s.blocks[i].instart);
+      totalcost[p] += CalculateBlockSizeAutoTypeOf(s.lz77, lstart, s.lz77.size(), run.litlens.size());
       s.block_sym_end.push_back(s.lz77.size());
       if (i < npoints) s.splitpoints.push_back(s.lz77.size());
     }
   });
+  const double tj1 = Now();
   // deflate.c:872-893: the second split attempt, on the optimal parse
   std::vector<std::vector<size_t>> pts2(np);
   std::vector<char> tried(np, 0);
@@ -262,6 +284,7 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
       if (tried[p]) BlockSplitLz77(st[p].lz77, static_cast<size_t>(options.blocksplittingmax), &pts2[p]);
     });
   }
+  const double tj2 = Now();
   ParallelForWide(np, [&](size_t p) {
     PartState& s = st[p];
     if (tried[p]) {
@@ -285,6 +308,10 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
       s.finals.push_back(f);
     }
   });
+  if (TraceCallEnv()) {
+    std::fprintf(stderr, "    DeflateParts(%zu parts): optimal batch %.2f ms; stores joined %.2f ms, second split %.2f ms, block costs %.2f ms\n", np,
+                 (tp1 - tp0) * 1e3, (tj1 - t3) * 1e3, (tj2 - tj1) * 1e3, (Now() - tj2) * 1e3);
+  }
   }
   ThreadTiming().split += Now() - t3;
 

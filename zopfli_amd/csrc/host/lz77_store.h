@@ -66,10 +66,29 @@ class Lz77Store {
   // Append `n` symbols starting at byte position `pos` (positions are implied
   // by the symbol lengths).  ZopfliAppendLZ77Store (lz77.c:151).
   void Append(const uint16_t* litlens, const uint16_t* dists, size_t n, size_t pos) {
-    Reserve(size() + n);
+    // (in one piece: a master block is a quarter of a million symbols, and three push_backs and a look at the sample
+    //  grid per symbol were most of what joining the blocks' stores cost)
+    const size_t base = size();
+    litlens_.resize(base + n);
+    dists_.resize(base + n);
+    pos_.resize(base + n);
+    if (n) {
+      std::memcpy(litlens_.data() + base, litlens, n * sizeof(uint16_t));
+      std::memcpy(dists_.data() + base, dists, n * sizeof(uint16_t));
+    }
+    samples_.reserve((base + n) / kSample + 1);
     for (size_t i = 0; i < n; ++i) {
-      Push(litlens[i], dists[i], pos);
-      pos += dists[i] == 0 ? 1 : litlens[i];
+      if ((base + i) % kSample == 0) samples_.push_back(running_);    // counts of the symbols before this one
+      pos_[base + i] = pos;
+      const unsigned litlen = litlens[i], dist = dists[i];
+      if (dist == 0) {
+        running_.ll[litlen]++;
+        pos += 1;
+      } else {
+        running_.ll[LengthSymbol(litlen)]++;
+        running_.d[DistSymbol(dist)]++;
+        pos += litlen;
+      }
     }
   }
   void Append(const Lz77Store& other) {

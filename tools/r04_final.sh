@@ -16,4 +16,4 @@ except Exception as e: print("ERR", e)
 PY
 timeout 200 python tools/latency.py > $OUT/latency.jsonl 2> $OUT/latency.err; cut -c1-200 $OUT/latency.jsonl
 TAG=${TAG:-r04_final}/match bash tools/r04_match.sh > $OUT/match.txt 2>&1; tail -9 $OUT/match.txt | cut -c1-300
-TAG=${TAG:-r04_final}/prof bash tools/collect_profiles.sh > $OUT/profiles.txt 2>&1; tail -30 $OUT/profiles.txt | cut -c1-250
+BENCH_ARGS="--steps 1 --warmup 0 --no-cpu-baseline --entry resident --no-blocksplitting1" TAG=${TAG:-r04_final}/prof bash tools/collect_profiles.sh > $OUT/profiles.txt 2>&1; tail -30 $OUT/profiles.txt | cut -c1-250

@@ -160,3 +160,18 @@ def test_adversarial_streams_vs_reference(gpu_lib, case):
     got = api.compress(data, 0, ZopfliOptions(iters), lib=gpu_lib)
     want = ol.ref_compress(data, 0, iters)
     assert got == want, (name, len(got), len(want))
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_match_fuzz(seed):
+    """tools/fuzz_match.py: streams glued from those generators, text, copies and noise, through ZopfliCompress with the
+    per-block choice of walk, the skip-walk forced and the hit-by-hit walk forced, random options and containers — byte for
+    byte the reference's (12 cases a seed here; 120 more were run for profiles/README.md)."""
+    import os
+    import subprocess
+    import sys
+    if not ol.have_ref():
+        pytest.skip("oracle/_ref not built")
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_match.py")
+    r = subprocess.run([sys.executable, tool, "12", str(seed)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -976,6 +976,15 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
       q.tot12 = d_tot12;
       q.energy = mk == 0 ? d_energy : nullptr;
       q.thr = MatchAutoHits();
+      {
+        // positions a wave takes at a time: larger pieces keep the lanes busier (fewer ends of a piece, where lanes
+        // wait for the piece's longest walks), smaller ones the waves when there are few tiles.  100 MB, pieces of 512 /
+        // 1024 / 2048 positions: T 22.4 / 20.0 / 20.4 ms, P 30.1 / 27.9 / 29.5, B 97.1 / 93.1 / 100.0 (ZOPFLI_AMD_M5_UNIT =
+        // 2 / 1 / 0 forces one)
+        static const int forced = [] { const char* e = std::getenv("ZOPFLI_AMD_M5_UNIT"); return e ? std::atoi(e) : -1; }();
+        const u64 waves = static_cast<u64>(kMatchGrid5) * (M5_THREADS / 64);
+        q.sub_shift = forced >= 0 ? static_cast<u32>(forced > 2 ? 2 : forced) : (mp.total_tiles >= 4 * waves ? 1u : 2u);
+      }
       if (mk == 5 || skip_all) {
         hipLaunchKernelGGL(k_match5, dim3(kMatchGrid5), dim3(M5_THREADS), 0, c->stream, q);   // (no profile counts: tools/match_skip_model.c has the entries touched)
         KCHK(c, "k_match5");

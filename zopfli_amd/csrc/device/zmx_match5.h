@@ -465,10 +465,10 @@ __global__ __launch_bounds__(RK_THREADS) void k_rank2(RankParams P) {
 }
 
 // ----------------------------------------------------------------------------
-// k_match5.  A wave owns a quarter of a 2048-position tile at a time (512 positions, 8 a lane) and its lanes take the
-// quarter's positions one after the other; nothing is staged in LDS: a walk touches ~10 entries, the 32 KiB window of
+// k_match5.  A wave owns a half or a quarter of a 2048-position tile at a time (sub_shift: 1024 positions where there are
+// many tiles, 512 where few) and its lanes take the piece's positions one after the other; nothing is staged in LDS: a walk touches ~10 entries, the 32 KiB window of
 // bytes k_match2 stages per tile would be read ~40 times per position staged, and with it goes the tile's barrier —
-// k_match2's lanes wait for the tile's longest walk, here a lane waits only at the end of its wave's quarter.  Per entry the lane has in flight together: the entry's record (16 + 8 bytes), the 4 bytes the filter
+// k_match2's lanes wait for the tile's longest walk, here a lane waits only at the end of its wave's piece.  Per entry the lane has in flight together: the entry's record (16 + 8 bytes), the 4 bytes the filter
 // tests and the entry's first 16 bytes; the position's own first 16 bytes stay in registers, so a common prefix
 // of up to 15 bytes — most of them — is decided in the iteration the entry arrives in.
 // ----------------------------------------------------------------------------
@@ -478,6 +478,7 @@ struct Match5Params {
   const u32* tot12;      // k_rank2: the sizes of a position's two classes in the chunk before its own
   const unsigned long long* energy;   // k_hits (null: every block)
   u64 thr;
+  u32 sub_shift;         // a wave takes 2048 >> sub_shift positions at a time (0, 1 or 2)
 };
 
 #define M5_THREADS 256
@@ -520,15 +521,17 @@ __global__ __launch_bounds__(M5_THREADS, 4) void k_match5(Match5Params Q) {
   u32* my_scratch = P.scratch + ((u64)blockIdx.x * M5_THREADS + tid) * SCRATCH_CPS;
 
   for (;;) {
-    // a wave takes a quarter of a 2048-position tile at a time (its own cursors: k_match2 may run beside it): a tile
-    // of two-symbol data is seconds of one wave's dependent loads, and the kernel ends with its last wave
+    // a wave takes a piece of a 2048-position tile at a time (its own cursors: k_match2 may run beside it): a whole
+    // tile of two-symbol data is seconds of one wave's dependent loads, and the kernel ends with its last wave
     u32 tk = 0;
     if (lane == 0) tk = atomicAdd(&P.counters[24 + xcd], 1u);
     tk = (u32)__builtin_amdgcn_readfirstlane((int)tk);
-    const u32 q_idx = ((tk / (4u * M_XCD_GROUP)) * 8u + xcd) * (4u * M_XCD_GROUP) + (tk % (4u * M_XCD_GROUP));
-    const u32 t_idx = q_idx >> 2;
+    const u32 sub = 1u << Q.sub_shift, grp = sub * M_XCD_GROUP;          // pieces per tile, per group of tiles of one XCD
+    const u32 q_idx = ((tk / grp) * 8u + xcd) * grp + (tk % grp);
+    const u32 t_idx = q_idx >> Q.sub_shift;
     if (t_idx >= P.total_tiles) break;
     const u32 tile = P.tile_list ? P.tile_list[t_idx] : t_idx;
+    const u32 unit = MT >> Q.sub_shift;
 
     u32 lo = 0, hi = P.nb;
     while (hi - lo > 1) {
@@ -537,9 +540,9 @@ __global__ __launch_bounds__(M5_THREADS, 4) void k_match5(Match5Params Q) {
     }
     const BlockDesc bd = P.blocks[lo];
     if (!m5_block_on(Q.energy, Q.thr, lo, bd.inend - bd.ws)) continue;     // k_match2's block
-    const u64 p0 = bd.instart + (u64)(tile - P.tile_off[lo]) * MT + (u64)(q_idx & 3u) * (MT / 4u);
+    const u64 p0 = bd.instart + (u64)(tile - P.tile_off[lo]) * MT + (u64)(q_idx & (sub - 1u)) * unit;
     if (p0 >= bd.inend) continue;
-    const u64 p1 = (p0 + MT / 4u < bd.inend) ? p0 + MT / 4u : bd.inend;
+    const u64 p1 = (p0 + unit < bd.inend) ? p0 + unit : bd.inend;
     const u32 ntile = (u32)(p1 - p0);
 
     // scalar bases, 32-bit lane offsets: region position li -> its record, its bytes

@@ -532,6 +532,18 @@ def main():
                               "positions_per_step": mpos / args.steps,
                               "ns_per_position": round(msec / mpos * 1e9, 4),
                               "hash_kernels_seconds_per_step": round(k_timing.get("hash_kernels", 0.0) / args.steps, 5)}
+            wpos = k_timing.get("skip_walk_positions", 0.0)
+            if wpos > 0:
+                # k_match5's own counts: what the skip-walk touched instead of the reference's hit-by-hit visits
+                li, wi = k_timing.get("skip_walk_lane_iterations", 0.0), k_timing.get("skip_walk_wave_iterations", 0.0)
+                roofline_match["skip_walk"] = {
+                    "positions_per_step": wpos / args.steps,
+                    "share_of_positions": round(wpos / mpos, 4),
+                    "entries_in_flight_per_position": round(li / wpos, 2),
+                    "lanes_busy_per_wave_iteration": round(li / max(wi, 1.0), 1),
+                    "note": "entries in flight = lanes with an entry's loads outstanding, summed over the wave iterations (an "
+                            "entry longer than 15 bytes in common takes one more iteration per 16 bytes); the reference's walk "
+                            "visits 100 (text) to 2 200 (two-symbol data) chain entries per position, counted here from ranks"}
         line = {
             "metric": "input MB/s at numiterations=15 (gzip, bit-exact vs reference)",
             "value": round(value, 4), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

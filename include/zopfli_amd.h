@@ -334,6 +334,10 @@ int zmx_last_host_timing(double* out2);
  * k_chain (or k_bucket) [2] table builds [3] positions whose record
  * the match kernel computed (the others were copied from the parent tables). */
 int zmx_last_match_timing(double* out4);
+/* The skip-walk (k_match5) of the table builds since the last Zopfli* call started / zmx_deflate_range: out3 = entries in
+ * flight summed over lanes and wave iterations (a position's walk touches ~10 entries whatever its chains' length), wave
+ * iterations, positions the kernel walked (blocks k_hits sent to it).  Zero when every block took k_match2. */
+int zmx_last_match_walk(double* out3);
 
 /* Several contexts on one device (the Zopfli* entry points keep up to three per device).  The budgets are the DEVICE's,
  * not a context's: what the pools of all its contexts keep cached between batches counts against one third of its memory

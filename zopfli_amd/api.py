@@ -173,6 +173,9 @@ def last_timing(lib=None):
     m = (ctypes.c_double * 4)()
     lib.zmx_last_match_timing(m)
     d["match_kernel"], d["hash_kernels"], d["table_builds"], d["positions_matched"] = m[0], m[1], m[2], m[3]
+    w = (ctypes.c_double * 3)()
+    lib.zmx_last_match_walk(w)
+    d["skip_walk_lane_iterations"], d["skip_walk_wave_iterations"], d["skip_walk_positions"] = w[0], w[1], w[2]
     return d
 
 

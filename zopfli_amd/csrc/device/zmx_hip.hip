@@ -36,6 +36,7 @@ thread_local std::string g_err;   // per calling thread (zmx_last_error)
 std::mutex g_stats_mutex;
 double g_kernel_seconds[3] = {0, 0, 0};  // k_wtab + k_badscan, chain kernels (k_dp5_spec + k_dpcheck + k_dp4_fix), k_trace (HIP events)
 double g_squeeze_launches = 0;
+double g_match5_stats[3] = {0, 0, 0};    // k_match5: entries in flight summed over lanes and iterations, wave iterations, positions it walked
 double g_match_stats[4] = {0, 0, 0, 0};  // k_match2 seconds, k_same + k_chain seconds, table builds, positions matched
 double g_seg_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // tasks, accepted, re-run: state / level / tie, positions re-run, re-run: values, positions
 
@@ -481,6 +482,12 @@ void zmx_internal_seg_stats(double* out8, int reset) {
   if (reset) for (int i = 0; i < 8; ++i) g_seg_stats[i] = 0;
 }
 
+void zmx_internal_match5_stats(double* out3, int reset) {
+  std::lock_guard<std::mutex> lock(g_stats_mutex);
+  for (int i = 0; i < 3; ++i) out3[i] = g_match5_stats[i];
+  if (reset) for (int i = 0; i < 3; ++i) g_match5_stats[i] = 0;
+}
+
 void zmx_internal_match_stats(double* out4, int reset) {
   std::lock_guard<std::mutex> lock(g_stats_mutex);
   for (int i = 0; i < 4; ++i) out4[i] = g_match_stats[i];
@@ -825,6 +832,8 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   u32* d_tot12 = nullptr;
   unsigned long long* d_energy = nullptr;   // k_hits (kernel 0 = per block: k_match5 where the chains are long)
   bool skip_any = false, skip_all = false;  // some / all blocks of this build take k_match5
+  double skip_positions = 0;                // positions of those blocks
+  unsigned long long* d_m5stats = nullptr;  // k_match5's per-wave sums
   bool join_stream2 = false;
   auto launch_hash = [&](const u64* d_link_lo) -> int {
     if (max_l == 0) return 0;
@@ -852,6 +861,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
         // reference's walk would make, block by block; kernel 5 forces it for every block.  (Whole blocks only: a
         // table built from a parent recomputes a few tiles with k_match2.)
         skip_any = mk == 5;
+        if (mk == 5) for (size_t b = 0; b < nb; ++b) skip_positions += static_cast<double>(t->blocks[b].inend - t->blocks[b].instart);
         if (mk == 0) {
           if (!d_energy) HIPCHK(hash_tmp.AllocT(&d_energy, nb, "d_energy"));
           HIPCHK(hipMemsetAsync(d_energy, 0, nb * sizeof(unsigned long long), c->stream));
@@ -867,7 +877,12 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
           HIPCHK(hipMemcpyAsync(energy.data(), d_energy, nb * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
           HIPCHK(hipStreamSynchronize(c->stream));
           size_t on = 0;
-          for (size_t b = 0; b < nb; ++b) on += energy[b] > MatchAutoHits() * (t->blocks[b].inend - t->blocks[b].ws) ? 1 : 0;
+          for (size_t b = 0; b < nb; ++b) {
+            if (energy[b] > MatchAutoHits() * (t->blocks[b].inend - t->blocks[b].ws)) {
+              ++on;
+              skip_positions += static_cast<double>(t->blocks[b].inend - t->blocks[b].instart);
+            }
+          }
           skip_any = on != 0;
           skip_all = on == nb;
         }
@@ -921,6 +936,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   if (mk != 3 && !c->d_scratch) HIPCHK(PoolAllocT(c, &c->d_scratch, static_cast<size_t>(kMatchGrid) * M2_THREADS * SCRATCH_CPS, "d_scratch"));
   HIPCHK(hipEventRecord(c->ev[1], c->stream));
   double match_positions = 0;
+  double m5_lane_iters = 0, m5_iters = 0;   // k_match5's own counts
   // the match-table kernel over `total_tiles` tiles (all of them, or those of tile_list)
   auto launch_match = [&](u32* pool, u32 pool_cap, u32 total_tiles, const u32* d_tiles, bool prof) -> int {
     if (total_tiles == 0) return 0;
@@ -976,6 +992,10 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
       q.tot12 = d_tot12;
       q.energy = mk == 0 ? d_energy : nullptr;
       q.thr = MatchAutoHits();
+      const size_t m5_waves = static_cast<size_t>(kMatchGrid5) * (M5_THREADS / 64);
+      if (!d_m5stats) HIPCHK(hash_tmp.AllocT(&d_m5stats, 2 * m5_waves, "d_m5stats"));
+      HIPCHK(hipMemsetAsync(d_m5stats, 0, 2 * m5_waves * sizeof(unsigned long long), c->stream));
+      q.wave_stats = d_m5stats;
       {
         // positions a wave takes at a time: larger pieces keep the lanes busier (fewer ends of a piece, where lanes
         // wait for the piece's longest walks), smaller ones the waves when there are few tiles.  100 MB, pieces of 512 /
@@ -1077,6 +1097,13 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     HIPCHK(hipMemcpyAsync(counters, t->d_counters, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     match_positions += static_cast<double>(pos_off);
+    if (d_m5stats) {      // (of the last attempt: the pool may grow and the kernel run again)
+      const size_t m5_waves = static_cast<size_t>(kMatchGrid5) * (M5_THREADS / 64);
+      std::vector<unsigned long long> ws(2 * m5_waves);
+      HIPCHK(hipMemcpy(ws.data(), d_m5stats, ws.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      m5_lane_iters = m5_iters = 0;
+      for (size_t w = 0; w < m5_waves; ++w) { m5_lane_iters += static_cast<double>(ws[2 * w]); m5_iters += static_cast<double>(ws[2 * w + 1]); }
+    }
     if (counters[1] & 2u) {
       u32 dbg[8] = {0};
       HIPCHK(hipMemcpy(dbg, t->d_counters + 32, sizeof(dbg), hipMemcpyDeviceToHost));
@@ -1101,6 +1128,11 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     g_match_stats[1] += ms_hash * 1e-3;
     g_match_stats[2] += 1;
     g_match_stats[3] += reuse ? static_cast<double>(tile_list.size()) * MT : match_positions;
+    if (skip_any && !reuse) {
+      g_match5_stats[0] += m5_lane_iters;
+      g_match5_stats[1] += m5_iters;
+      g_match5_stats[2] += skip_positions;
+    }
     if (std::getenv("ZOPFLI_AMD_PROF") && !reuse) {
       unsigned long long hc[2] = {0, 0};
       HIPCHK(hipMemcpy(hc, t->d_counters + 4, sizeof(hc), hipMemcpyDeviceToHost));

@@ -479,6 +479,7 @@ struct Match5Params {
   const unsigned long long* energy;   // k_hits (null: every block)
   u64 thr;
   u32 sub_shift;         // a wave takes 2048 >> sub_shift positions at a time (0, 1 or 2)
+  unsigned long long* wave_stats;   // optional, two per wave of the grid: entries in flight summed over lanes and iterations, iterations
 };
 
 #define M5_THREADS 256
@@ -519,6 +520,7 @@ __global__ __launch_bounds__(M5_THREADS, 4) void k_match5(Match5Params Q) {
   const u64 lt_mask = (1ull << lane) - 1;
   const u32 xcd = blockIdx.x & 7;
   u32* my_scratch = P.scratch + ((u64)blockIdx.x * M5_THREADS + tid) * SCRATCH_CPS;
+  unsigned long long sum_lane_iter = 0, sum_iter = 0;     // what this wave's walks cost (wave_stats)
 
   for (;;) {
     // a wave takes a piece of a 2048-position tile at a time (its own cursors: k_match2 may run beside it): a whole
@@ -590,6 +592,7 @@ __global__ __launch_bounds__(M5_THREADS, 4) void k_match5(Match5Params Q) {
     uint4 PA = make_uint4(0, 0, 0, 0);
     u32 plv0 = 0, plv1 = 0, plv2 = 0, plv3 = 0, plv4 = 0;   // the position's own level links (lv0|lv1, lv2|lv3, ...)
     u32 n_iter = 0;
+    u32 n_lane_iter = 0;           // lanes with an entry in flight, summed over the piece's iterations
 
     auto fetch = [&](u32 d, u32 kind) {
       xd = d;
@@ -780,6 +783,7 @@ __global__ __launch_bounds__(M5_THREADS, 4) void k_match5(Match5Params Q) {
       // A wave-loop that does not end would hang the device: far beyond what a tile can take (8 positions a lane,
       // at most 8192 hits each), the tile is given up, the state of a running lane goes to counters[32..39] and
       // the host fails the build.
+      n_lane_iter += (u32)__popcll(m_run);
       if (++n_iter > (1u << 20)) {
         atomicOr(&P.counters[1], 2u);
         {
@@ -930,5 +934,14 @@ __global__ __launch_bounds__(M5_THREADS, 4) void k_match5(Match5Params Q) {
       if (moved && !fin) fin = !next_entry();
       if (fin) st = M5_PEND;
     }
+    sum_lane_iter += n_lane_iter;
+    sum_iter += n_iter;
+  }
+  // (plain stores, one slot per wave: two atomic adds per piece at this point made the kernel not come back — twice,
+  //  never understood)
+  if (Q.wave_stats && lane == 0) {
+    unsigned long long* w = Q.wave_stats + 2u * ((u64)blockIdx.x * (M5_THREADS / 64) + (tid >> 6));
+    w[0] = sum_lane_iter;
+    w[1] = sum_iter;
   }
 }

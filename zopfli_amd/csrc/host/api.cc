@@ -26,6 +26,7 @@
 extern "C" void zmx_internal_kernel_stats(double* seconds3, double* squeeze_launches, int reset);
 extern "C" void zmx_internal_seg_stats(double* out8, int reset);
 extern "C" void zmx_internal_match_stats(double* out4, int reset);
+extern "C" void zmx_internal_match5_stats(double* out3, int reset);
 // implemented by the device layer: size of the resident input
 extern "C" size_t zmx_internal_input_size(zmx_ctx* ctx);
 // implemented by the device layer: the caller's host copy of the resident input (borrowed)
@@ -537,6 +538,7 @@ void ResetTiming() {
   zmx_internal_kernel_stats(a, &b, 1);
   zmx_internal_seg_stats(a, 1);
   zmx_internal_match_stats(a, 1);
+  zmx_internal_match5_stats(a, 1);
 }
 
 void PushByte(unsigned v, unsigned char** out, size_t* outsize) {
@@ -712,6 +714,11 @@ int zmx_last_kernel_timing(double* out4) {
 
 int zmx_last_match_timing(double* out4) {
   zmx_internal_match_stats(out4, 0);
+  return 0;
+}
+
+int zmx_last_match_walk(double* out3) {
+  zmx_internal_match5_stats(out3, 0);
   return 0;
 }
 

@@ -350,6 +350,10 @@ typedef void (*zmx_oom_hook_t)(int device);
 void zmx_set_oom_hook(zmx_oom_hook_t hook);
 int zmx_ctx_set_share(zmx_ctx* ctx, unsigned contexts_on_device);
 int zmx_ctx_trim_cache(zmx_ctx* ctx);
+/* Which streams the context's next calls run on: 0 = the pair it was created with, +1 / -1 = a pair of the highest /
+ * lowest priority the device has.  Only while the context is idle.  The Zopfli* entry points give the contexts a call with
+ * block splitting is dealt over three different priorities (ZOPFLI_AMD_STREAM_PRIO=0: never). */
+int zmx_ctx_set_priority(zmx_ctx* ctx, int level);
 
 /* Which match-table kernel the table builds that START after this call use (the ZOPFLI_AMD_MATCH environment
  * variable sets the initial choice): 0 = per block, k_match5 where k_hits estimates long chains, k_match2 elsewhere

@@ -71,6 +71,7 @@ int zmx_set_match_kernel(int) { return 0; }   // (no kernels here)
 void zmx_set_oom_hook(zmx_oom_hook_t) {}
 int zmx_ctx_set_share(zmx_ctx*, unsigned) { return 0; }
 int zmx_ctx_trim_cache(zmx_ctx*) { return 0; }
+int zmx_ctx_set_priority(zmx_ctx*, int) { return 0; }
 int zmx_png_filter_types(zmx_ctx*, const unsigned char*, size_t, size_t, size_t, unsigned char*, unsigned char*) { g_err = "not in the host test library"; return -1; }
 // (the RCCL gather of dist.cc is not part of the host-logic test library)
 int zmx_dist_unique_id(unsigned char*) { g_err = "no RCCL in the host test library"; return -1; }

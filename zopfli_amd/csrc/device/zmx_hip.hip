@@ -124,6 +124,7 @@ struct zmx_ctx {
   size_t pool_free_bytes = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipStream_t stream2 = nullptr;   // the run tasks' k_dp5_spec beside the others' (zmx_squeeze_run)
+  hipStream_t alt_stream[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // zmx_ctx_set_priority: [0] the created pair, [1] high, [2] low
   hipEvent_t ev2[2] = {nullptr, nullptr};
   u32* h_stage = nullptr;    // pinned staging for store downloads (grow-only)
   size_t stage_cap = 0;      // in u32
@@ -539,6 +540,30 @@ int zmx_ctx_create(int device, zmx_ctx** out) {
   return 0;
 }
 
+// Which streams the context's next calls run on: level 0 = the pair it was created with, +1 / -1 = a pair of the highest /
+// lowest priority the device has (made when first asked for).  A call with block splitting that is dealt over the three
+// contexts of a device gives them three priorities (api.cc): the contexts then run one AFTER the other where they would
+// share the device evenly, so their host phases — the split searches, the joins — come at different times and fall beside
+// the others' kernels instead of beside each other (100 MB of text: 152 -> 145 ms); without block splitting there is
+// little host work to hide and running in turn only costs the overlap of the kernels' tails (123 -> 130 ms), so such
+// calls stay on level 0.  Only between calls: the context must be idle.
+int zmx_ctx_set_priority(zmx_ctx* c, int level) {
+  DeviceGuard dev_guard(c->device);
+  HIPCHK(dev_guard.err);
+  const int k = level > 0 ? 1 : level < 0 ? 2 : 0;
+  if (k && !c->alt_stream[k][0]) {
+    int least = 0, greatest = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithPriority(&c->alt_stream[k][i], hipStreamDefault, k == 1 ? greatest : least));
+  }
+  if (!c->alt_stream[0][0]) { c->alt_stream[0][0] = c->stream; c->alt_stream[0][1] = c->stream2; }   // the pair of zmx_ctx_create
+  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream2));
+  c->stream = c->alt_stream[k][0];
+  c->stream2 = c->alt_stream[k][1];
+  return 0;
+}
+
 void zmx_ctx_destroy(zmx_ctx* c) {
   if (!c) return;
   DeviceGuard dev_guard(c->device);
@@ -550,8 +575,12 @@ void zmx_ctx_destroy(zmx_ctx* c) {
   (void)hipFree(c->d_guard_tab);
   for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   for (int i = 0; i < 2; ++i) if (c->ev2[i]) (void)hipEventDestroy(c->ev2[i]);
-  if (c->stream2) (void)hipStreamDestroy(c->stream2);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->alt_stream[0][0]) {       // (stream / stream2 are one of these pairs)
+    for (int k = 0; k < 3; ++k) for (int i = 0; i < 2; ++i) if (c->alt_stream[k][i]) (void)hipStreamDestroy(c->alt_stream[k][i]);
+  } else {
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+  }
   delete c;
 }
 

@@ -347,3 +347,35 @@ def test_concurrent_callers():
     for t in threads:
         t.join()
     assert got == want
+
+
+def test_host_bit_writer_on_every_block():
+    """ZOPFLI_AMD_DEVICE_ENCODE=0: every block's bits from the host bit writer (bit_writer.h, block_cost.cc EncodeBlock —
+    codes reversed once per block, a symbol's code and extra bits in one piece, four bytes out at a time) instead of
+    from zmx_encode_blocks: the streams of every class, with fixed-tree and dynamic blocks, long matches at long
+    distances (13 extra bits) and literals only, must equal the reference's."""
+    import subprocess
+    import sys
+    code = (
+        "import hashlib, sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import oracle_lib as ol\n"
+        "from zopfli_amd import ZopfliOptions, api, generate\n"
+        "host = ol.hosttest_library()\n"
+        "bad = []\n"
+        "cases = [(c, n, it, bs, fmt) for c, n in (('T', 90000), ('X', 60000), ('R', 30000), ('Z', 120000), ('B', 20000), ('P', 70000), ('M', 150000))\n"
+        "         for it, bs, fmt in ((1, 1, 0), (3, 0, 2), (2, 1, 1))]\n"
+        "cases += [('T', 300, 2, 1, 0), ('R', 40, 1, 1, 2), ('Z', 1000, 1, 0, 0)]\n"
+        "for c, n, it, bs, fmt in cases:\n"
+        "    data = generate(c, n)\n"
+        "    got = api.compress(data, fmt, ZopfliOptions(it, bs), lib=host)\n"
+        "    want = ol.ref_compress(data, fmt, it, bs)\n"
+        "    if got != want: bad.append((c, n, it, bs, fmt, len(got), len(want)))\n"
+        "print('BAD' if bad else 'OK', bad)\n"
+        % (os.path.dirname(os.path.dirname(__file__)), os.path.dirname(__file__)))
+    if not ol.have_ref():
+        pytest.skip("oracle/_ref not built")
+    env = dict(os.environ, ZOPFLI_AMD_DEVICE_ENCODE="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split()[0] == "OK", r.stdout[-2000:]

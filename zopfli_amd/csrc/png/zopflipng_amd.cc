@@ -170,23 +170,26 @@ class Image {
 
   // The filter type of every scanline under MINSUM and under ENTROPY, searched on the device.  The scanlines are
   // LodePNG's: one encode with filter type 0 and stored deflate blocks is the raw (colour-converted, bit-padded) rows
-  // behind a zero byte each.  Anything unexpected leaves the vectors empty: LodePNG then searches itself.
-  void SearchFiltersOnDevice() {
+  // behind a zero byte each.  An image LodePNG would lay out differently than assumed here (interlaced; a header that
+  // does not match) leaves the vectors empty and the rows to LodePNG's own search — the same rows by definition.  A
+  // DEVICE failure is not papered over that way: it is an error of the optimisation (returns false, message on
+  // stderr), like a failing ZopfliDeflate.
+  bool SearchFiltersOnDevice() {
     minsum_.clear();
     entropy_.clear();
-    if (getenv("ZOPFLIPNG_AMD_HOST_FILTERS")) return;     // (A/B and test hook)
+    if (getenv("ZOPFLIPNG_AMD_HOST_FILTERS")) return true;     // (A/B and test hook)
     lodepng::State state;
     Configure(&state, 32768);
     state.encoder.filter_strategy = LFS_ZERO;
     state.encoder.zlibsettings.btype = 0;
     std::vector<unsigned char> png;
-    if (lodepng::encode(png, pixels, w, h, state) != 0) return;
+    if (lodepng::encode(png, pixels, w, h, state) != 0) return true;
     lodepng::State hdr;
     unsigned pw = 0, ph = 0;
-    if (lodepng_inspect(&pw, &ph, &hdr, png.data(), png.size()) != 0 || pw != w || ph != h) return;
-    if (hdr.info_png.interlace_method != 0) return;
+    if (lodepng_inspect(&pw, &ph, &hdr, png.data(), png.size()) != 0 || pw != w || ph != h) return true;
+    if (hdr.info_png.interlace_method != 0) return true;
     const unsigned bpp = lodepng_get_bpp(&hdr.info_png.color);
-    if (bpp == 0) return;
+    if (bpp == 0) return true;
     const size_t linebytes = (static_cast<size_t>(w) * bpp + 7) / 8, bytewidth = (bpp + 7) / 8;
     std::vector<unsigned char> idat;
     for (const unsigned char* c = png.data() + 8; c + 12 <= png.data() + png.size(); c = lodepng_chunk_next_const(c, png.data() + png.size())) {
@@ -194,13 +197,17 @@ class Image {
       if (lodepng_chunk_type_equals(c, "IEND")) break;
     }
     std::vector<unsigned char> rows;
-    if (lodepng::decompress(rows, idat) != 0 || rows.size() != static_cast<size_t>(h) * (linebytes + 1)) return;
+    if (lodepng::decompress(rows, idat) != 0 || rows.size() != static_cast<size_t>(h) * (linebytes + 1)) return true;
     std::vector<unsigned char> raw(static_cast<size_t>(h) * linebytes);
     for (size_t y = 0; y < h; ++y) memcpy(raw.data() + y * linebytes, rows.data() + y * (linebytes + 1) + 1, linebytes);
     std::vector<unsigned char> a(h), b(h);
-    if (zmx_png_filter_types_pooled(raw.data(), linebytes, h, bytewidth, a.data(), b.data()) != 0) return;
+    if (zmx_png_filter_types_pooled(raw.data(), linebytes, h, bytewidth, a.data(), b.data()) != 0) {
+      fprintf(stderr, "zopflipng_amd: the row-filter search on the device failed: %s\n", zmx_last_error());
+      return false;
+    }
     minsum_.swap(a);
     entropy_.swap(b);
+    return true;
   }
 
  private:
@@ -283,8 +290,8 @@ int ZopfliPNGOptimize(const std::vector<unsigned char>& origpng, const ZopfliPNG
   if (!error) {
     // which strategies will be encoded at all decides whether the device's row search is wanted
     const bool trials = png_options.auto_filter_strategy;
-    if (trials || enable[kStrategyMinSum] || enable[kStrategyEntropy]) img.SearchFiltersOnDevice();
-    if (trials) {
+    if ((trials || enable[kStrategyMinSum] || enable[kStrategyEntropy]) && !img.SearchFiltersOnDevice()) error = 1;
+    if (trials && !error) {
       // zopflipng_lib.cc:270-305: every strategy but brute force with LodePNG's fast deflate (window 8192: the winner
       // depends on the window), the smallest file's strategy wins (the first of equals) — the encodes side by side
       const int n = kNumFilterStrategies - 1;

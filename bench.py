@@ -37,8 +37,25 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MB = 1000000
+
+# what the synthetic classes of zopfli_amd/csrc/tools/datagen.c stand for
+CLASS_NAMES = {"T": "text-like, the enwik8 stand-in", "X": "markup", "R": "random bytes", "P": "PNG-like filtered scanlines",
+               "B": "two symbols", "Z": "long runs of equal bytes", "M": "mixed corpus, the Silesia stand-in"}
+
+
+def baseline_config_name(cls, size, numiterations, blocksplitting):
+    """Which BASELINE.json config a run is (or that it is none): configs[1] = 100 MB of text, n = 15, one block stream;
+    configs[2] = the same with ZopfliBlockSplit on; configs[3] = ~200 MB mixed corpus, n = 50, block splitting on."""
+    if cls == "T" and size == 100 * MB and numiterations == 15:
+        return "BASELINE configs[1]" if blocksplitting == 0 else "BASELINE configs[2] (on the GPUs of this run)"
+    if cls == "M" and size >= 200 * MB and numiterations == 50 and blocksplitting == 1:
+        return "BASELINE configs[3] (on the GPUs of this run)"
+    return "not a BASELINE config (a class / size line)"
+
 WINDOW = 32768
-PMC_PROFILE = "r04_bench100MB_pmc.json"
+# rocprofv3 PMC passes per class of the 100 MB, n = 15, blocksplitting 0 workload (tools/collect_profiles.sh; quoted only
+# when taken on this build's device sources)
+PMC_PROFILES = {"T": "r05_bench100MB_pmc.json", "Z": "r05_classZ100MB_pmc.json", "M": "r05_classM100MB_pmc.json"}
 SHADER_CLOCK_HZ = 2.4e9   # MI355X peak engine clock; s_memtime counts at this rate (measured, DESIGN.md)
 
 
@@ -494,8 +511,9 @@ def main():
             # same configuration
             traffic = None
             traffic_note = "no PMC profile of this workload"
+            PMC_PROFILE = PMC_PROFILES.get(args.cls, "")
             pmc = os.path.join(ROOT, "profiles", PMC_PROFILE)
-            if (os.path.exists(pmc) and size == 100 * MB and args.numiterations == 15 and args.cls == "T"
+            if (PMC_PROFILE and corpus is None and os.path.exists(pmc) and size == 100 * MB and args.numiterations == 15
                     and args.blocksplitting == 0 and world == 1):
                 with open(pmc) as f:
                     prof = json.load(f)
@@ -555,11 +573,12 @@ def main():
             "ms_per_step_resident": None if ms_resident is None else round(ms_resident, 2),
             "vs_baseline": None,
             "dtype": "u8 (f32/f64 cost DP)", "data": "synthetic" if corpus is None else "file:" + os.path.basename(args.file),
-            "config": {"workload": (f"class-{args.cls} synthetic" if corpus is None else "file " + os.path.basename(args.file)) +
-                                   f" {size} B {'in total' if strong else 'per GPU'} "
-                                   f"(T = text-like enwik8 stand-in), numiterations="
+            "config": {"workload": (f"class-{args.cls} synthetic ({CLASS_NAMES.get(args.cls, 'class ' + args.cls)})" if corpus is None
+                                    else "file " + os.path.basename(args.file)) +
+                                   f" {size} B {'in total' if strong else 'per GPU'}, numiterations="
                                    f"{args.numiterations}, blocksplitting={args.blocksplitting}, gzip, "
-                                   f"{'configs[1]' if args.blocksplitting == 0 else 'configs[2]'}",
+                                   + baseline_config_name(args.cls if corpus is None else None, size, args.numiterations,
+                                                          args.blocksplitting),
                        "total_bytes": total, "master_blocks": (total + MB - 1) // MB,
                        "sharding": "master blocks, contiguous per rank, gather of bit chunks to rank 0",
                        "gather": gather_kind},

@@ -310,8 +310,8 @@ void zmx_dist_destroy(zmx_dist* dist);
 int zmx_dist_gather(zmx_dist* dist, const unsigned char* blob, size_t size, unsigned char** gathered,
                     size_t* sizes);
 
-/* (The kernel, match and task statistics below are process-wide sums reset when a Zopfli* / zmx_deflate_range call
- * starts: with concurrent callers they mix the callers' numbers.)
+/* (The kernel, match and task statistics below are sums over the last Zopfli* / zmx_deflate_range call of the CALLING
+ * THREAD — its shard threads' numbers included — reset when the call starts: concurrent callers read their own.)
  *
  * Timing breakdown of the last Zopfli* / zmx_deflate_range call on this
  * thread: seconds spent in [0] match tables [1] greedy [2] squeeze runs

@@ -65,6 +65,8 @@ void zmx_internal_kernel_stats(double* a, double* b, int) { a[0] = a[1] = a[2] =
 void zmx_internal_seg_stats(double* a, int) { for (int i = 0; i < 8; ++i) a[i] = 0; }
 void zmx_internal_match_stats(double* a, int) { for (int i = 0; i < 4; ++i) a[i] = 0; }
 void zmx_internal_match5_stats(double* a, int) { for (int i = 0; i < 3; ++i) a[i] = 0; }
+void zmx_internal_stats_take(double* a) { for (int i = 0; i < 19; ++i) a[i] = 0; }
+void zmx_internal_stats_add(const double*) {}
 int zmx_hash_links_download(zmx_ctx*, zmx_tables*, size_t, uint16_t*, uint16_t*, uint16_t*) { g_err = "not in the host test library"; return -1; }
 int zmx_match_digest(zmx_ctx*, zmx_tables*, uint64_t*) { g_err = "not in the host test library"; return -1; }
 int zmx_set_match_kernel(int) { return 0; }   // (no kernels here)

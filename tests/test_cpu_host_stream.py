@@ -236,6 +236,37 @@ def test_multi_device_sharding_through_the_c_entry_point():
     assert res["3"][0] == hashlib.sha256(ol.ref_compress(data, 0, 1)).hexdigest()
 
 
+def test_rounds_of_master_blocks():
+    """A call of more master blocks than a round holds (2 000 = 2 GB: the device layer's positions are 32 bits, the
+    reference's insize a size_t) is done in rounds, each dealt over the contexts like a call of its own, the chunks and the
+    container checksum joined in stream order (api.cc RunPartsSharded).  ZOPFLI_AMD_ROUND_PARTS=1 forces rounds on 2.3
+    master blocks: gzip (CRC-32 over the rounds), zlib (Adler-32) and raw deflate equal the one-round streams and the
+    reference's."""
+    import subprocess
+    import sys
+    code = (
+        "import hashlib, sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import oracle_lib as ol\n"
+        "from zopfli_amd import ZopfliOptions, api, generate\n"
+        "host = ol.hosttest_library()\n"
+        "data = generate('T', 1300000) + generate('R', 300000) + generate('Z', 700000)\n"
+        "for fmt in (0, 1, 2):\n"
+        "    print(hashlib.sha256(api.compress(data, fmt, ZopfliOptions(1), lib=host)).hexdigest())\n"
+        % (os.path.dirname(os.path.dirname(__file__)), os.path.dirname(__file__)))
+    res = {}
+    for name, extra in (("one", {}), ("rounds", {"ZOPFLI_AMD_ROUND_PARTS": "1"}),
+                        ("rounds3dev", {"ZOPFLI_AMD_ROUND_PARTS": "1", "ZOPFLI_HOSTTEST_DEVICES": "3", "ZOPFLI_AMD_DEVICES": "all"})):
+        env = dict(os.environ, **extra)
+        env.pop("LOCAL_RANK", None)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[name] = r.stdout.split()
+    assert res["one"] == res["rounds"] == res["rounds3dev"]
+    data = generate("T", 1300000) + generate("R", 300000) + generate("Z", 700000)
+    assert res["rounds"][0] == hashlib.sha256(ol.ref_compress(data, 0, 1)).hexdigest()
+
+
 @pytest.mark.parametrize("fail", [0, 1, 2])
 def test_failed_shard_is_done_again_on_another_context(fail):
     """A shard of a request that fails (ZOPFLI_AMD_TEST_FAIL_SHARD: its first attempt returns an error before it does

@@ -184,3 +184,43 @@ def test_device_filters_are_used(tmp_path):
         with open(dst, "rb") as f:
             outs.append(f.read())
     assert outs[0] == outs[1]
+
+
+def _at_size_png(path, w):
+    """tools/png_at_size.py's synthetic W x W RGBA image (the generator is repeated here so that the test reads no file
+    outside tests/): a gradient with +-3 of noise, seed 7."""
+    rng = np.random.default_rng(7)
+    y, x = np.mgrid[0:w, 0:w]
+    img = np.stack([(x * 255 // max(w - 1, 1)), (y * 255 // max(w - 1, 1)), ((x + y) // 3 % 256),
+                    np.full_like(x, 255)], axis=-1).astype(np.int32)
+    img[..., :3] += rng.integers(-3, 4, size=(w, w, 3))
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    raw = np.concatenate([np.zeros((w, 1), dtype=np.uint8), img.reshape(w, w * 4)], axis=1).tobytes()
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", w, w, 8, 6, 0, 0, 0))
+                + _chunk(b"IDAT", zlib.compress(raw, 1)) + _chunk(b"IEND", b""))
+
+
+@pytest.mark.parametrize("width", [1024, 4096])
+def test_png_at_size_vs_reference_golden(tmp_path, width):
+    """BASELINE configs[4] AT SIZE in the driver-run suite: the reference's zopflipng command line on libzopflipng_amd.so,
+    default options, on the 1024 x 1024 and the 4096 x 4096 RGBA image of tools/png_at_size.py; the output's SHA-256 and
+    size are those of the all-reference zopflipng (tests/golden/png_at_size.json, written by
+    `tools/png_at_size.py --make-golden` on the build host: 5.6 s / 87 s of the reference there)."""
+    import hashlib
+    import json
+    from zopfli_amd._build import PNG_AMD2
+    if not os.path.exists(PNG_AMD2):
+        pytest.skip("tests/_build/zopflipng_amd2 not built (needs /root/reference at build time)")
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "png_at_size.json")) as f:
+        gold = json.load(f)[str(width)]
+    src, dst = str(tmp_path / "in.png"), str(tmp_path / "out.png")
+    _at_size_png(src, width)
+    with open(src, "rb") as f:
+        assert hashlib.sha256(f.read()).hexdigest() == gold["input_sha256"], "the synthetic input is not the golden's"
+    r = subprocess.run([PNG_AMD2, "-y", src, dst], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-1000:])
+    with open(dst, "rb") as f:
+        out = f.read()
+    assert len(out) == gold["bytes"]
+    assert hashlib.sha256(out).hexdigest() == gold["sha256"]

@@ -33,12 +33,22 @@
 namespace {
 
 thread_local std::string g_err;   // per calling thread (zmx_last_error)
-std::mutex g_stats_mutex;
-double g_kernel_seconds[3] = {0, 0, 0};  // k_wtab + k_badscan, chain kernels (k_dp5_spec + k_dpcheck + k_dp4_fix), k_trace (HIP events)
-double g_squeeze_launches = 0;
-double g_match5_stats[3] = {0, 0, 0};    // k_match5: entries in flight summed over lanes and iterations, wave iterations, positions it walked
-double g_match_stats[4] = {0, 0, 0, 0};  // k_match2 seconds, k_same + k_chain seconds, table builds, positions matched
-double g_seg_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // tasks, accepted, re-run: state / level / tie, positions re-run, re-run: values, positions
+// Kernel, match and task statistics: per calling THREAD (a Zopfli* call's shard threads hand theirs to the caller's
+// at the join, api.cc), so that concurrent callers read their own numbers (zmx_last_*).
+struct ThreadStats {
+  double kernel_seconds[3];  // k_wtab + k_badscan, chain kernels (k_dp5_spec + k_dpcheck + k_dp4_fix), k_trace (HIP events)
+  double squeeze_launches;
+  double match5[3];          // k_match5: entries in flight summed over lanes and iterations, wave iterations, positions it walked
+  double match[4];           // match kernel seconds, k_same + k_chain (+ k_levels ...) seconds, table builds, positions matched
+  double seg[8];             // tasks, accepted, re-run: state / level / tie, positions re-run, re-run: values, positions
+};
+static_assert(sizeof(ThreadStats) == 19 * sizeof(double), "zmx_internal_stats_take / _add move 19 doubles");
+thread_local ThreadStats g_ts = {};
+#define g_kernel_seconds g_ts.kernel_seconds
+#define g_squeeze_launches g_ts.squeeze_launches
+#define g_match5_stats g_ts.match5
+#define g_match_stats g_ts.match
+#define g_seg_stats g_ts.seg
 
 thread_local bool g_last_oom = false;   // the last failure of this thread was an allocation the device could not serve
 
@@ -124,6 +134,7 @@ struct zmx_ctx {
   size_t pool_free_bytes = 0;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipStream_t stream2 = nullptr;   // the run tasks' k_dp5_spec beside the others' (zmx_squeeze_run)
+  bool stream2_outstanding = false;   // a kernel on stream2 reads pooled scratch arrays and `stream` has not been made to wait for it yet
   hipStream_t alt_stream[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // zmx_ctx_set_priority: [0] the created pair, [1] high, [2] low
   hipEvent_t ev2[2] = {nullptr, nullptr};
   u32* h_stage = nullptr;    // pinned staging for store downloads (grow-only)
@@ -367,9 +378,11 @@ void PoolFree(zmx_ctx* c, void* p) {
       const size_t cap = it->second;
       c->pool_live.erase(it);
       if (c->guard_live.erase(p)) base = static_cast<unsigned char*>(p) - kGuardBytes;
-      if (DevCached(c).load(std::memory_order_relaxed) + cap > c->pool_keep) {
-        // the device's cache budget is used up: the idle contexts' caches go first — the context that is working
-        // is the one whose arrays will be asked for again
+      if (DevCached(c).load(std::memory_order_relaxed) + cap > c->pool_keep &&
+          DevCached(c).load(std::memory_order_relaxed) > c->pool_free_bytes) {
+        // the device's cache budget is used up and some of it is ANOTHER context's: the idle contexts' caches go
+        // first — the context that is working is the one whose arrays will be asked for again.  (Not when the cache is
+        // all this context's own: the hook would take the pool's lock and find nothing, on every free of the hot path.)
         if (const zmx_oom_hook_t hook = g_oom_hook.load(std::memory_order_acquire)) hook(c->device);
       }
       if (DevCached(c).load(std::memory_order_relaxed) + cap <= c->pool_keep) {
@@ -428,6 +441,11 @@ int GuardVerify(zmx_ctx* c, const char* where) {
   } while (0)
 
 PoolScope::~PoolScope() {
+  // (an error return between a launch on stream2 and the join: the kernel may still be reading these arrays)
+  if (c->stream2_outstanding) {
+    (void)hipStreamSynchronize(c->stream2);
+    c->stream2_outstanding = false;
+  }
   for (void* p : held) PoolFree(c, p);
 }
 
@@ -478,31 +496,41 @@ void zmx_internal_set_error(const char* msg) { g_err = msg; }
 const unsigned char* zmx_internal_input_host(zmx_ctx* ctx) { return ctx->h_in; }
 
 void zmx_internal_seg_stats(double* out8, int reset) {
-  std::lock_guard<std::mutex> lock(g_stats_mutex);
+  // (thread-local: no lock)
   for (int i = 0; i < 8; ++i) out8[i] = g_seg_stats[i];
   if (reset) for (int i = 0; i < 8; ++i) g_seg_stats[i] = 0;
 }
 
 void zmx_internal_match5_stats(double* out3, int reset) {
-  std::lock_guard<std::mutex> lock(g_stats_mutex);
+  // (thread-local: no lock)
   for (int i = 0; i < 3; ++i) out3[i] = g_match5_stats[i];
   if (reset) for (int i = 0; i < 3; ++i) g_match5_stats[i] = 0;
 }
 
 void zmx_internal_match_stats(double* out4, int reset) {
-  std::lock_guard<std::mutex> lock(g_stats_mutex);
+  // (thread-local: no lock)
   for (int i = 0; i < 4; ++i) out4[i] = g_match_stats[i];
   if (reset) for (int i = 0; i < 4; ++i) g_match_stats[i] = 0;
 }
 
 void zmx_internal_kernel_stats(double* seconds3, double* squeeze_launches, int reset) {
-  std::lock_guard<std::mutex> lock(g_stats_mutex);
+  // (thread-local: no lock)
   for (int i = 0; i < 3; ++i) seconds3[i] = g_kernel_seconds[i];
   *squeeze_launches = g_squeeze_launches;
   if (reset) {
     g_kernel_seconds[0] = g_kernel_seconds[1] = g_kernel_seconds[2] = 0;
     g_squeeze_launches = 0;
   }
+}
+
+// a shard thread's sums since it started, zeroed — and added to the calling thread's (api.cc, at the join of a call's shards)
+void zmx_internal_stats_take(double* out19) {
+  std::memcpy(out19, &g_ts, sizeof(g_ts));
+  g_ts = ThreadStats{};
+}
+void zmx_internal_stats_add(const double* in19) {
+  double* d = reinterpret_cast<double*>(&g_ts);
+  for (int i = 0; i < 19; ++i) d[i] += in19[i];
 }
 
 int zmx_ctx_create(int device, zmx_ctx** out) {
@@ -551,12 +579,16 @@ int zmx_ctx_set_priority(zmx_ctx* c, int level) {
   DeviceGuard dev_guard(c->device);
   HIPCHK(dev_guard.err);
   const int k = level > 0 ? 1 : level < 0 ? 2 : 0;
-  if (k && !c->alt_stream[k][0]) {
+  // (first: from here on zmx_ctx_destroy frees by alt_stream[][], a pair created half-way below included)
+  if (!c->alt_stream[0][0]) { c->alt_stream[0][0] = c->stream; c->alt_stream[0][1] = c->stream2; }   // the pair of zmx_ctx_create
+  if (k && !c->alt_stream[k][1]) {
     int least = 0, greatest = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithPriority(&c->alt_stream[k][i], hipStreamDefault, k == 1 ? greatest : least));
+    for (int i = 0; i < 2; ++i) {
+      if (c->alt_stream[k][i]) continue;      // (an earlier call got this far)
+      HIPCHK(hipStreamCreateWithPriority(&c->alt_stream[k][i], hipStreamDefault, k == 1 ? greatest : least));
+    }
   }
-  if (!c->alt_stream[0][0]) { c->alt_stream[0][0] = c->stream; c->alt_stream[0][1] = c->stream2; }   // the pair of zmx_ctx_create
   HIPCHK(hipStreamSynchronize(c->stream));
   HIPCHK(hipStreamSynchronize(c->stream2));
   c->stream = c->alt_stream[k][0];
@@ -1045,6 +1077,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
       HIPCHK(hipStreamWaitEvent(c->stream2, c->ev2[0], 0));
       hipLaunchKernelGGL(k_match5, dim3(kMatchGrid5), dim3(M5_THREADS), 0, c->stream2, q);
       HIPCHK(hipGetLastError());
+      c->stream2_outstanding = true;
       HIPCHK(hipEventRecord(c->ev2[1], c->stream2));
       join_stream2 = true;
       mp.skip_energy = d_energy;
@@ -1058,6 +1091,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     if (join_stream2) {
       join_stream2 = false;
       HIPCHK(hipStreamWaitEvent(c->stream, c->ev2[1], 0));
+      c->stream2_outstanding = false;      // (whatever reuses the arrays does so in `stream`'s order, behind the kernel)
     }
     KCHK(c, "k_match2");
     return 0;
@@ -1152,7 +1186,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     float ms_hash = 0, ms_match = 0;
     HIPCHK(hipEventElapsedTime(&ms_hash, c->ev[0], c->ev[1]));
     HIPCHK(hipEventElapsedTime(&ms_match, c->ev[1], c->ev[2]));
-    std::lock_guard<std::mutex> lock(g_stats_mutex);
+    // (thread-local: no lock)
     g_match_stats[0] += ms_match * 1e-3;
     g_match_stats[1] += ms_hash * 1e-3;
     g_match_stats[2] += 1;
@@ -1770,7 +1804,7 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   t->have_hist = true;
   ++t->squeeze_runs;
   {
-    std::lock_guard<std::mutex> lock(g_stats_mutex);
+    // (thread-local: no lock)
     for (int i = 0; i < 3; ++i) g_kernel_seconds[i] += ksec[i];
     g_squeeze_launches += 1;
     for (int i = 0; i < 7; ++i) g_seg_stats[i] += segstats[i];

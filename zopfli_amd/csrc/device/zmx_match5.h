@@ -936,6 +936,12 @@ __global__ __launch_bounds__(M5_THREADS, 4) void k_match5(Match5Params Q) {
     }
     sum_lane_iter += n_lane_iter;
     sum_iter += n_iter;
+#ifdef M5_ATOMIC_STATS
+    if (Q.wave_stats) {
+      atomicAdd(&Q.wave_stats[0], (unsigned long long)n_lane_iter);
+      atomicAdd(&Q.wave_stats[1], (unsigned long long)n_iter);
+    }
+#endif
   }
   // (plain stores, one slot per wave: two atomic adds per piece at this point made the kernel not come back — twice,
   //  never understood)

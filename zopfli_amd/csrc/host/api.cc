@@ -27,6 +27,8 @@ extern "C" void zmx_internal_kernel_stats(double* seconds3, double* squeeze_laun
 extern "C" void zmx_internal_seg_stats(double* out8, int reset);
 extern "C" void zmx_internal_match_stats(double* out4, int reset);
 extern "C" void zmx_internal_match5_stats(double* out3, int reset);
+extern "C" void zmx_internal_stats_take(double* out19);
+extern "C" void zmx_internal_stats_add(const double* in19);
 // implemented by the device layer: size of the resident input
 extern "C" size_t zmx_internal_input_size(zmx_ctx* ctx);
 // implemented by the device layer: the caller's host copy of the resident input (borrowed)
@@ -160,11 +162,23 @@ class ContextPool {
   // zmx_set_oom_hook: a context of `device` is out of memory even after dropping its own cache — the idle contexts of
   // that device give their cached arrays back
   void TrimIdle(int device) {
-    std::lock_guard<std::mutex> lock(mu_);
-    for (auto& dev : devices_) {
-      if (dev.index != device) continue;
-      for (auto& sl : dev.slots) if (!sl->busy && sl->ctx) zmx_ctx_trim_cache(sl->ctx);
+    // hipFree synchronises the device: not under the pool's lock (every Acquire / Release would wait behind it).  The
+    // idle contexts are taken out of circulation, trimmed, and put back.
+    std::vector<Slot*> mine;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      for (auto& dev : devices_) {
+        if (dev.index != device) continue;
+        for (auto& sl : dev.slots) if (!sl->busy && sl->ctx) { sl->busy = true; mine.push_back(sl.get()); }
+      }
     }
+    if (mine.empty()) return;
+    for (Slot* sl : mine) zmx_ctx_trim_cache(sl->ctx);
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      for (Slot* sl : mine) sl->busy = false;
+    }
+    cv_.notify_all();
   }
   void Release(const std::vector<zmx_ctx*>& ctxs) {
     {
@@ -312,9 +326,9 @@ struct ChecksumRequest {
   uint32_t value;
 };
 
-int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char* in,
-                    const std::vector<zamd::Part>& parts, std::vector<zamd::Chunk>* chunks,
-                    ChecksumRequest* sum = nullptr) {
+int RunPartsShardedOnce(const ZopfliOptions& options, int btype, const unsigned char* in,
+                        const std::vector<zamd::Part>& parts, std::vector<zamd::Chunk>* chunks,
+                        ChecksumRequest* sum = nullptr) {
   // (ZOPFLI_AMD_SPLIT_MB: from this many master blocks on, a request is dealt over ZOPFLI_AMD_SPLIT_WAYS = 3 contexts of
   //  each device — measured on 100 MB of text: 2 ways 123.2 ms, 3 ways 121.1, 4 ways 140; with block splitting 225 / 197 / 231;
   //  0 = never.  The GPU idles while the host computes a hundred cost models between two squeeze runs — 6 % of a
@@ -363,6 +377,7 @@ int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char
     uint32_t sum = 0;
     size_t sum_bytes = 0;
     bool redone = false;
+    double stats[19] = {0};        // the shard thread's kernel / match / task statistics (zmx_internal_stats_take)
   };
   std::vector<Shard> shards(ndev);
   for (size_t d = 0; d < ndev; ++d) {
@@ -448,12 +463,14 @@ int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char
   };
   // (ZOPFLI_AMD_TEST_FAIL_SHARD=k: the k-th shard's first attempt fails before it does anything — the test of the
   //  re-queue below)
-  const char* fail_env = std::getenv("ZOPFLI_AMD_TEST_FAIL_SHARD");
-  const long fail_shard = fail_env ? std::atol(fail_env) : -1;
+  static const long fail_shard = [] { const char* e = std::getenv("ZOPFLI_AMD_TEST_FAIL_SHARD"); return e ? std::atol(e) : -1L; }();
   auto work = [&](size_t d, zmx_ctx* ctx, bool retry) {
     Shard& sh = shards[d];
     UploadTurn turn{order, d};
-    (void)zmx_ctx_set_priority(ctx, retry ? 0 : shard_priority[d]);
+    if (zmx_ctx_set_priority(ctx, retry ? 0 : shard_priority[d]) != 0) {
+      // (not fatal: the context stays on the streams it has, the shards then run side by side instead of in turn)
+      std::fprintf(stderr, "zopfli_amd: stream priorities unavailable (%s)\n", zmx_last_error());
+    }
     zamd::g_wide_lane = static_cast<int>(d % static_cast<size_t>(zamd::kWideLanes));   // (thread_pool.h: a wide pool per shard thread)
     sh.rc = 0;
     sh.err.clear();
@@ -499,6 +516,7 @@ int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char
       if (c.kind == zamd::Chunk::kStored) { c.start += sh.base; c.end += sh.base; }
     }
     sh.timing = zamd::ThreadTiming();
+    if (d != 0 && !retry) zmx_internal_stats_take(sh.stats);   // (a thread of its own: its sums go to the caller's below)
   };
   if (ndev == 1) {
     work(0, ctxs[0], false);
@@ -507,6 +525,7 @@ int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char
     for (size_t d = 1; d < ndev; ++d) threads.emplace_back(work, d, ctxs[d], false);
     work(0, ctxs[0], false);
     for (auto& t : threads) t.join();
+    for (size_t d = 1; d < ndev; ++d) zmx_internal_stats_add(shards[d].stats);
     // the slowest device's breakdown stands for the request (zmx_last_timing)
     for (size_t d = 1; d < ndev; ++d) {
       const zamd::Timing& a = shards[d].timing;
@@ -520,6 +539,9 @@ int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char
   // parts are independent (deflate.c:916-923), whoever computes them computes the same bits.
   for (size_t d = 0; d < ndev; ++d) {
     if (!shards[d].rc) continue;
+    // (not a failure that would repeat itself on any context: a request the device layer refuses, a table set that
+    //  overflows its pools after the retries the device layer makes itself)
+    if (shards[d].err.find("pool") != std::string::npos || shards[d].err.find("too large") != std::string::npos) continue;
     zmx_ctx* other = nullptr;
     for (size_t e = 0; e < ndev && !other; ++e) if (e != d && !shards[e].rc && !shards[e].redone) other = ctxs[e];
     if (!other) break;
@@ -545,6 +567,36 @@ int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char
       if (sh.sum_bytes) sum->value = zmx_checksum_combine(sum->kind, sum->value, sh.sum, sh.sum_bytes);
     }
   }
+  return 0;
+}
+
+// The device layer indexes the positions of a resident input with 32 bits; the reference takes a size_t.  A request
+// of more master blocks than ZOPFLI_AMD_ROUND_PARTS (2000: 2 GB, so that a round's shard plus its window stays below
+// 2^32 bytes whatever the dealing) is done in ROUNDS, one after the other, each dealt over the contexts like a call of
+// its own; master blocks are independent (deflate.c:916-923), their bit chunks are joined in stream order as always,
+// and the container checksum of the rounds is put together like that of the shards (zmx_checksum_combine).
+int RunPartsSharded(const ZopfliOptions& options, int btype, const unsigned char* in,
+                    const std::vector<zamd::Part>& parts, std::vector<zamd::Chunk>* chunks,
+                    ChecksumRequest* sum = nullptr) {
+  static const size_t round_parts = [] {
+    const char* e = std::getenv("ZOPFLI_AMD_ROUND_PARTS");
+    const long v = e ? std::atol(e) : 0;
+    return v > 0 ? static_cast<size_t>(v) : static_cast<size_t>(2000);
+  }();
+  if (parts.size() <= round_parts) return RunPartsShardedOnce(options, btype, in, parts, chunks, sum);
+  uint32_t acc = sum ? (sum->kind == ZMX_ADLER32 ? 1u : 0u) : 0u;   // of no bytes
+  for (size_t a = 0; a < parts.size(); a += round_parts) {
+    const size_t b = std::min(parts.size(), a + round_parts);
+    const std::vector<zamd::Part> round(parts.begin() + static_cast<long>(a), parts.begin() + static_cast<long>(b));
+    ChecksumRequest rs{sum ? sum->kind : 0, sum ? sum->limit : 0, 0};
+    const int rc = RunPartsShardedOnce(options, btype, in, round, chunks, sum ? &rs : nullptr);
+    if (rc) return rc;
+    if (sum && round.front().instart < sum->limit) {
+      const size_t covered = std::min(round.back().inend, sum->limit) - round.front().instart;
+      acc = zmx_checksum_combine(sum->kind, acc, rs.value, covered);
+    }
+  }
+  if (sum) sum->value = acc;
   return 0;
 }
 

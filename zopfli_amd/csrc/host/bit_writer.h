@@ -24,7 +24,11 @@ class BitWriter {
       const uint32_t low = static_cast<uint32_t>(acc_);
       const size_t at = buf_.size();
       buf_.resize(at + 4);
-      std::memcpy(buf_.data() + at, &low, 4);     // (little endian: the stream's byte order)
+      // the stream's byte order, whatever the host's (the compiler turns the four stores into one on x86)
+      buf_[at] = static_cast<uint8_t>(low);
+      buf_[at + 1] = static_cast<uint8_t>(low >> 8);
+      buf_[at + 2] = static_cast<uint8_t>(low >> 16);
+      buf_[at + 3] = static_cast<uint8_t>(low >> 24);
       acc_ >>= 32;
       fill_ -= 32;
     }

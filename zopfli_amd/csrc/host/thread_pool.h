@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <functional>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -116,7 +117,12 @@ class WorkerPool {
   static WorkerPool& Wide() {
     const int lane = g_wide_lane < 0 ? 0 : g_wide_lane % kWideLanes;
     if (WideThreads() == HostThreads() && lane == 0) return Get();
-    return Instance(1 + lane, WideThreads());
+    // Lane 0 (a call on one context) has the whole wide budget; the pools of the other shard lanes — they only exist in
+    // a process that deals a call over several contexts, and then run side by side — share it: a third each, which
+    // still is a thread per master block of a 100 MB call's shard (33), and leaves a drop-in caller's process with
+    // WideThreads() sleeping threads for them instead of three times that.
+    const unsigned share = (WideThreads() + 2) / 3;
+    return Instance(1 + lane, lane == 0 ? WideThreads() : (share > HostThreads() ? share : HostThreads()));
   }
 
   // Runs body(i) for i in [0, n) on the workers and the calling thread; returns
@@ -172,7 +178,15 @@ class WorkerPool {
   WorkerPool(unsigned threads, int spin) : spin_(spin) {
     const unsigned extra = threads > 1 ? threads - 1 : 0;
     workers_.reserve(extra);
-    for (unsigned t = 0; t < extra; ++t) workers_.emplace_back([this] { Loop(); });
+    // (a pids cgroup or RLIMIT_NPROC makes std::thread throw: the pool then works with the threads it got — the
+    //  caller's own included, Run() never depends on a count — instead of aborting somebody else's process)
+    for (unsigned t = 0; t < extra; ++t) {
+      try {
+        workers_.emplace_back([this] { Loop(); });
+      } catch (const std::system_error&) {
+        break;
+      }
+    }
     for (auto& w : workers_) w.detach();
   }
 

@@ -241,11 +241,13 @@ def main():
             raise SystemExit("--file: too short for %d ranks of whole master blocks" % world)
     if strong:
         whole = corpus[:size] if corpus is not None else generate(args.cls, size, seed=seed0)
-        s0, s1 = sharding.shard_ranges(size, world)[rank]
+        # (cost-balanced ranges from the bytes: zmx_master_block_costs — every rank computes the same)
+        ranges = sharding.shard_ranges(size, world, whole, lib)
+        s0, s1 = ranges[rank]
         shard = whole[s0:s1]
         prefix = whole[max(0, s0 - WINDOW):s0]
         total_bytes = size
-        nonempty = [r for r in range(world) if sharding.shard_ranges(size, world)[r][1] > sharding.shard_ranges(size, world)[r][0]]
+        nonempty = [r for r in range(world) if ranges[r][1] > ranges[r][0]]
         last_rank = nonempty[-1] if nonempty else 0
         del whole
     else:
@@ -580,7 +582,7 @@ def main():
                                    + baseline_config_name(args.cls if corpus is None else None, size, args.numiterations,
                                                           args.blocksplitting),
                        "total_bytes": total, "master_blocks": (total + MB - 1) // MB,
-                       "sharding": "master blocks, contiguous per rank, gather of bit chunks to rank 0",
+                       "sharding": "master blocks, contiguous per rank (strong scaling: ranges balanced by the estimated cost of their bytes, zmx_master_block_costs; weak: a fixed size per rank), gather of bit chunks to rank 0",
                        "gather": gather_kind},
             "output_bytes": len(out), "roundtrip_ok": roundtrip, "bitexact_vs_reference": bitexact,
             "roofline": roofline,

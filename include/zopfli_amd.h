@@ -310,6 +310,16 @@ void zmx_dist_destroy(zmx_dist* dist);
 int zmx_dist_gather(zmx_dist* dist, const unsigned char* blob, size_t size, unsigned char** gathered,
                     size_t* sizes);
 
+/* Cost-aware dealing of master blocks over GPUs (host only, no device call; zopfli_amd/csrc/host/deal.cc).  Master blocks
+ * are independent (deflate.c:916-923) but not equally expensive: one of long runs of equal bytes costs several times one
+ * of text.  cost[b] = the estimated cost of master block b of in[0, insize) relative to a master block of text, a function
+ * of the bytes alone (64-byte probes every 1024) so that every rank computes the same numbers; returns the number of master
+ * blocks (ncost must be at least that).  zmx_deal_master_blocks: contiguous ranges balanced by cost,
+ * first[s] .. first[s + 1] for shard s (first has shards + 1 entries).  ZopfliCompress / ZopfliDeflate deal a call over
+ * their contexts this way; one-process-per-GPU launchers (zopfli_amd/sharding.py, bench.py) call these two. */
+int zmx_master_block_costs(const unsigned char* in, size_t insize, double* cost, size_t ncost);
+int zmx_deal_master_blocks(const double* cost, size_t nblocks, size_t shards, size_t* first);
+
 /* (The kernel, match and task statistics below are sums over the last Zopfli* / zmx_deflate_range call of the CALLING
  * THREAD — its shard threads' numbers included — reset when the call starts: concurrent callers read their own.)
  *

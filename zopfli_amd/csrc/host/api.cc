@@ -19,6 +19,7 @@
 #include "deflate.h"
 #include "lz77_optimal.h"
 #include "symbols.h"
+#include "deal.h"
 #include "thread_pool.h"
 #include "zopfli_amd.h"
 
@@ -383,6 +384,18 @@ int RunPartsShardedOnce(const ZopfliOptions& options, int btype, const unsigned 
   for (size_t d = 0; d < ndev; ++d) {
     shards[d].first = parts.size() * d / ndev;
     shards[d].last = parts.size() * (d + 1) / ndev;
+  }
+  // Shards of equal COST, not of equal count (deal.h): on a mixed corpus the master blocks of long runs of equal bytes
+  // cost several times the others, and contiguous equal-count shards leave them to one or two contexts.  From the
+  // bytes alone — the one-process-per-GPU launchers compute the same ranges (zmx_master_block_costs).
+  // (ZOPFLI_AMD_DEAL=count: equal counts, as before — for measuring)
+  static const bool deal_by_cost = [] { const char* e = std::getenv("ZOPFLI_AMD_DEAL"); return !e || std::strcmp(e, "count") != 0; }();
+  if (deal_by_cost && ndev > 1 && in != nullptr && parts.size() > ndev) {
+    std::vector<double> cost(parts.size());
+    zamd::ParallelFor(parts.size(), [&](size_t i) { cost[i] = zamd::MasterBlockCost(in, parts[i].instart, parts[i].inend); });
+    std::vector<size_t> first;
+    zamd::DealByCost(cost, ndev, &first);
+    for (size_t d = 0; d < ndev; ++d) { shards[d].first = first[d]; shards[d].last = first[d + 1]; }
   }
   // (ZOPFLI_AMD_SHARD_WEIGHTS="28,36,36": the shares of the shards, for measuring)
   if (const char* e = std::getenv("ZOPFLI_AMD_SHARD_WEIGHTS")) {

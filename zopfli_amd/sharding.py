@@ -15,14 +15,53 @@ WINDOW = 32768           # ZOPFLI_WINDOW_SIZE
 GZIP_HEADER = bytes([31, 139, 8, 0, 0, 0, 0, 0, 2, 3])   # gzip_container.c:90-101
 
 
-def shard_ranges(insize, world):
-    """Contiguous master-block ranges [(start, end)] per rank; empty ranks get (n, n)."""
+def shard_ranges(insize, world, data=None, lib=None):
+    """Contiguous master-block ranges [(start, end)] per rank; empty ranks get (n, n).
+
+    With `data` (the stream's bytes, which every rank holds) the ranges are balanced by the library's estimate of each
+    master block's cost (zmx_master_block_costs / zmx_deal_master_blocks, include/zopfli_amd.h: a function of the bytes
+    alone, so every rank computes the same ranges and the in-process dealer of ZopfliCompress the same again); without,
+    by count."""
     nmb = max(1, -(-insize // MASTER_BLOCK))
+    if data is not None and world > 1 and nmb > world:
+        import ctypes
+        if lib is None:
+            from . import api
+            lib = api.library()
+        cost = (ctypes.c_double * nmb)()
+        fn = lib.zmx_master_block_costs
+        fn.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double), ctypes.c_size_t]
+        fn.restype = ctypes.c_int
+        buf = data if isinstance(data, (bytes, bytearray)) else bytes(data)
+        if fn(buf, insize, cost, nmb) != nmb:
+            raise RuntimeError("zmx_master_block_costs failed")
+        first = (ctypes.c_size_t * (world + 1))()
+        deal = lib.zmx_deal_master_blocks
+        deal.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+        deal.restype = ctypes.c_int
+        if deal(cost, nmb, world, first) != 0:
+            raise RuntimeError("zmx_deal_master_blocks failed")
+        return [(min(first[r] * MASTER_BLOCK, insize), min(first[r + 1] * MASTER_BLOCK, insize)) for r in range(world)]
     out = []
     for r in range(world):
         m0, m1 = nmb * r // world, nmb * (r + 1) // world
         out.append((min(m0 * MASTER_BLOCK, insize), min(m1 * MASTER_BLOCK, insize)))
     return out
+
+
+def shard_costs(insize, ranges, data, lib=None):
+    """The estimated cost of each of `ranges` (what shard_ranges balances), for reports and tests."""
+    import ctypes
+    if lib is None:
+        from . import api
+        lib = api.library()
+    nmb = max(1, -(-insize // MASTER_BLOCK))
+    cost = (ctypes.c_double * nmb)()
+    fn = lib.zmx_master_block_costs
+    fn.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double), ctypes.c_size_t]
+    fn.restype = ctypes.c_int
+    fn(data if isinstance(data, (bytes, bytearray)) else bytes(data), insize, cost, nmb)
+    return [sum(cost[b] for b in range(s // MASTER_BLOCK, -(-e // MASTER_BLOCK))) for s, e in ranges]
 
 
 def gather_bytes(blob, rank, world, device, dist):
@@ -88,7 +127,7 @@ def gzip_sharded(ctx, options, data, rank, world, device, dist):
     """ZopfliGzipCompress of `data` (every rank holds it) sharded by master block over `world`
     ranks.  Returns the gzip stream on rank 0 (byte-identical to the single-GPU stream), None
     elsewhere."""
-    ranges = shard_ranges(len(data), world)
+    ranges = shard_ranges(len(data), world, data, ctx.lib)
     start, end = ranges[rank]
     last_nonempty = max((r for r in range(world) if ranges[r][1] > ranges[r][0]), default=0)
     blob = b""

@@ -133,7 +133,7 @@ def test_cost_aware_ranges_agree_and_balance(world):
     block = sharding.shard_costs(n, [(b, min(n, b + sharding.MASTER_BLOCK)) for b in range(0, n, sharding.MASTER_BLOCK)], data, lib)
     assert max(cost) <= mean + max(block)          # what a prefix walk guarantees at any granularity
     by_count = sharding.shard_costs(n, sharding.shard_ranges(n, world), data, lib)
-    assert max(by_count) > 1.2 * mean, by_count
+    assert max(by_count) > max(cost) + 1.0, (by_count, cost)     # equal counts are off by more than a master block of text
 
 
 def test_deal_edge_cases():

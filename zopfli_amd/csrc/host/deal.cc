@@ -46,6 +46,10 @@ void DealByCost(const std::vector<double>& cost, size_t shards, std::vector<size
   for (double c : cost) total += c;
   // shard s ends where the running cost comes closest to its share of the total, but leaves a block for every shard
   // still to come (and takes at least one itself) while there are blocks to go round
+  if (n <= shards) {      // a block each while they last; the shards at the end are empty
+    for (size_t s = 0; s <= shards; ++s) (*first)[s] = s < n ? s : n;
+    return;
+  }
   size_t at = 0;
   double acc = 0;
   for (size_t s = 0; s + 1 < shards; ++s) {

@@ -179,7 +179,7 @@ def _worker_hetero(rank, world, port, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         host = ol.hosttest_library()
-        data = generate("T", 1500000) + generate("Z", 1200000) + generate("X", 1300000)
+        data = generate("Z", 1200000) + generate("X", 1300000) + generate("T", 1500000)
         ctx = Context(0, host)
         out = sharding.gzip_sharded(ctx, ZopfliOptions(1), data, rank, world, torch.device("cpu"), dist)
         ctx.close()
@@ -197,7 +197,7 @@ def test_heterogeneous_corpus_two_ranks_cost_dealt(tmp_path):
     import oracle_lib as ol
     from zopfli_amd import ZopfliOptions, api, generate, sharding
 
-    data = generate("T", 1500000) + generate("Z", 1200000) + generate("X", 1300000)
+    data = generate("Z", 1200000) + generate("X", 1300000) + generate("T", 1500000)
     ranges = sharding.shard_ranges(len(data), 2, data, ol.hosttest_library())
     assert ranges != sharding.shard_ranges(len(data), 2)          # the dealing really is by cost here
     out_path = str(tmp_path / "sharded.gz")

@@ -21,7 +21,7 @@
 #include "zmx_match4.h"
 #include "zmx_match5.h"
 #include "zmx_dp4.h"
-#include "zmx_dp5.h"
+#include "zmx_dp5.h"     // (includes zmx_dp6.h: the cooperative run-task job)
 #include "zmx_encode.h"
 #include "zmx_checksum.h"
 #include "zmx_trace.h"
@@ -216,6 +216,9 @@ struct zmx_tables {
   u32* d_wg_tasks = nullptr;       // k_dp5_spec's workgroups: four tasks of one block each
   u32 n_wg = 0;
   u32 n_wg_runs = 0;               // ... of which the last n_wg_runs hold run tasks (k_taskkind): k_dp5_spec<.., true>
+  u32* d_task_kind = nullptr;      // [tasks] k_taskkind: 1 = a run task
+  u32* d_run_list = nullptr;       // the run tasks, longest first: k_dp6_spec's workgroups (zmx_dp6.h)
+  u32 n_run_list = 0;
   u32* d_wmeta = nullptr;          // per 32-position window: 40 words, what k_dp5_spec needs to fetch its rows (k_mkdesc)
   u32* d_winroff = nullptr;        // per 32-position window: offset of its first row in the block's codes (k_mkdesc)
   u32* d_winflag = nullptr;        // per 32-position window: fast path possible (k_mkdesc)
@@ -661,6 +664,8 @@ static void ReleaseTableArrays(zmx_ctx* c, zmx_tables* t, bool keep_stores) {
   rel(t->d_tasks);
   rel(t->d_task_off);
   rel(t->d_wg_tasks);
+  rel(t->d_task_kind);
+  rel(t->d_run_list);
   rel(t->d_wmeta);
   rel(t->d_runin);
   rel(t->d_runout);
@@ -1427,6 +1432,24 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     }
     t->n_wg = static_cast<u32>(wg.size() / D5_WG);
     t->n_wg_runs = static_cast<u32>(wg_runs.size() / D5_WG);
+    // the cooperative kernel's list (zmx_dp6.h): a workgroup per run task, the longest first — a squeeze run waits for
+    // its longest task, and a giant started behind a queue of small ones ends that much later
+    {
+      std::vector<u32> runs;
+      for (size_t k = 0; k < ntk; ++k) if (kind[k]) runs.push_back(static_cast<u32>(k));
+      auto walked = [&](u32 k) {
+        const SegTask& T = t->tasks[k];
+        const u32 Bk = t->bsize[T.block];
+        return (T.pend < Bk ? T.pend : Bk) - T.q;
+      };
+      std::stable_sort(runs.begin(), runs.end(), [&](u32 a, u32 b2) { return walked(a) > walked(b2); });
+      t->n_run_list = static_cast<u32>(runs.size());
+      HIPCHK(PoolAlloc(c, &t->d_task_kind, ntk + 4));
+      HIPCHK(PoolAlloc(c, &t->d_run_list, runs.size() + 4));
+      if (ntk) HIPCHK(hipMemcpyAsync(t->d_task_kind, kind.data(), ntk * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+      if (!runs.empty()) HIPCHK(hipMemcpyAsync(t->d_run_list, runs.data(), runs.size() * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));   // (locals)
+    }
     wg.insert(wg.end(), wg_runs.begin(), wg_runs.end());
     HIPCHK(PoolAlloc(c, &t->d_wg_tasks, wg.size() + 4));
     if (!wg.empty()) HIPCHK(hipMemcpyAsync(t->d_wg_tasks, wg.data(), wg.size() * sizeof(u32), hipMemcpyHostToDevice, c->stream));
@@ -1671,6 +1694,13 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   cp.redo_count = t->d_redo;
   cp.redo_wg = t->d_redo + 4;
   cp.redo_pass = 0;
+  // (ZOPFLI_AMD_COOP=1: run tasks by k_dp6_spec, four waves a task (zmx_dp6.h) — built and measured in round 5, NOT the
+  //  default: 52.6 ms of chain per run on class Z against 45.9 with one wave a task)
+  static const int coop = [] { const char* e = std::getenv("ZOPFLI_AMD_COOP"); return e ? std::atoi(e) : 0; }();
+  cp.coop = coop != 0 ? 1 : 0;
+  cp.kind = t->d_task_kind;
+  cp.run_list = t->d_run_list;
+  cp.flags = t->d_flags;
   cp.wmeta = t->d_wmeta;
   cp.winroff = t->d_winroff;
   cp.winflag = t->d_winflag;
@@ -1717,7 +1747,9 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
         HIPCHK(hipStreamWaitEvent(c->stream2, c->ev2[0], 0));
         Dp4Params cr = cp;
         cr.task0 = t->n_wg;
-        if (cp.prof) hipLaunchKernelGGL((k_dp5_spec<true, 2, true>), dim3(t->n_wg_runs), bdim, 0, c->stream2, cr);
+        if (cp.coop && cp.prof) hipLaunchKernelGGL((k_dp6_spec<2, true>), dim3(t->n_run_list), dim3(64 * D6_NW), 0, c->stream2, cr);
+        else if (cp.coop) hipLaunchKernelGGL((k_dp6_spec<2, false>), dim3(t->n_run_list), dim3(64 * D6_NW), 0, c->stream2, cr);
+        else if (cp.prof) hipLaunchKernelGGL((k_dp5_spec<true, 2, true>), dim3(t->n_wg_runs), bdim, 0, c->stream2, cr);
         else hipLaunchKernelGGL((k_dp5_spec<false, 2, true>), dim3(t->n_wg_runs), bdim, 0, c->stream2, cr);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c->ev2[1], c->stream2));
@@ -1749,7 +1781,12 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
         // (one workgroup per listed task; the workgroups beyond the list have nothing to do)
         const unsigned cap = ntask;
         // (the variant for run tasks wherever the set has any: what is run again there is mostly theirs)
-        if (t->n_wg_runs) {
+        if (t->n_wg_runs && cp.coop) {
+          // the listed run tasks by k_dp6_spec, the listed text tasks by the text variant (each passes over the other's)
+          hipLaunchKernelGGL((k_dp6_spec<2, false>), dim3(cap), dim3(64 * D6_NW), 0, c->stream, c2);
+          if (cp.prof) hipLaunchKernelGGL((k_dp5_spec<true, 4, false>), dim3(cap), dim3(64 * D5_WG), 0, c->stream, c2);
+          else hipLaunchKernelGGL((k_dp5_spec<false, 4, false>), dim3(cap), dim3(64 * D5_WG), 0, c->stream, c2);
+        } else if (t->n_wg_runs) {
           if (cp.prof) hipLaunchKernelGGL((k_dp5_spec<true, 2, true>), dim3(cap), dim3(64 * D5_WG), 0, c->stream, c2);
           else hipLaunchKernelGGL((k_dp5_spec<false, 2, true>), dim3(cap), dim3(64 * D5_WG), 0, c->stream, c2);
         } else {
@@ -1817,6 +1854,17 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     double a[ZMX_PROF_N] = {};
     for (size_t b = 0; b < nb; ++b)
       for (unsigned k = 0; k < ZMX_PROF_N; ++k) a[k] += static_cast<double>(pr[b * ZMX_PROF_N + k]);
+    if (cp.coop && t->n_run_list) {
+      // k_dp6_spec's first pass (zmx_dp6.h): wave 0's cycles by activity, summed over the run tasks (the text tasks' counters
+      // of k_dp5_spec share the slots: read this line on long-run data only)
+      double mxj = 0;
+      for (size_t b = 0; b < nb; ++b) mxj = std::max(mxj, static_cast<double>(pr[b * ZMX_PROF_N + 16]));
+      std::fprintf(stderr, "coop prof (k_dp6_spec, first pass, wave 0): job cycles %.3g (longest job %.3g): token+flow %.3g, class 1 %.3g, class 2 %.3g, "
+                   "headers %.3g, other stretches %.3g (%.0f positions, %.0f each), run stretches %.3g (%.0f positions, %.0f each), general step %.3g (%.0f, %.0f each), "
+                   "shortcuts %.3g (%.0f, %.0f each), waiting for wave 1 at the rotation %.3g (%.0f windows, %.0f each); wave 1: %.3g of %.3g cycles inside get()\n",
+                   a[9], mxj, a[0], a[1], a[2], a[3], a[4], a[10], a[4] / (a[10] + 1e-9), a[5], a[11], a[5] / (a[11] + 1e-9), a[6], a[12], a[6] / (a[12] + 1e-9),
+                   a[7], a[13], a[7] / (a[13] + 1e-9), a[8], a[14], a[8] / (a[14] + 1e-9), a[15], a[17]);
+    }
     std::fprintf(stderr, "squeeze prof: edges %.2f ms chain %.2f ms trace %.2f ms; chain wave busy %.1f cycles/position, "
                  "%.0f steps, fast %.1f%% of %.0f positions walked (%zu in the blocks); tasks %u accepted %u re-run "
                  "state %u values %u level %u tie %u (%u positions, %u by the lean job)\n",

@@ -54,7 +54,7 @@
 //  for every outstanding global load and store of the wave, the LDS-DMA prefetches included: measured, the first version
 //  of this job was 2.4 x slower than the one-wave job for that reason alone)
 struct D6Lds {
-  u32 ring;                        // [D6_RING] 8 bytes each: value | sequence number << 32
+  u32 ring;                        // [D6_RING] values, then [D6_RING] sequence numbers (u32 each)
   u32 rot;                         // [3][D6_ROTD][32] 8 bytes each: channel s - 1 carries register s's low half to wave s - 1
   u32 done;                        // [D6_NW] windows wave r has finished (its low half is in the channel)
   u32 abort;                       // [1] a wave gave up: everybody ends
@@ -85,14 +85,14 @@ __device__ __forceinline__ D6Lds d6_lds_carve(unsigned char* base, float* xc, u1
 // LDS-only ordering inside the workgroup: the wave's LDS operations are complete (a generic fence would also wait for
 // its global loads and stores)
 // The stream's own LDS instructions, as asm: a volatile C++ access makes the compiler wait for every LDS operation in
-// flight before AND after it; the stream needs neither (a slot is one 8-byte write; the LDS queue of a wave is in order).
-__device__ __forceinline__ void d6_ds_write64(u32 addr, u32 lo, u32 hi) {
-  const unsigned long long v = ((unsigned long long)hi << 32) | lo;
-  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
-__device__ __forceinline__ unsigned long long d6_ds_read64(u32 addr) {
-  unsigned long long v;
-  asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+// flight before AND after it; the stream needs neither.  A slot is TWO words in two arrays, the value written first, the
+// sequence number second (the LDS queue of a wave is in order), and read in the opposite order — number, then value: a
+// reader that sees the number sees the value, whatever the LDS does with two waves' instructions at once (one 8-byte
+// slot, written and read whole, was the first version: 5 block runs in 1200 differed).
+__device__ __forceinline__ void d6_ds_write32(u32 addr, u32 v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ u32 d6_ds_read32(u32 addr) {
+  u32 v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
   return v;
 }
 __device__ __forceinline__ void d6_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -156,7 +156,11 @@ __device__ __forceinline__ void d6_run_job(const Dp4Params& P, const D4Job& J, u
     __builtin_amdgcn_endpgm();
   };
   auto put = [&](u32 v) {
-    if (lane == 0) d6_ds_write64(L.ring + 8u * (seq & (D6_RING - 1u)), v, seq);
+    if (lane == 0) {
+      const u32 a = L.ring + 4u * (seq & (D6_RING - 1u));
+      d6_ds_write32(a, v);
+      d6_ds_write32(a + 4u * D6_RING, seq);
+    }
     ++seq;
   };
   // A reader takes 64 slots at a time (lane i: slot seq + i) and serves itself from the registers while the sequence
@@ -175,10 +179,10 @@ __device__ __forceinline__ void d6_run_job(const Dp4Params& P, const D4Job& J, u
         return v;
       }
       if (PROF && spins == 0) t0_ = __builtin_readcyclecounter();
-      const unsigned long long x = d6_ds_read64(L.ring + 8u * ((seq + lane) & (D6_RING - 1u)));
+      const u32 a = L.ring + 4u * ((seq + lane) & (D6_RING - 1u));
+      cache_hi = d6_ds_read32(a + 4u * D6_RING);      // the numbers first, then the values (see d6_ds_write32)
+      cache_lo = d6_ds_read32(a);
       cache_base = seq;
-      cache_lo = (u32)x;
-      cache_hi = (u32)(x >> 32);
       if ((++spins & 63u) == 0 && (*v_abort != 0u || spins > D6_SPIN_MAX)) give_up();
     }
   };
@@ -192,20 +196,24 @@ __device__ __forceinline__ void d6_run_job(const Dp4Params& P, const D4Job& J, u
   // takes the words by v_readlane with constant lane numbers.  A get / put per source was a dozen scalar branches each
   // (the loop "slot there? else read again" does not compile into anything short): 280 cycles a run row.
   auto put_block = [&](u32 acc, u32 n) {           // lanes 0 .. n - 1 of acc
-    if (lane < n) d6_ds_write64(L.ring + 8u * ((seq + lane) & (D6_RING - 1u)), acc, seq + lane);
+    if (lane < n) {
+      const u32 a = L.ring + 4u * ((seq + lane) & (D6_RING - 1u));
+      d6_ds_write32(a, acc);
+      d6_ds_write32(a + 4u * D6_RING, seq + lane);
+    }
     seq += n;
   };
   auto get_block = [&](u32 n) -> u32 {             // returns the words in lanes 0 .. n - 1
     const u64 want = (1ull << n) - 1ull;
     u32 spins = 0;
-    unsigned long long x;
+    const u32 a = L.ring + 4u * ((seq + lane) & (D6_RING - 1u));
     for (;;) {
-      x = d6_ds_read64(L.ring + 8u * ((seq + lane) & (D6_RING - 1u)));
-      if ((__ballot((u32)(x >> 32) == seq + lane) & want) == want) break;
+      const u32 tag = d6_ds_read32(a + 4u * D6_RING);
+      if ((__ballot(tag == seq + lane) & want) == want) break;
       if ((++spins & 63u) == 0 && (*v_abort != 0u || spins > D6_SPIN_MAX)) give_up();
     }
     seq += n;
-    return (u32)x;
+    return d6_ds_read32(a);
   };
 
   // ---- the cell registers this wave owns: register `role` in (c0, l0), register 4 in (c1, l1) on the last wave

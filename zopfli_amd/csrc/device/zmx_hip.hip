@@ -897,6 +897,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   uint4* d_xrec = nullptr;
   u32* d_tot12 = nullptr;
   unsigned long long* d_energy = nullptr;   // k_hits (kernel 0 = per block: k_match5 where the chains are long)
+  u32* d_cmax = nullptr;                    // k_hits: the chunks' largest classes (k_rank2)
   bool skip_any = false, skip_all = false;  // some / all blocks of this build take k_match5
   double skip_positions = 0;                // positions of those blocks
   unsigned long long* d_m5stats = nullptr;  // k_match5's per-wave sums
@@ -928,17 +929,26 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
         // table built from a parent recomputes a few tiles with k_match2.)
         skip_any = mk == 5;
         if (mk == 5) for (size_t b = 0; b < nb; ++b) skip_positions += static_cast<double>(t->blocks[b].inend - t->blocks[b].instart);
-        if (mk == 0) {
+        const unsigned hits_chunks = static_cast<unsigned>((max_l + RK_CH - 1) / RK_CH);
+        {
+          // k_hits: the blocks' hit estimates (kernel 0: which walk a block gets) and the chunks' largest classes (k_rank2:
+          // where the 8192-hit cap can bind; ZOPFLI_AMD_RANK_ALL=1: ranks everywhere, as in round 4)
+          static const bool rank_all = [] { const char* e = std::getenv("ZOPFLI_AMD_RANK_ALL"); return e && std::atoi(e) != 0; }();
           if (!d_energy) HIPCHK(hash_tmp.AllocT(&d_energy, nb, "d_energy"));
+          if (!d_cmax && !rank_all) HIPCHK(hash_tmp.AllocT(&d_cmax, nb * static_cast<size_t>(hits_chunks) + 1, "d_cmax"));
           HIPCHK(hipMemsetAsync(d_energy, 0, nb * sizeof(unsigned long long), c->stream));
+          if (d_cmax) HIPCHK(hipMemsetAsync(d_cmax, 0, (nb * static_cast<size_t>(hits_chunks) + 1) * sizeof(u32), c->stream));
           HitsParams hp;
           hp.in = c->d_in;
           hp.blocks = t->d_blocks;
           hp.same16 = t->d_same16;
           hp.energy = d_energy;
-          const dim3 g5(static_cast<unsigned>((max_l + RK_CH - 1) / RK_CH), static_cast<unsigned>(nb));
+          hp.cmax = d_cmax;
+          const dim3 g5(hits_chunks, static_cast<unsigned>(nb));
           hipLaunchKernelGGL(k_hits, g5, dim3(RK_THREADS), 0, c->stream, hp);
           KCHK(c, "k_hits");
+        }
+        if (mk == 0) {
           std::vector<unsigned long long> energy(nb);
           HIPCHK(hipMemcpyAsync(energy.data(), d_energy, nb * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
           HIPCHK(hipStreamSynchronize(c->stream));
@@ -981,6 +991,8 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
           rp.tot12 = d_tot12;
           rp.energy = lp.energy;
           rp.thr = lp.thr;
+          rp.cmax = d_cmax;
+          rp.cmax_stride = hits_chunks;
           const dim3 g3(static_cast<unsigned>((max_l + RK_CH - 1) / RK_CH), static_cast<unsigned>(nb));
           hipLaunchKernelGGL(k_rank2, g3, dim3(RK_THREADS), 0, c->stream, rp);
           KCHK(c, "k_rank2");

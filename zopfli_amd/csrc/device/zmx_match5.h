@@ -221,6 +221,7 @@ struct HitsParams {
   const BlockDesc* blocks;
   const u16* same16;
   unsigned long long* energy;
+  u32* cmax;          // [blocks][gridDim.x] the largest class of the chunk: of the 3-byte hash | of val2 << 16 (k_rank2: can the 8192-hit cap bind here?)
 };
 
 __device__ __forceinline__ u32 rk_val2(u32 bytes, u64 p, u64 L, u32 same) {
@@ -267,13 +268,53 @@ __global__ __launch_bounds__(RK_THREADS) void k_hits(HitsParams P) {
   }
   __syncthreads();
   unsigned long long sum = 0;
+  u32 mx2 = 0;
   for (u32 i = tid; i < 16384; i += RK_THREADS) {
     const u32 c = cnt[i];
     const unsigned long long a = c & 0xffffu, b = c >> 16;
     sum += a * a + b * b;
+    mx2 = mx2 > (u32)a ? mx2 : (u32)a;
+    mx2 = mx2 > (u32)b ? mx2 : (u32)b;
   }
   for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
   if ((tid & 63u) == 0) atomicAdd(&P.energy[blockIdx.y], sum);
+  if (P.cmax == nullptr) return;
+  // The same count for the 3-byte hash (the first chain's classes), and the largest class of either kind: a position's
+  // walk visits at most the members of its two classes in its own chunk and the one before (a superset of its window),
+  // so where the four maxima stay below 8192 the cap of lz77.c:527-530 cannot bind and nobody needs ranks (k_rank2).
+  __shared__ u32 s_mx[2];
+  __syncthreads();
+  if (tid < 2) s_mx[tid] = 0;
+  for (u32 i = tid; i < 16384; i += RK_THREADS) cnt[i] = 0;
+  __syncthreads();
+  for (u64 s = e0; s < e1; s += RK_THREADS * 4u) {
+    u32 by[4];
+#pragma unroll
+    for (u32 u = 0; u < 4; ++u) {
+      const u64 p = s + RK_THREADS * u + tid;
+      by[u] = p < e1 ? rk_load_u32(base + p) : 0u;
+    }
+#pragma unroll
+    for (u32 u = 0; u < 4; ++u) {
+      const u64 p = s + RK_THREADS * u + tid;
+      if (p < e1) {
+        const u32 key = rk_val2(by[u], p, L, 3u);
+        atomicAdd(&cnt[key >> 1], 1u << (16u * (key & 1u)));
+      }
+    }
+  }
+  __syncthreads();
+  u32 mx1 = 0;
+  for (u32 i = tid; i < 16384; i += RK_THREADS) {
+    const u32 c = cnt[i];
+    mx1 = mx1 > (c & 0xffffu) ? mx1 : (c & 0xffffu);
+    mx1 = mx1 > (c >> 16) ? mx1 : (c >> 16);
+  }
+  mx1 = rdlane_u32(wave_scan_max(mx1), 63);
+  mx2 = rdlane_u32(wave_scan_max(mx2), 63);
+  if ((tid & 63u) == 0) { atomicMax(&s_mx[0], mx1); atomicMax(&s_mx[1], mx2); }
+  __syncthreads();
+  if (tid == 0) P.cmax[(u64)blockIdx.y * gridDim.x + blockIdx.x] = (s_mx[0] > 0xffffu ? 0xffffu : s_mx[0]) | ((s_mx[1] > 0xffffu ? 0xffffu : s_mx[1]) << 16);
 }
 
 // ----------------------------------------------------------------------------
@@ -306,6 +347,8 @@ struct RankParams {
   u32* tot12;         // out: one per region position
   const unsigned long long* energy;
   u64 thr;
+  const u32* cmax;    // k_hits: [blocks][cmax_stride] the chunks' largest classes, or null (ranks everywhere)
+  u32 cmax_stride;
 };
 
 // val2 of 8 consecutive positions p .. p + 7 from the 16 bytes at p and their 8 run lengths
@@ -345,8 +388,23 @@ __global__ __launch_bounds__(RK_THREADS) void k_rank2(RankParams P) {
   uint4* xr = P.xrec + bd.reg_off * 2;
   u32* t12 = P.tot12 + bd.reg_off;
 
+  // Can the 8192-hit cap (lz77.c:527-530) bind for a position of this chunk?  Its walk visits at most the members of its
+  // two classes in this chunk and the one before: if the largest classes of the two chunks (k_hits) add up to less, no —
+  // k_match5 then neither counts nor tests (the record says so: bit 31 of word 2), and ranks are needed only where a
+  // capped chunk FOLLOWS (its positions' candidates reach back into this one).  Text and markup: no chunk is capped, and
+  // the three rank passes — one of them a single wave walking the chunk in order — were 8 of the 13 ms of the record build.
+  bool cap_own = true, need = true;
+  if (P.cmax != nullptr) {
+    const u32* cm = P.cmax + (u64)blockIdx.y * P.cmax_stride;
+    auto capped = [&](u32 ch) -> bool {
+      const u32 a = cm[ch], b = ch ? cm[ch - 1] : 0u;
+      return (a & 0xffffu) + (b & 0xffffu) + (a >> 16) + (b >> 16) >= ZMX_MAX_CHAIN_HITS;
+    };
+    cap_own = capped(blockIdx.x);
+    need = cap_own || (e1 < L && capped(blockIdx.x + 1u));
+  }
   // the two classes in turn: cls 0 = the 3-byte hash (val: the first chain), cls 1 = val2 (the second chain)
-  for (u32 cls = 0; cls < 2; ++cls) {
+  for (u32 cls = 0; cls < 2 && need; ++cls) {
     u16* tt = P.tot + cls * P.total_l + bd.reg_off;
     u16* rk = P.rank + cls * P.total_l + bd.reg_off;
     __syncthreads();
@@ -429,8 +487,9 @@ __global__ __launch_bounds__(RK_THREADS) void k_rank2(RankParams P) {
     uint4 l4[4], lv[LV_N];
 #pragma unroll
     for (u32 i = 0; i < 4; ++i) l4[i] = reinterpret_cast<const uint4*>(lk + s)[i];
-    const uint4 ta = *reinterpret_cast<const uint4*>(tt1 + s), tb = *reinterpret_cast<const uint4*>(tt2 + s);
-    const uint4 ra = *reinterpret_cast<const uint4*>(rk1 + s), rb = *reinterpret_cast<const uint4*>(rk2 + s);
+    const uint4 z4 = make_uint4(0, 0, 0, 0);
+    const uint4 ta = need ? *reinterpret_cast<const uint4*>(tt1 + s) : z4, tb = need ? *reinterpret_cast<const uint4*>(tt2 + s) : z4;
+    const uint4 ra = need ? *reinterpret_cast<const uint4*>(rk1 + s) : z4, rb = need ? *reinterpret_cast<const uint4*>(rk2 + s) : z4;
 #pragma unroll
     for (u32 j = 0; j < LV_N; ++j) lv[j] = *reinterpret_cast<const uint4*>(lev + (u64)j * P.total_l + s);
     const u32 taw[4] = {ta.x, ta.y, ta.z, ta.w}, tbw[4] = {tb.x, tb.y, tb.z, tb.w};
@@ -451,7 +510,7 @@ __global__ __launch_bounds__(RK_THREADS) void k_rank2(RankParams P) {
       uint4 a, b;
       a.x = lx;                                        // prev1 | prev2 << 16
       a.y = (ly & 0xffffu) | (r1 << 16);               // same | rank within its 3-byte-hash class (in its chunk)
-      a.z = r2;                                        // rank within its val2 class
+      a.z = r2 | (cap_own ? 0u : 0x80000000u);         // rank within its val2 class; bit 31: the cap cannot bind for this position
       a.w = l[0] | (l[1] << 16);
       b.x = l[2] | (l[3] << 16);
       b.y = l[4] | (l[5] << 16);
@@ -743,7 +802,10 @@ __global__ __launch_bounds__(M5_THREADS, 4) void k_match5(Match5Params Q) {
             same_pos = Ap.y & 0xffffu;
             byte0 = P0.x & 255u;
             ncp = 0;
-            bestlen = 1; bestdist = 0; chain = 1; idx = 0; curd = 0; lev_k = -1; need_link = false;
+            bestlen = 1; bestdist = 0; chain = 1; curd = 0; lev_k = -1; need_link = false;
+            // (where the cap cannot bind — k_rank2's verdict, bit 31 — the count starts so far below zero that no sum of
+            //  hops, garbage there, brings it up to 8192: the tests below are signed)
+            idx = (Ap.z >> 31) ? 0xC0000000u : 0u;
             if (size_rem < 3) {                      // lz77.c:440-446
               rec[0] = 0;
               rec[1] = same_pos | (byte0 << 16);
@@ -879,7 +941,7 @@ __global__ __launch_bounds__(M5_THREADS, 4) void k_match5(Match5Params Q) {
           }
           if (!ok) {
             moved = true;                        // not on the second chain: never visited
-          } else if (idx + hops > ZMX_MAX_CHAIN_HITS) {
+          } else if ((int)(idx + hops) > (int)ZMX_MAX_CHAIN_HITS) {
             fin = true;                          // beyond the 8192nd candidate (lz77.c:527-530)
           } else {
             idx += hops;
@@ -916,7 +978,7 @@ __global__ __launch_bounds__(M5_THREADS, 4) void k_match5(Match5Params Q) {
         // a candidate the reference visits that does not beat bestlength — its own chain's next hit, or the switch
         // point: count it (and what lies between), test the switch rule
         const u32 hops = fk == 0u ? 1u : (gcur1 - gx1) & 0xffffu;
-        if (idx + hops > ZMX_MAX_CHAIN_HITS) {
+        if ((int)(idx + hops) > (int)ZMX_MAX_CHAIN_HITS) {
           fin = true;
         } else {
           idx += hops;

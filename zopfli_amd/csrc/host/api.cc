@@ -484,7 +484,6 @@ int RunPartsShardedOnce(const ZopfliOptions& options, int btype, const unsigned 
       // (not fatal: the context stays on the streams it has, the shards then run side by side instead of in turn)
       std::fprintf(stderr, "zopfli_amd: stream priorities unavailable (%s)\n", zmx_last_error());
     }
-    zamd::g_wide_lane = static_cast<int>(d % static_cast<size_t>(zamd::kWideLanes));   // (thread_pool.h: a wide pool per shard thread)
     sh.rc = 0;
     sh.err.clear();
     sh.chunks.clear();

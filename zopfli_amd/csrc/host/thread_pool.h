@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <system_error>
 #include <thread>
@@ -102,28 +103,15 @@ inline unsigned WideThreads() {
   return n;
 }
 
-// Which of the wide pools the calling thread's ParallelForWide goes to.  A request that is dealt over several contexts of a
-// device runs one host thread per context (api.cc), and a pool takes one job at a time: with one wide pool the block-split
-// searches of three contexts — 33 master blocks each, ten milliseconds a search, half the pool idle — stood in line,
-// 30 ms with nothing on the device.  Each of those threads has its own (the threads sleep when there is no job).
-constexpr int kWideLanes = 4;
-inline thread_local int g_wide_lane = 0;
+// (Round 4 gave every shard thread of a call a wide pool of its own — a pool took one job at a time, and the block-split
+//  searches of three contexts stood in line — which left a drop-in caller's process with three times WideThreads()
+//  sleeping threads.  The wide pool now takes any number of jobs at once: WidePool below.)
 
 class WorkerPool {
  public:
   // The pools are created on first use and leaked on purpose (no join at exit).  A forked child has
   // none of the worker threads: it forgets the parent's pools and makes its own on first use.
   static WorkerPool& Get() { return Instance(0, HostThreads()); }
-  static WorkerPool& Wide() {
-    const int lane = g_wide_lane < 0 ? 0 : g_wide_lane % kWideLanes;
-    if (WideThreads() == HostThreads() && lane == 0) return Get();
-    // Lane 0 (a call on one context) has the whole wide budget; the pools of the other shard lanes — they only exist in
-    // a process that deals a call over several contexts, and then run side by side — share it: a third each, which
-    // still is a thread per master block of a 100 MB call's shard (33), and leaves a drop-in caller's process with
-    // WideThreads() sleeping threads for them instead of three times that.
-    const unsigned share = (WideThreads() + 2) / 3;
-    return Instance(1 + lane, lane == 0 ? WideThreads() : (share > HostThreads() ? share : HostThreads()));
-  }
 
   // Runs body(i) for i in [0, n) on the workers and the calling thread; returns
   // when all are done.  One job at a time (callers are serialised).
@@ -150,7 +138,7 @@ class WorkerPool {
 
  private:
   static std::atomic<WorkerPool*>* Slots() {
-    static std::atomic<WorkerPool*> slots[1 + kWideLanes];
+    static std::atomic<WorkerPool*> slots[1];
     return slots;
   }
   static std::mutex& CreateMutex() {
@@ -158,7 +146,7 @@ class WorkerPool {
     return *m;
   }
   static void ForgetInChild() {
-    for (int i = 0; i < 1 + kWideLanes; ++i) Slots()[i].store(nullptr);
+    Slots()[0].store(nullptr);
     new (&CreateMutex()) std::mutex();         // the parent may have forked while holding it
   }
   static WorkerPool& Instance(int which, unsigned threads) {
@@ -244,6 +232,121 @@ class WorkerPool {
   std::atomic<uint64_t> generation_{0};
 };
 
+// The wide pool: WideThreads() workers shared by every caller, ANY NUMBER OF JOBS AT ONCE.  Its tasks are long (a block-split
+// search, a master block's encoding: milliseconds), so a mutex per task taken is nothing, and a call dealt over three
+// contexts has its three shard threads' jobs served side by side by the same workers — each job gets the whole pool while
+// the others have nothing to do.  Created on first use, leaked on purpose, forgotten in a forked child (as WorkerPool).
+class WidePool {
+ public:
+  static WidePool& Get() {
+    WidePool* p = Slot().load(std::memory_order_acquire);
+    if (p) return *p;
+    std::lock_guard<std::mutex> lock(CreateMutex());
+    p = Slot().load(std::memory_order_acquire);
+    if (!p) {
+      static std::once_flag atfork;
+      std::call_once(atfork, [] { pthread_atfork(nullptr, nullptr, &WidePool::ForgetInChild); });
+      p = new WidePool(WideThreads());
+      Slot().store(p, std::memory_order_release);
+    }
+    return *p;
+  }
+
+  void Run(size_t n, const std::function<void(size_t)>& body) {
+    auto job = std::make_shared<Job>();
+    job->body = &body;
+    job->n = n;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      jobs_.push_back(job);
+    }
+    wake_.notify_all();
+    // the caller works on its own job, then waits for the tasks others took
+    for (;;) {
+      const size_t i = job->next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= n) break;
+      body(i);
+      job->done.fetch_add(1, std::memory_order_acq_rel);
+    }
+    {
+      std::unique_lock<std::mutex> lock(mu_);
+      for (auto it = jobs_.begin(); it != jobs_.end(); ++it) {
+        if (it->get() == job.get()) { jobs_.erase(it); break; }
+      }
+      done_.wait(lock, [&] { return job->done.load(std::memory_order_acquire) >= n; });
+    }
+  }
+
+ private:
+  struct Job {
+    const std::function<void(size_t)>* body = nullptr;
+    size_t n = 0;
+    std::atomic<size_t> next{0}, done{0};
+  };
+  static std::atomic<WidePool*>& Slot() {
+    static std::atomic<WidePool*> slot{nullptr};
+    return slot;
+  }
+  static std::mutex& CreateMutex() {
+    static std::mutex* m = new std::mutex();
+    return *m;
+  }
+  static void ForgetInChild() {
+    Slot().store(nullptr);
+    new (&CreateMutex()) std::mutex();
+  }
+  explicit WidePool(unsigned threads) {
+    const unsigned extra = threads > 1 ? threads - 1 : 0;
+    for (unsigned t = 0; t < extra; ++t) {
+      try {
+        std::thread([this] { Loop(); }).detach();
+      } catch (const std::system_error&) {
+        break;      // (a pids cgroup / RLIMIT_NPROC: the callers do the work themselves)
+      }
+    }
+  }
+  void Loop() {
+    size_t turn = 0;
+    for (;;) {
+      std::shared_ptr<Job> job;
+      size_t i = 0;
+      {
+        std::unique_lock<std::mutex> lock(mu_);
+        for (;;) {
+          // a job that still has tasks to hand out, the jobs in turn
+          const size_t nj = jobs_.size();
+          for (size_t k = 0; k < nj && !job; ++k) {
+            const std::shared_ptr<Job>& c = jobs_[(turn + k) % nj];
+            const size_t at = c->next.load(std::memory_order_relaxed);
+            if (at < c->n) {
+              i = c->next.fetch_add(1, std::memory_order_relaxed);
+              if (i < c->n) job = c;
+            }
+          }
+          if (job) break;
+          wake_.wait(lock);
+        }
+        ++turn;
+      }
+      // (tasks of one job in a row without the lock while it has any)
+      for (;;) {
+        (*job->body)(i);
+        const bool last = job->done.fetch_add(1, std::memory_order_acq_rel) + 1 >= job->n;
+        if (last) {
+          std::lock_guard<std::mutex> lock(mu_);
+          done_.notify_all();
+        }
+        i = job->next.fetch_add(1, std::memory_order_relaxed);
+        if (i >= job->n) break;
+      }
+    }
+  }
+
+  std::mutex mu_;
+  std::condition_variable wake_, done_;
+  std::vector<std::shared_ptr<Job>> jobs_;
+};
+
 inline thread_local bool g_inside_parallel_for = false;
 
 // Calls fn(i) for i in [0, n), dynamically load-balanced.  Nested calls run inline.
@@ -276,7 +379,8 @@ void ParallelForWide(size_t n, Fn&& fn) {
     fn(i);
     g_inside_parallel_for = was;
   };
-  WorkerPool::Wide().Run(n, body);
+  if (WideThreads() <= HostThreads()) { WorkerPool::Get().Run(n, body); return; }
+  WidePool::Get().Run(n, body);
 }
 
 }  // namespace zamd

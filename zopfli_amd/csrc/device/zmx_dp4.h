@@ -349,7 +349,7 @@ struct Dp4Params {
   int fix_lean_min;        // k_dp4_fix: a task with this many generic windows is re-run by the lean one-wave job
   int redo_pass;           // k_dp5_spec: 1 = this launch runs P.redo_wg (workgroups beyond *redo_count have nothing to do)
   // the cooperative run tasks (zmx_dp6.h)
-  int coop;                // 1 = run tasks are k_dp6_spec's (four waves a task); k_dp5_spec's second pass then skips them, k_dp4_fix's lean re-runs use d6_run_job
+  int coop;                // 1 = run tasks are k_dp6_spec's (four waves a task); k_dp5_spec's second pass then skips them
   const u32* kind;         // [tasks] k_taskkind: 1 = a run task
   const u32* run_list;     // k_dp6_spec, first pass: the run tasks, longest first
   u32* flags;              // [2] the table set's consistency flags (flags[1] bit 3: a cooperative job's wave gave up waiting)

@@ -591,7 +591,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
           //  it does in some builds: zmx_dp6.h has the case)
           int vo = (int)(lane2 - 2u * (u32)(8 * h + u + 1));
           int vo2 = vo + 128;
-          asm volatile("" : "+v"(vo), "+v"(vo2));
+          asm("" : "+v"(vo), "+v"(vo2));
           ca[u] = (u32)(u16)__builtin_amdgcn_raw_buffer_load_b16(rs_, vo, 0, 0);
           cb[u] = (u32)(u16)__builtin_amdgcn_raw_buffer_load_b16(rs_, vo2, 0, 0);
           rb_ += 2u * ke8[u];
@@ -1284,7 +1284,7 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
   __syncthreads();
   __shared__ __align__(8) double s_w1[D5_W1];
   __shared__ u8 s_sym1[D5_W1];
-  __shared__ __align__(8) uint2 s_ri[4][32];
+  __shared__ __align__(8) uint2 s_ri[32];
   d5_build_w1(s_wtab, s_w1, s_sym1);
   u16* la_block = P.la + bd.la_off;
   d4_copy_over(P, t0, B, la_block);   // the head is exact
@@ -1409,23 +1409,8 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
       ++n_lean;
       D5IntTab IT;
       IT.on = false; IT.lo = 0; IT.span = 0;
-      if (P.coop) {
-        // the cooperative job (zmx_dp6.h): the workgroup's four waves on one task, the cell registers dealt over them; its
-        // LDS comes out of the pipeline's areas, idle in this job (staging: the code ring; the table by k: tile 2; stream,
-        // rotation channels and counters: the second half of tile 1)
-        const u32 wv = threadIdx.x >> 6;
-        const D6Lds L6 = d6_lds_carve(reinterpret_cast<unsigned char*>(&s_t1[1][0]), s_xc, s_xl);
-#define D6_FIX_JOB(R) d6_run_job<false, R>(P, J, b, bd, s_wtab, L6, reinterpret_cast<u16*>(reinterpret_cast<unsigned char*>(s_ring) + R * D5_STAGE_BYTES), \
-                   *reinterpret_cast<const uint2 (*)[ZMX_WTAB]>(&s_t1[0][0]), IT, s_w1, s_sym1, s_ri[R], reinterpret_cast<uint2*>(&s_t2[0][0]) + R * D5_RKN)
-        switch (wv) {
-          case 0: D6_FIX_JOB(0); break;
-          case 1: D6_FIX_JOB(1); break;
-          case 2: D6_FIX_JOB(2); break;
-          default: D6_FIX_JOB(3); break;
-        }
-#undef D6_FIX_JOB
-      } else if (threadIdx.x < 64) {
-        d5_run_job<PROF, true>(P, J, b, bd, s_wtab, s_xc, s_xl, s_ring, *reinterpret_cast<const uint2 (*)[ZMX_WTAB]>(&s_t1[0][0]), IT, s_w1, s_sym1, s_ri[0],
+      if (threadIdx.x < 64) {
+        d5_run_job<PROF, true>(P, J, b, bd, s_wtab, s_xc, s_xl, s_ring, *reinterpret_cast<const uint2 (*)[ZMX_WTAB]>(&s_t1[0][0]), IT, s_w1, s_sym1, s_ri,
                                reinterpret_cast<uint2*>(&s_t2[0][0]));   // (s_rk: the pipeline's tiles are idle in this job)
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

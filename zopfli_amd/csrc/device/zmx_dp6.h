@@ -32,8 +32,8 @@
 // windows deep and the stream ring 1024 slots — more than four windows can fill.  No spin is unbounded: a wave that has
 // waited 2^22 rounds raises flags[1] bit 3 (the host fails the run), tells the others through LDS and ends.
 //
-// The text tasks keep k_dp5_spec<.., 4, false> (a wave per task: their rows fit one register).  k_dp4_fix's lean re-runs
-// use this job with the workgroup's four waves.
+// The text tasks keep k_dp5_spec<.., 4, false> (a wave per task: their rows fit one register); k_dp4_fix's serial re-runs
+// keep the one-wave job (with the cooperative job compiled into it, that kernel was a fifth slower on text).
 #pragma once
 
 #define D6_NW 4u                   // waves of a cooperative job
@@ -524,7 +524,7 @@ __device__ __forceinline__ void d6_run_job(const Dp4Params& P, const D4Job& J, u
             //  — between the eight rows and puts the differences into the offset field: those lanes then read 0, "no edge".
             //  Found as a lost literal edge, in one build out of two.)
             int vo = (int)(lane2 - 2u * (u32)(8 * h + u + 1)) + (int)(128u * role);
-            asm volatile("" : "+v"(vo));
+            asm("" : "+v"(vo));
             ca[u] = (u32)(u16)__builtin_amdgcn_raw_buffer_load_b16(rs_, vo, 0, 0);
           }
           rb_ += 2u * ke8[u];

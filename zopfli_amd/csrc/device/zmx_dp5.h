@@ -680,6 +680,9 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
             st_land = rg0;
             st_ok = true;
           }
+          // (the region that comes in replaces the one two below it: this wave's reads of that one must have been served
+          //  — zmx_dp6.h has the case that showed it; here the reads were always consumed before, this makes it explicit)
+          if (st_iss < rg0 + 2u) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           while (st_iss < rg0 + 2u) {
             const u16* src_ = rows + 1024u * st_iss + 8u * lane;
             const u32 dst_ = (stage_half << 1) + 2048u * (st_iss & 1u);
@@ -973,6 +976,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
             st_land = rg0;
             st_ok = true;
           }
+          if (st_iss < rg0 + 2u) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (this wave's reads of the region that is replaced: served)
           while (st_iss < rg0 + 2u) {                                // (region st_iss takes the half of region st_iss - 2 < rg0)
             const u16* src_ = rows + 1024u * st_iss + 8u * lane;
             const u32 dst_ = (stage_half << 1) + 2048u * (st_iss & 1u);

@@ -602,6 +602,10 @@ __device__ __forceinline__ void d6_run_job(const Dp4Params& P, const D4Job& J, u
           st_land = rg0;
           st_ok = true;
         }
+        // (a region comes in over the one two below it: every read of that one this wave has issued must have been served —
+        //  the DMA's data can be back from the L2 before a queued ds_read is.  Found by tools/r05_coop_stress.py: with the
+        //  code reads of four rows issued back to back, 20 block runs in 2 400 read a row's codes from the region after next.)
+        if (st_iss < rg0 + 2u) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         while (st_iss < rg0 + 2u) {
           const u16* src_ = rows + 1024u * st_iss + 8u * lane;
           const u32 dst_ = (stage_half << 1) + 2048u * (st_iss & 1u);

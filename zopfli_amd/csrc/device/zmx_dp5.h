@@ -285,7 +285,9 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
   };
   float vmax = 0.0f;
   u32 mid_hi = 0;                                   // (set with the entry snapshot)
-  const float mid_margin = 2.0f * P.wmax[b];
+  // (text tasks, round 5: between two looks — every 64 positions — the cells of text grow by ~250 bits, ten largest weights;
+  //  the snapshot is left that much earlier.  The margin only decides WHERE the snapshot lies, never whether it counts.)
+  const float mid_margin = (RUNS ? 2.0f : 16.0f) * P.wmax[b];
   if (J.mid != nullptr && lane == 0) J.mid->base = SEG_NONE;
   u32 wbase = (u32)__builtin_amdgcn_readfirstlane((int)J.start);
   bool noshort = J.noshort != 0;
@@ -420,7 +422,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
       vmax = 0.0f;
       // where the binade of the entry state ends (the bit pattern of its 2^(e+1)); 0: no mid snapshot for this task
       const u32 e0_ = rdlane_u32(__float_as_uint(c[0]), skip < 32u ? skip : 0u);
-      mid_hi = (RUNS && J.mid != nullptr && e0_ < 0x70000000u) ? (e0_ & 0x7f800000u) + 0x00800000u : 0u;
+      mid_hi = (J.mid != nullptr && e0_ < 0x70000000u) ? (e0_ & 0x7f800000u) + 0x00800000u : 0u;
     }
     // A task that grows out of its binade is only accepted with a level that was exactly right (zmx_dp4.h: d4_accept),
     // and long tasks on long-run data mostly do grow out of one.  What they did BEFORE they came near the end of the
@@ -430,7 +432,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
     // WHERE the snapshot lies; whether the prefix stayed inside the binade is decided by its recorded maximum.)
     // (at a multiple of 64 only: k_dp4's pipeline, which may be the one to continue from here, walks in groups of 64 and
     //  has to stop at the base its successor started from)
-    if (RUNS && mid_hi != 0 && la_lo != SEG_NONE && skip == 0 && (wbase & 63u) == 0) {
+    if (mid_hi != 0 && la_lo != SEG_NONE && skip == 0 && (wbase & 63u) == 0) {
       const u32 c0_ = rdlane_u32(__float_as_uint(c[0]), 0);
       if (c0_ < 0x70000000u && __uint_as_float(c0_) + mid_margin >= __uint_as_float(mid_hi)) {
 #pragma unroll
@@ -1240,10 +1242,10 @@ __global__ __launch_bounds__(64 * D5_WG, WAVES) void k_dp5_spec(Dp4Params P) {
   J.init = nullptr;
   J.entry = &P.entry[t];
   J.exit = &P.exit[t];
-  // (run tasks only: they are the long ones — tens of thousands of positions between two cut points — that leave their
-  //  binade; the text variant keeps its window loop as it was, and its mid[t].base is set to none below)
-  J.mid = RUNS && T.pout != 0 && P.mid != nullptr ? &P.mid[t] : nullptr;
-  if (!RUNS && T.pout != 0 && P.mid != nullptr && (threadIdx.x & 63) == 0) P.mid[t].base = SEG_NONE;
+  // (round 3: run tasks only — the long ones, tens of thousands of positions between two cut points; round 5: text tasks
+  //  too: a block has a binade boundary per doubling of its cost whatever its size, and in a SMALL call the serial re-runs
+  //  of the tasks that cross one were most of k_dp4_fix: 0.66 ms per run of a 1 MB call)
+  J.mid = T.pout != 0 && P.mid != nullptr ? &P.mid[t] : nullptr;
   J.over_lo = T.pend <= B ? T.pend : SEG_NONE;
   J.over = P.over + (u64)t * SEG_OVER;
   if (T.pout == 0) {       // the head of the block

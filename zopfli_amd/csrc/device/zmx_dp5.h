@@ -1307,6 +1307,9 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
   __shared__ double s_ck_d[FIX_CH], s_dl[FIX_CH];
   __shared__ float s_ck_vmin[FIX_CH], s_vmax[FIX_CH];
   __shared__ u32 s_ck_match[FIX_CH], s_xbase[FIX_CH], s_pend[FIX_CH], s_acc[FIX_CH];
+  __shared__ double s_wsum[4], s_dprev;
+  __shared__ u32 s_wfail[4];
+  static_assert(FIX_CH == 64 * (D3_NB + 2), "the sweep judges a chunk's tasks a thread each");
   for (u32 c0 = t0 + 1; c0 < t1; c0 += FIX_CH) {
   const u32 cn = t1 - c0 < FIX_CH ? t1 - c0 : FIX_CH;
   for (u32 i = threadIdx.x; i < cn; i += blockDim.x) {
@@ -1320,6 +1323,40 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
   }
   __syncthreads();
   for (u32 t = c0; t < c0 + cn; ++t) {
+    // The walk, a SWEEP at a time (round 5): nearly every task is simply accepted, and deciding so one task after the
+    // other — four waves doing the same dozen double-precision operations — was 1 200 cycles a task, 0.25 ms of this
+    // kernel's 0.43 per 1 MB block.  All tasks of the chunk from t on are judged at once, a thread each: their shifts are a
+    // prefix sum of the checks' differences (sums of multiples of float ulps: exact in any order, as in k_dpscan), the
+    // acceptance test is the one below with that shift; everything up to the first task that fails is accepted, and
+    // that task takes the serial step — which re-runs it — as before.  (Not behind a re-run: the next task's check is stale.)
+    if (!rerun_prev) {
+      const u32 ti0 = t - c0;
+      const u32 i = threadIdx.x;                       // (FIX_CH = the workgroup's threads: a thread per task of the chunk)
+      const bool act = i >= ti0 && i < cn;
+      double incl = act ? s_ck_d[i] : 0.0;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(incl, o, 64);
+        if ((int)lane >= o) incl += up;
+      }
+      if (lane == 63) s_wsum[threadIdx.x >> 6] = incl;
+      __syncthreads();
+      double before = 0.0;
+      for (u32 w = 0; w < (threadIdx.x >> 6); ++w) before += s_wsum[w];
+      const double delta_i = delta_prev + before + incl;
+      const bool ok_i = act && s_ck_match[i] == 1 && d4_accept(s_ck_vmin[i], (double)s_vmax[i], delta_i, wmax, tiemask) == 0;
+      const u64 failm = __ballot(act && !ok_i);
+      if (lane == 0) s_wfail[threadIdx.x >> 6] = failm ? (threadIdx.x & ~63u) + (u32)__ffsll((long long)failm) - 1u : 0xffffffffu;
+      __syncthreads();
+      u32 first_fail = cn;
+      for (u32 w = 0; w < (blockDim.x >> 6); ++w) first_fail = s_wfail[w] < first_fail ? s_wfail[w] : first_fail;
+      if (act && i < first_fail) { s_acc[i] = 1; s_dl[i] = delta_i; }
+      if (first_fail > ti0 && i == first_fail - 1u) s_dprev = delta_i;
+      __syncthreads();
+      if (first_fail > ti0) { delta_prev = s_dprev; n_ok += first_fail - ti0; }
+      t = c0 + first_fail;
+      if (t >= c0 + cn) break;
+    }
     const u32 ti = t - c0;
     SegCheck ck;
     if (rerun_prev) ck = d4_check(&P.exit[t - 1], &P.entry[t], lane);   // every wave computes the same
@@ -1432,12 +1469,14 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
   __syncthreads();
   // the chunk's accepted tasks: their cells beyond pend (d4_copy_over), one task per wave at a time; and every
   // task's level for the next run
-  for (u32 i = threadIdx.x >> 6; i < cn; i += blockDim.x >> 6) {
+  // (sixteen lanes a task, sixteen tasks at a time: a task's copy is one or two dependent global round trips of a few dozen
+  //  cells, and with a wave per task — four in flight — those round trips were a third of this kernel on text)
+  for (u32 i = threadIdx.x >> 4; i < cn; i += blockDim.x >> 4) {
     if (!s_acc[i]) continue;
     const u32 pend = s_pend[i], stop = s_xbase[i];
     if (pend > B) continue;                   // the last task of the block runs to the end
     const u16* over = P.over + (u64)(c0 + i) * SEG_OVER;
-    for (u32 k = lane; pend + k < stop && pend + k <= B; k += 64) la_block[pend + k] = over[k];
+    for (u32 k = threadIdx.x & 15u; pend + k < stop && pend + k <= B; k += 16) la_block[pend + k] = over[k];
   }
   for (u32 i = threadIdx.x; i < cn; i += blockDim.x) P.lvl[c0 + i] = (float)((double)P.lvl[c0 + i] + s_dl[i]);
   __syncthreads();

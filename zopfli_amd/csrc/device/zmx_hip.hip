@@ -740,7 +740,10 @@ static unsigned SegL(u64 total_positions) {
   //  1024 loses to the per-task set-up again: 4.2 ms)
   // (a call of 64 KiB is 64 tasks of 1024 positions on 256 CUs: 512 halves the latency of every pass — 18.6 -> 16.8 ms
   //  for the call —, at 1 MB 512 loses to the per-task set-up again: 39 -> 44 ms)
-  return total_positions <= (256u << 10) ? 512u : total_positions < (2u << 20) ? 1024u : 2048u;
+  // (round 5: with k_dp4_fix judging a chunk's tasks at once the per-task set-up is gone and short tasks win further up —
+  //  64 KiB: 256 13.2 ms against 13.8 with 512; 1 MB: 512 23.1 against 24.1 with 1024; 4 MB: 512 33.6 against 38.1;
+  //  100 MB: 2048 3.63 ms per run against 3.94 with 1024 — tools/r05_segl.sh)
+  return total_positions <= (128u << 10) ? 256u : total_positions <= (16u << 20) ? 512u : total_positions <= (48u << 20) ? 1024u : 2048u;
 }
 // The first task of a block is exact by construction and runs beside the others: let it cover the
 // stretch where the costs double every few thousand positions and no guess would stay in its binade.

@@ -826,6 +826,37 @@ def test_master_blocks_dealt_over_device_contexts():
         assert res["0"][0] == hashlib.sha256(ol.ref_compress(data, 0, 3)).hexdigest()
 
 
+def test_mid_size_calls_dealt_at_stream_priorities():
+    """Round 5's dealing rules (api.cc RunPartsShardedOnce): a call of 4 master blocks or more with block splitting
+    — and data with long runs of equal bytes with or without it — goes over three contexts of the device at three
+    stream priorities (ZOPFLI_AMD_DEAL_AFTER=0: from the process's first such call on, not its eighth).  The call trace
+    shows the three shards, and the streams equal those of a process that never deals (ZOPFLI_AMD_SPLIT_MB=0) and
+    the reference's."""
+    import subprocess
+    import sys
+    code = (
+        "import hashlib, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from zopfli_amd import ZopfliOptions, api, generate\n"
+        "data = generate('T', 2100000) + generate('Z', 1900000, 5) + generate('P', 1300000)\n"
+        "o = ZopfliOptions(3)\n"
+        "print(hashlib.sha256(api.compress(data, 0, o)).hexdigest())\n"
+        "o.blocksplitting = 0\n"
+        "print(hashlib.sha256(api.compress(data * 4, 0, o)).hexdigest())\n"
+        % os.path.dirname(os.path.dirname(__file__)))
+    res = {}
+    for name, extra in (("dealt", {"ZOPFLI_AMD_DEAL_AFTER": "0", "ZOPFLI_AMD_TRACE_CALL": "1"}), ("never", {"ZOPFLI_AMD_SPLIT_MB": "0"})):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[name] = r.stdout.split()
+        if name == "dealt":
+            assert r.stderr.count("shard 2 (") == 2, r.stderr[-3000:]      # both calls ran as three shards
+    assert res["dealt"] == res["never"]
+    if ol.have_ref():
+        data = generate("T", 2100000) + generate("Z", 1900000, 5) + generate("P", 1300000)
+        assert res["dealt"][0] == hashlib.sha256(ol.ref_compress(data, 0, 3)).hexdigest()
+
+
 def test_rccl_gather_world_of_one(gpu_ctx):
     """zmx_dist_* (dist.cc): librccl loads, a communicator of one rank forms on the device and the
     gather returns rank 0's own blob — all of the RCCL path a one-GPU box can run; with more ranks the

@@ -81,10 +81,24 @@ class ContextPool {
   // one free context on each of up to `want` devices (at least one), in device order; with `per_device` > 1 up to
   // that many free contexts of every device it uses (a large request on one device is dealt over two of its
   // contexts: one half's host phases run beside the other half's kernels)
-  std::vector<zmx_ctx*> Acquire(size_t want, size_t per_device = 1, std::vector<int>* device_of = nullptr) {
+  // `polite`: a call that is not large takes several contexts of a device only while it is the only caller — with other
+  // calls in flight (holding contexts or waiting for one) it takes one, as every call below the dealing threshold does.
+  std::vector<zmx_ctx*> Acquire(size_t want, size_t per_device = 1, std::vector<int>* device_of = nullptr,
+                                bool polite = false) {
     std::unique_lock<std::mutex> lock(mu_);
     Init();
+    ++in_flight_;
+    // ... and it does not CREATE the further contexts before the eighth such call of the process (ZOPFLI_AMD_DEAL_AFTER):
+    // a context costs ~ 50 ms to set up and saves such a call 5 - 15 ms, which a program that compresses a few files
+    // and exits never earns back (zopflipng on one 1024 x 1024 image: 0.62 -> 0.70 s when its calls set up two more
+    // contexts); a long-lived caller pays once.  (The first context a call takes is created whenever none is free.)
+    static const size_t deal_after = [] {
+      const char* e = std::getenv("ZOPFLI_AMD_DEAL_AFTER");
+      return e ? static_cast<size_t>(std::max(0, std::atoi(e))) : static_cast<size_t>(8);
+    }();
+    const bool may_create_more = !polite || per_device <= 1 || ++polite_wishes_ >= deal_after;
     for (;;) {
+      if (polite && in_flight_ > 1) per_device = 1;
       std::vector<Slot*> slots;
       size_t used_devices = 0;
       for (auto& dev : devices_) {
@@ -96,7 +110,7 @@ class ContextPool {
           for (auto& sl : dev.slots) {
             if (!sl->busy && std::find(slots.begin(), slots.end(), sl.get()) == slots.end()) { s = sl.get(); break; }
           }
-          if (!s && dev.slots.size() < lanes_) {
+          if (!s && dev.slots.size() < lanes_ && (may_create_more || lane == 0)) {
             // a new context: the slot is taken now, the context is created below without the pool's lock (HIP
             // start-up, streams, events: up to seconds on first use, and every Release would wait behind it)
             dev.slots.emplace_back(new Slot{nullptr, false, &dev});
@@ -184,6 +198,7 @@ class ContextPool {
   void Release(const std::vector<zmx_ctx*>& ctxs) {
     {
       std::lock_guard<std::mutex> lock(mu_);
+      if (in_flight_) --in_flight_;
       for (auto& dev : devices_)
         for (auto& sl : dev.slots)
           if (std::find(ctxs.begin(), ctxs.end(), sl->ctx) != ctxs.end()) sl->busy = false;
@@ -246,6 +261,8 @@ class ContextPool {
   std::condition_variable cv_;
   std::vector<Device> devices_;
   size_t lanes_ = 3;
+  size_t in_flight_ = 0;     // calls between Acquire and Release
+  size_t polite_wishes_ = 0; // polite calls so far that asked for more than one context of a device
 };
 
 ContextPool& Pool() {
@@ -266,7 +283,8 @@ double WallMs() {
 struct Lease {
   std::vector<int> device_of;      // HIP device index of ctxs[i]
   std::vector<zmx_ctx*> ctxs;
-  explicit Lease(size_t want, size_t per_device = 1) : ctxs(Pool().Acquire(want, per_device, &device_of)) {}
+  explicit Lease(size_t want, size_t per_device = 1, bool polite = false)
+      : ctxs(Pool().Acquire(want, per_device, &device_of, polite)) {}
   ~Lease() { Pool().Release(ctxs); }
 };
 
@@ -334,18 +352,29 @@ int RunPartsShardedOnce(const ZopfliOptions& options, int btype, const unsigned 
   //  each device — measured on 100 MB of text: 2 ways 123.2 ms, 3 ways 121.1, 4 ways 140; with block splitting 225 / 197 / 231;
   //  0 = never.  The GPU idles while the host computes a hundred cost models between two squeeze runs — 6 % of a
   //  100 MB call — and through the whole block-split search; two halves fill each other's gaps.)
-  static const size_t split_from = [] {
+  // Round 5, from how many master blocks on (profiles/r05_split_from.txt): with block splitting from 4 — the contexts'
+  // split searches fall beside each other's kernels: 4 MB of text 33.7 -> 29.2 ms, 8 MB 46.5 -> 37.4, 12 MB 59.8 -> 43.6,
+  // 24 MB 97.4 -> 62.8 (it was 32 until then); without block splitting it is worth 3 - 6 % from 12 MB on and nothing
+  // below: from 16.
+  static const long split_from_env = [] {
     const char* e = std::getenv("ZOPFLI_AMD_SPLIT_MB");
-    return e ? static_cast<size_t>(std::max(0, std::atoi(e))) : static_cast<size_t>(32);
+    return e ? static_cast<long>(std::max(0, std::atoi(e))) : -1L;
   }();
+  const size_t split_from = split_from_env >= 0 ? static_cast<size_t>(split_from_env)
+                                                : (options.blocksplitting && btype == 2 ? 4 : 16);
   static const size_t split_ways = [] {
     const char* e = std::getenv("ZOPFLI_AMD_SPLIT_WAYS");
     return e ? static_cast<size_t>(std::max(1, std::atoi(e))) : static_cast<size_t>(3);
   }();
-  // Not on data with long runs of equal bytes: there the squeeze runs wait for a few very long single-wave tasks
-  // (zmx_dp5.h), and a second context's tasks on the same SIMDs slow exactly those (class Z: 61 -> 35 MB/s).  Sampled:
-  // one probe every 4096 bytes, "the next 64 bytes are equal"; 1 % of the probes is enough to stay on one context.
-  bool runs = false;
+  // Data with long runs of equal bytes: there the squeeze runs wait for a few very long single-wave tasks (zmx_dp5.h)
+  // and most of the device idles — but a second context's tasks on the same SIMDs slow exactly those tasks (round 3,
+  // class Z: 61 -> 35 MB/s on two contexts, so such data stayed on one).  Round 5: dealt all the same, with the contexts
+  // at three stream PRIORITIES (as calls with block splitting are, below): the first context's long tasks win their
+  // SIMDs, the others fill what it leaves — class Z 131 -> 190 MB/s, class M 165 -> 245 (189 / 245 on four, 187 / 250 on
+  // six contexts; without the priorities 112 / 170; profiles/r05_runs_ctx.txt).  Sampled: one probe every 4096 bytes,
+  // "the next 64 bytes are equal"; 1 % of the probes make a call "data with runs".
+  // (ZOPFLI_AMD_SPLIT_RUNS=0 or ZOPFLI_AMD_STREAM_PRIO=0: such data on one context, as before — for measuring)
+  bool runs = false, one_context = false;
   if (split_from && parts.size() >= split_from && in != nullptr) {
     const size_t lo = parts.front().instart, hi = parts.back().inend;
     size_t probes = 0, hits = 0;
@@ -356,16 +385,13 @@ int RunPartsShardedOnce(const ZopfliOptions& options, int btype, const unsigned 
       hits += k == 64;
     }
     runs = probes > 0 && hits * 100 >= probes;
-    // (With block splitting the contexts run in turn — stream priorities, below — and a second context disturbs the
-    //  first's long tasks less than it hides of its split searches, as long as the runs are a part of the data: a mixed
-    //  corpus with 13 % long-run master blocks 133 -> 142 MB/s; data that is all runs stays on one context: 130 -> 127.)
-    static const bool prio_on = [] { const char* e = std::getenv("ZOPFLI_AMD_STREAM_PRIO"); return !e || std::atoi(e) != 0; }();
-    if (runs && prio_on && options.blocksplitting && btype == 2 && hits * 100 < probes * 30) runs = false;
-    static const bool split_runs = [] { const char* e = std::getenv("ZOPFLI_AMD_SPLIT_RUNS"); return e && std::atoi(e) != 0; }();
-    if (split_runs) runs = false;      // (ZOPFLI_AMD_SPLIT_RUNS=1: deal such data over two contexts all the same — for measuring)
+    static const int prio_on = [] { const char* e = std::getenv("ZOPFLI_AMD_STREAM_PRIO"); return e ? std::atoi(e) : 1; }();
+    static const bool split_runs = [] { const char* e = std::getenv("ZOPFLI_AMD_SPLIT_RUNS"); return !e || std::atoi(e) != 0; }();
+    one_context = runs && !(prio_on && split_runs);
   }
   const double tr_begin = WallMs();
-  const Lease lease(parts.size(), split_from && parts.size() >= split_from && !runs ? split_ways : 1);
+  const Lease lease(parts.size(), split_from && parts.size() >= split_from && !one_context ? split_ways : 1,
+                    /*polite=*/parts.size() < 32);
   const double tr_lease = WallMs();
   const std::vector<zmx_ctx*>& ctxs = lease.ctxs;
   const size_t ndev = std::min(ctxs.size(), parts.size());
@@ -439,9 +465,11 @@ int RunPartsShardedOnce(const ZopfliOptions& options, int btype, const unsigned 
   // With block splitting the contexts of one device run at three stream priorities — one after the other instead of
   // side by side: their split searches and joins then fall beside the others' kernels (zmx_ctx_set_priority; 100 MB of
   // text 152 -> 145 ms, without block splitting 123 -> 130: there every context stays on its default streams).
-  static const bool use_priorities = [] { const char* e = std::getenv("ZOPFLI_AMD_STREAM_PRIO"); return !e || std::atoi(e) != 0; }();
+  // Data with runs: with or without block splitting (above).
+  // (ZOPFLI_AMD_STREAM_PRIO=0: never; 2: always — for measuring)
+  static const int use_priorities = [] { const char* e = std::getenv("ZOPFLI_AMD_STREAM_PRIO"); return e ? std::atoi(e) : 1; }();
   std::vector<int> shard_priority(ndev, 0);
-  if (use_priorities && options.blocksplitting && btype == 2) {
+  if (use_priorities && ((options.blocksplitting && btype == 2) || runs || use_priorities == 2)) {
     for (size_t d = 0; d < ndev; ++d) {
       size_t before = 0, same = 0;
       for (size_t e = 0; e < ndev; ++e) {

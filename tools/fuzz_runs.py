@@ -16,6 +16,9 @@ import oracle_lib as ol  # noqa: E402
 from zopfli_amd import ZopfliOptions, api, generate  # noqa: E402
 
 TEXTY = os.environ.get("FUZZ_TEXT", "0") != "0"
+# FUZZ_SIZES="4200000,6100000,17000000": calls of several master blocks — with ZOPFLI_AMD_DEAL_AFTER=0 they are dealt over
+# three contexts of the device at three stream priorities (api.cc), from 4 master blocks on with block splitting, 16 without
+SIZES = [int(x) for x in os.environ.get("FUZZ_SIZES", "70000,300000,1000000,1000001,1200000,2100000").split(",")]
 EDGES = [1, 2, 3, 4, 31, 32, 33, 63, 64, 65, 127, 128, 129, 257, 258, 259, 260, 289, 290, 515, 516, 517, 518, 773, 774, 775,
          1023, 1024, 1025, 1031, 1032, 1033, 2047, 2048, 2049]
 
@@ -56,9 +59,9 @@ def main():
     lib = api.library()
     bad = 0
     for k in range(cases):
-        size = rng.choice([70000, 300000, 1000000, 1000001, 1200000, 2100000])
+        size = rng.choice(SIZES)
         data = make_case(rng, size)
-        n = rng.choice([3, 3, 15])
+        n = rng.choice([3, 3, 15]) if size < 3000000 else rng.choice([1, 2, 3])
         bs = rng.choice([0, 1])
         ref = ol.ref_compress(data, 0, n, bs, 15)
         mine = api.compress(data, 0, ZopfliOptions(n, bs, 15), lib=lib)

@@ -21,5 +21,6 @@ except Exception as e: print("ERR", e)
 PY
 timeout 200 python tools/latency.py > $OUT/latency.jsonl 2> $OUT/latency.err; cut -c1-200 $OUT/latency.jsonl
 TMPDIR=/tmp timeout -k 5 400 python tools/png_at_size.py 4096 --ref > $OUT/png4096_same_host.json 2> $OUT/png4096.err; cat $OUT/png4096_same_host.json
+[ "${PROFILES:-1}" = 1 ] || exit 0     # (PROFILES=0: the device sources are those of the last profile set)
 BENCH_ARGS="--steps 1 --warmup 0 --no-cpu-baseline --entry resident --no-blocksplitting1" TAG=${TAG:-r05_final}/prof bash tools/collect_profiles.sh > $OUT/profiles.txt 2>&1; tail -30 $OUT/profiles.txt | cut -c1-250
 BENCH_ARGS="--cls Z --steps 1 --warmup 0 --no-cpu-baseline --entry resident --no-blocksplitting1" TAG=${TAG:-r05_final}/profZ bash tools/collect_profiles.sh > $OUT/profilesZ.txt 2>&1; tail -12 $OUT/profilesZ.txt | cut -c1-250

@@ -920,6 +920,9 @@ __device__ __forceinline__ void d4_run_job(const Dp4Params& P, const D4Job& J, u
 
 // exit[t - 1] against entry[t] for every task but the heads: one wave per task
 __global__ __launch_bounds__(64) void k_dpcheck(Dp4Params P) {
+  // (k_dpscan's list of tasks to run again starts empty: every k_dpscan follows a k_dpcheck, and whoever reads the
+  //  counter — the redo pass of k_dp5_spec — has run by the time the next k_dpcheck starts)
+  if (blockIdx.x == 0 && threadIdx.x == 0) *P.redo_count = 0;
   const u32 t = P.task0 + blockIdx.x;
   if (P.tasks[t].pout == 0) return;
   const SegCheck r = d4_check(&P.exit[t - 1], &P.entry[t], threadIdx.x);

@@ -187,6 +187,7 @@ struct zmx_tables {
   u64* d_block_edges = nullptr;   // per block: DP edges
   u32* d_badpos = nullptr;        // bit per position: it owns a match edge below mincost (k_badscan, per run)
   size_t badpos_words = 0;
+  bool badpos_clean = false;      // the bitmap is all zero (no run since the last memset has marked a position)
   u64* d_code_base = nullptr;     // per block: first slot in d_codes
   u16* d_codes = nullptr;         // the DP edges as weight codes (k_codes)
   double* d_wtab = nullptr;       // [nb][ZMX_WTAB] the weights of the current run (k_wtab)
@@ -1554,7 +1555,8 @@ int zmx_lz77_greedy(zmx_ctx* c, zmx_tables* t, int slot, uint32_t* nsym, uint32_
 // an upper bound of every edge weight, the binades in which a weight can tie in the float rounding,
 // and a first guess of the block's cost.  The weights are the 256 literal costs and
 // ((lbits + dbits) + ll[lsym]) + d[dsym] for the 29 x 30 symbol pairs (squeeze.c:155).
-static void RunInfo(const double* cost, const u32* hist, u32 B, float* wmax_out, u32* tiemask_out, float* est_out) {
+static void RunInfo(const double* cost, const u32* hist, u32 B, float* wmax_out, u32* tiemask_out, float* est_out,
+                    double mincost = 0.0, bool* below_mincost = nullptr) {
   const double* ll = cost;
   const double* d = cost + ZMX_NUM_LL;
   auto lbits = [](int s) { return s < 265 || s == 285 ? 0 : (s - 261) / 4; };
@@ -1566,6 +1568,13 @@ static void RunInfo(const double* cost, const u32* hist, u32 B, float* wmax_out,
     for (int ds = 0; ds < 30; ++ds) w[n++] = (static_cast<double>(lbits(ls) + dbits(ds)) + ll[ls]) + d[ds];
   double wmax = 0;
   for (int i = 0; i < n; ++i) wmax = std::max(wmax, w[i]);
+  // a match weight below mincost (possible only through rounding in the cost model): k_wtab finds the same ones with
+  // the same arithmetic, and only then do k_badscan and its bitmap have anything to do (zmx_squeeze_run)
+  if (below_mincost) {
+    bool any = false;
+    for (int i = 256; i < n; ++i) any |= w[i] < mincost;
+    *below_mincost = any;
+  }
   // dbl(w + c) = c + RNE(w / 2^(e-52)) 2^(e-52) for a float c of binade e; the float rounding of that
   // sum ties iff the remainder modulo the float ulp 2^(e-23) is exactly half of it, i.e. iff
   // r = RNE(w 2^(52-e)) has r mod 2^29 = 2^28.  Integer arithmetic on the mantissa: w = m 2^x.
@@ -1634,6 +1643,7 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     if (slot[b] != 0 && slot[b] != 1) return FailMsg("zmx_squeeze_run: slot must be 0 or 1");
   }
   const size_t nb = t->nb;
+  bool any_below_mincost = false;
   // the run's input in the pinned mirror: costs, mincosts, slots, and per block what the chain's acceptance test has
   // to know about this cost model (RunInfo)
   {
@@ -1647,9 +1657,13 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     std::memcpy(h_min, mincost, nb * sizeof(double));
     std::memcpy(h_slot, slot, nb * sizeof(int));
     const u32* hh = t->have_hist ? t->h_hist.data() : nullptr;
+    std::vector<char> below(nb, 0);
     zamd::ParallelFor(nb, [&](size_t b) {
-      RunInfo(cost + b * ZMX_HIST, hh ? hh + b * ZMX_HIST : nullptr, t->bsize[b], &wmax[b], &tiemask[b], &est[b]);
+      bool bad = false;
+      RunInfo(cost + b * ZMX_HIST, hh ? hh + b * ZMX_HIST : nullptr, t->bsize[b], &wmax[b], &tiemask[b], &est[b], mincost[b], &bad);
+      below[b] = bad ? 1 : 0;
     });
+    for (size_t b = 0; b < nb; ++b) any_below_mincost |= below[b] != 0;
   }
   HIPCHK(hipMemcpyAsync(t->d_runin, t->h_runin, t->runin_bytes, hipMemcpyHostToDevice, c->stream));
   static const bool want_prof = std::getenv("ZOPFLI_AMD_PROF") != nullptr;
@@ -1660,6 +1674,7 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   wp.mincost = t->d_mincost;
   wp.wtab = t->d_wtab;
   wp.badcodes = t->d_badcodes;
+  wp.stats = t->d_segstats;
   BadScanParams bp;
   bp.blocks = t->d_blocks;
   bp.tile_off = t->d_tile_off;
@@ -1720,7 +1735,12 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   cp.winroff = t->d_winroff;
   cp.winflag = t->d_winflag;
   cp.win_off = t->d_win_off;
-  HIPCHK(hipMemsetAsync(t->d_badpos, 0, t->badpos_words * sizeof(u32), c->stream));
+  // k_badscan's bitmap: all zero unless some block of this run has a match weight below mincost (RunInfo) — nearly never,
+  // and then neither the memset nor the scan is launched (two of a run's ~20 stream operations; a small call is mostly
+  // the gaps between them)
+  const bool scan_bad = any_below_mincost;
+  if (scan_bad || !t->badpos_clean) HIPCHK(hipMemsetAsync(t->d_badpos, 0, t->badpos_words * sizeof(u32), c->stream));
+  t->badpos_clean = !scan_bad;
   TraceSegParams tp;
   tp.blocks = t->d_blocks;
   tp.seg_off = t->d_seg_off;
@@ -1748,7 +1768,7 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     // the run's weights per block, and (rarely) the positions that own an edge below mincost
     hipLaunchKernelGGL(k_wtab, dim3(nblk), dim3(256), 0, c->stream, wp);
     KCHK(c, "k_wtab");
-    if (tiles) hipLaunchKernelGGL(k_badscan, dim3(tiles), dim3(256), 0, c->stream, bp);
+    if (tiles && scan_bad) hipLaunchKernelGGL(k_badscan, dim3(tiles), dim3(256), 0, c->stream, bp);
     KCHK(c, "k_badscan");
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
@@ -1787,7 +1807,7 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
       //  87 / 92 / 93 % accepted with 1 / 2 / 3 — but every pass waits for its longest task: 1 264 / 1 362 / 1 601 ms)
       static const int redo = [] { const char* e = std::getenv("ZOPFLI_AMD_SEG_REDO"); return e ? std::atoi(e) : 1; }();
       for (int pass = 0; pass < redo; ++pass) {
-        HIPCHK(hipMemsetAsync(t->d_redo, 0, sizeof(u32), c->stream));
+        // (the list's counter was zeroed by the k_dpcheck before: zmx_dp4.h)
         hipLaunchKernelGGL(k_dpscan, dim3(nblk), dim3(64), 0, c->stream, cp);
         KCHK(c, "k_dpscan");
         Dp4Params c2 = cp;
@@ -1827,17 +1847,18 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     KCHK(c, "k_trace_emit");
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[3], c->stream));
-    HIPCHK(hipEventSynchronize(c->ev[3]));
-    for (int i = 0; i < 3; ++i) {
-      float ms = 0;
-      HIPCHK(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
-      ksec[i] += ms * 1e-3;
-    }
   }
+  // ONE host round trip per run: the results travel behind the last kernel, the host waits for the copy and reads the
+  // phase times then (waiting for ev[3] first and only then asking for the copy was two).  The task statistics are
+  // zeroed by the next run's k_wtab.
   u32 segstats[8];
   HIPCHK(hipMemcpyAsync(t->h_runout, t->d_runout, t->runout_bytes, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipMemsetAsync(t->d_segstats, 0, sizeof(segstats), c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < 3; ++i) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+    ksec[i] += ms * 1e-3;
+  }
   {
     const u32* o_hist = reinterpret_cast<const u32*>(t->h_runout);
     const u32* o_nsym = o_hist + nb * ZMX_HIST;

@@ -606,12 +606,14 @@ struct WtabParams {
   const double* mincost;   // [nb]
   double* wtab;            // [nb][ZMX_WTAB]
   u32* badcodes;           // [nb][40]: word 0 = number of weights below mincost, words 4.. = their bitmap
+  u32* stats;              // the run's 8 task statistics (k_dp4_fix adds to them): zeroed here, the run's first kernel
 };
 
 __global__ __launch_bounds__(256) void k_wtab(WtabParams P) {
   __shared__ u32 s_bad[40];
   const u32 b = blockIdx.x, tid = threadIdx.x;
   if (tid < 40) s_bad[tid] = 0;
+  if (b == 0 && tid < 8 && P.stats) P.stats[tid] = 0;
   __syncthreads();
   const double* ll = P.cost + (u64)b * 320;
   const double* d = ll + 288;

@@ -267,6 +267,38 @@ def test_rounds_of_master_blocks():
     assert res["rounds"][0] == hashlib.sha256(ol.ref_compress(data, 0, 1)).hexdigest()
 
 
+def test_calls_of_few_master_blocks_are_dealt_from_the_nth_on():
+    """api.cc ContextPool::Acquire, `polite`: a call below 32 master blocks is dealt over three contexts of its device
+    (from 4 master blocks on with block splitting), but the contexts beyond the first are only created from the process's
+    ZOPFLI_AMD_DEAL_AFTER-th such call on (8 by default: setting a context up costs more than a short-lived program gets
+    back).  With 3: the call trace shows one shard for the first two calls and three for the third and fourth; all four
+    streams are the reference's."""
+    import subprocess
+    import sys
+    code = (
+        "import hashlib, sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import oracle_lib as ol\n"
+        "from zopfli_amd import ZopfliOptions, api\n"
+        "host = ol.hosttest_library()\n"
+        "data = bytes(4100000)\n"
+        "for k in range(4):\n"
+        "    print(hashlib.sha256(api.compress(data, 0, ZopfliOptions(1), lib=host)).hexdigest())\n"
+        "    sys.stderr.write('== call %%d done\\n' %% k)\n"
+        % (os.path.dirname(os.path.dirname(__file__)), os.path.dirname(__file__)))
+    env = dict(os.environ, ZOPFLI_AMD_DEAL_AFTER="3", ZOPFLI_AMD_TRACE_CALL="1")
+    for k in ("LOCAL_RANK", "ZOPFLI_AMD_DEVICES", "ZOPFLI_AMD_SPLIT_MB"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    digests = r.stdout.split()
+    assert len(digests) == 4 and len(set(digests)) == 1
+    assert digests[0] == hashlib.sha256(ol.ref_compress(bytes(4100000), 0, 1)).hexdigest()
+    per_call = r.stderr.split("== call ")
+    shards = [seg.count("shard 2 (") for seg in per_call[:4]]
+    assert shards == [0, 0, 1, 1], (shards, r.stderr[-3000:])
+
+
 @pytest.mark.parametrize("fail", [0, 1, 2])
 def test_failed_shard_is_done_again_on_another_context(fail):
     """A shard of a request that fails (ZOPFLI_AMD_TEST_FAIL_SHARD: its first attempt returns an error before it does

@@ -45,16 +45,24 @@ using zamd::kMasterBlock;
   std::exit(EXIT_FAILURE);
 }
 
-// ZOPFLI_AMD_KEEP_HEAP=1: freed host memory stays with the process (glibc: no mmap for large blocks, no trimming).
-// With block splitting the symbols of every block pass through host vectors (hundreds of MB per 100 MB of input),
-// and every munmap of a process with a few hundred worker threads is a TLB shootdown on all their CPUs: on
-// incompressible input (one symbol per byte) returning that memory took as long as the compression.  Opt-in: it
-// changes the allocator of the whole process.
+// Freed host memory stays with the process: glibc neither trims its arenas nor shrinks the worker threads' heaps
+// (M_TRIM_THRESHOLD, M_TOP_PAD; blocks above the mmap threshold are still mapped and returned one by one).  The symbols
+// of every block pass through host vectors — hundreds of MB per 100 MB of input with block splitting — and with a few
+// dozen worker threads every heap that shrinks is a munmap / madvise with a TLB shootdown on all their CPUs: on
+// incompressible input returning that memory once took as long as the compression.  Round 5, 100 MB, one box: text 806 ->
+// 825 MB/s, with block splitting 656 -> 755; random data 712 -> 751 and 343 -> 374 (profiles/r05_keep_heap.txt); it was
+// opt-in until then because it changes a setting of the whole process's allocator — what it costs the host program is
+// that small blocks it frees are kept for reuse instead of being handed back to the kernel.
+// ZOPFLI_AMD_KEEP_HEAP=0: leave malloc alone.
 void MaybeKeepHeap() {
   static const bool once = [] {
     const char* e = std::getenv("ZOPFLI_AMD_KEEP_HEAP");
-    if (e && std::atoi(e) != 0) {
-      mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    if (e && std::atoi(e) == 0) return true;
+    if (e && std::atoi(e) == 2) {          // (for measuring: large blocks from the heap too — 32 MB is the most glibc takes; no better)
+      mallopt(M_MMAP_THRESHOLD, 32 << 20);
+      mallopt(M_TRIM_THRESHOLD, 1 << 30);
+      mallopt(M_TOP_PAD, 64 << 20);
+    } else {
       mallopt(M_TRIM_THRESHOLD, 1 << 30);
       mallopt(M_TOP_PAD, 256 << 20);
     }

@@ -58,7 +58,7 @@ void MaybeKeepHeap() {
   static const bool once = [] {
     const char* e = std::getenv("ZOPFLI_AMD_KEEP_HEAP");
     if (e && std::atoi(e) == 0) return true;
-    if (e && std::atoi(e) == 2) {          // (for measuring: large blocks from the heap too — 32 MB is the most glibc takes; no better)
+    if (e && std::atoi(e) == 2) {          // (for measuring: large blocks from the heap too — 32 MB is the most glibc takes; no better, nor is 1 MB)
       mallopt(M_MMAP_THRESHOLD, 32 << 20);
       mallopt(M_TRIM_THRESHOLD, 1 << 30);
       mallopt(M_TOP_PAD, 64 << 20);

@@ -163,7 +163,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=100 * MB, help="bytes per GPU (default: the 100 MB workload)")
-    ap.add_argument("--blocksplitting", type=int, default=0, help="0 = configs[1] (default), 1 = configs[2]")
+    ap.add_argument("--blocksplitting", type=int, default=None, help="0 = configs[1] (the default at N = 1), 1 = configs[2] "
+                    "(the default of the N > 1 headline)")
     ap.add_argument("--cls", default="T", choices=list("TXRZBPM"),
                     help="synthetic input class (zopfli_amd/csrc/tools/datagen.c): T text-like (default, enwik8 "
                          "stand-in), X markup-like, M mixed corpus (Silesia stand-in), ...")
@@ -175,9 +176,11 @@ def main():
     ap.add_argument("--gather", default="rccl-c", choices=["rccl-c", "torch"],
                     help="who gathers the ranks' blobs at N>1: the library's own RCCL gather (zmx_dist_*, dist.cc; "
                          "falls back to torch.distributed if it cannot start) or torch.distributed's gather")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N>1: weak = --size bytes per GPU (default), strong = --size bytes in total "
-                         "(BASELINE configs[2]: one 100 MB stream sharded by master block)")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="N>1: strong = --size bytes in total (BASELINE configs[2]: one 100 MB stream sharded by master "
+                         "block), weak = --size bytes per GPU.  Default at N > 1: the strong line with the reference's "
+                         "default block splitting is the headline and the weak line (blocksplitting 0, 100 MB per GPU) "
+                         "rides along under `weak`")
     ap.add_argument("--device-index", type=int, default=None, help="HIP device of this rank (default LOCAL_RANK)")
     ap.add_argument("--entry", default="both", choices=["both", "zopfli_compress", "resident"],
                     help="N = 1: which way into the library is timed (default both: `value` = ZopfliCompress, "
@@ -193,11 +196,24 @@ def main():
     if args.devices:
         os.environ["ZOPFLI_AMD_DEVICES"] = args.devices
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as typed: start the N ranks ourselves (one process per GPU, 127.0.0.1 rendezvous)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import copy
 
     import torch
     import torch.distributed as dist
@@ -220,6 +236,82 @@ def main():
     if local_world > 1 and "ZOPFLI_AMD_THREADS" not in os.environ:
         os.environ["ZOPFLI_AMD_THREADS"] = str(max(8, min(64, (os.cpu_count() or 64) // local_world)))
     lib = api.library()
+
+    # ---- the gather: the library's own RCCL gather unless it cannot start (one communicator for the whole run)
+    cdist = None
+    comm_ctx = None
+    gather_kind = "none (one rank)"
+    if world > 1:
+        gather_kind = "torch.distributed " + args.backend
+        if args.gather == "rccl-c" and args.backend == "nccl":
+            from zopfli_amd import Dist
+            comm_ctx = Context(dev_index, lib)
+            err = ""
+            uid = [None]
+            try:
+                if rank == 0:
+                    uid[0] = Dist.unique_id(lib)
+            except RuntimeError as e:   # e.g. librccl missing
+                err = str(e)
+            dist.broadcast_object_list(uid, src=0)
+            ok = 0
+            if uid[0] is not None:
+                try:
+                    cdist = Dist(comm_ctx, rank, world, uid[0])
+                    ok = 1 if cdist.comm_count() == world else 0   # RCCL itself must have seen N ranks
+                    if not ok:
+                        err = "ncclCommCount = %d, expected %d" % (cdist.comm_count(), world)
+                except RuntimeError as e:
+                    err = str(e)
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                gather_kind = ("library RCCL (zmx_dist_gather: ncclAllGather sizes + grouped ncclSend/ncclRecv; "
+                               "ncclCommCount = %d)" % world)
+            else:
+                if cdist is not None:
+                    cdist.close()
+                cdist = None
+                gather_kind += " (library RCCL gather unavailable: %s)" % err
+
+    def run_one(args):
+        """One measured configuration (args.scaling / args.blocksplitting resolved); the JSON line on rank 0."""
+        return _run_one(args, rank, world, dev_index, device, torch, dist, lib, cdist, gather_kind)
+
+    if world == 1 or args.scaling is not None:
+        a = copy.copy(args)
+        a.scaling = a.scaling or "weak"
+        a.blocksplitting = 0 if a.blocksplitting is None else a.blocksplitting
+        line = run_one(a)
+    else:
+        # N > 1 as the driver types it: BASELINE configs[2] is the headline — ONE stream of --size bytes, the reference's
+        # default block splitting, its master blocks sharded over the N ranks (strong scaling) — and the weak line
+        # (--size bytes per GPU, blocksplitting 0: N x configs[1]) rides along
+        a = copy.copy(args)
+        a.scaling = "strong"
+        a.blocksplitting = 1 if a.blocksplitting is None else a.blocksplitting
+        line = run_one(a)
+        w = copy.copy(args)
+        w.scaling = "weak"
+        w.blocksplitting = 0
+        w.no_in_process = True
+        w.no_cpu_baseline = True
+        wline = run_one(w)
+        if rank == 0:
+            line["weak"] = {k: wline[k] for k in ("value", "unit", "ms_per_step", "scaling", "steps", "config", "output_bytes",
+                                                  "roundtrip_ok", "roofline", "roofline_match", "breakdown_s_per_step")}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if cdist is not None:
+        cdist.close()
+    if comm_ctx is not None:
+        comm_ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def _run_one(args, rank, world, dev_index, device, torch, dist, lib, cdist, gather_kind):
+    from zopfli_amd import Context, ZopfliOptions, api, generate, sharding
     options = ZopfliOptions(args.numiterations, args.blocksplitting, 15)
     size = args.size
     strong = args.scaling == "strong" and world > 1
@@ -267,37 +359,6 @@ def main():
     ctx.set_input(resident)  # H2D, outside the timed region
     instart, inend = len(prefix), len(resident)
     final = 1 if rank == last_rank else 0
-    # ---- the gather: the library's own RCCL gather unless it cannot start
-    cdist = None
-    gather_kind = "none (one rank)"
-    if world > 1:
-        gather_kind = "torch.distributed " + args.backend
-        if args.gather == "rccl-c" and args.backend == "nccl":
-            from zopfli_amd import Dist
-            err = ""
-            uid = [None]
-            try:
-                if rank == 0:
-                    uid[0] = Dist.unique_id(lib)
-            except RuntimeError as e:   # e.g. librccl missing
-                err = str(e)
-            dist.broadcast_object_list(uid, src=0)
-            ok = 0
-            if uid[0] is not None:
-                try:
-                    cdist = Dist(ctx, rank, world, uid[0])
-                    ok = 1
-                except RuntimeError as e:
-                    err = str(e)
-            flag = torch.tensor([ok], dtype=torch.int32, device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                gather_kind = "library RCCL (zmx_dist_gather: ncclAllGather sizes + grouped ncclSend/ncclRecv)"
-            else:
-                if cdist is not None:
-                    cdist.close()
-                cdist = None
-                gather_kind += " (library RCCL gather unavailable: %s)" % err
     header = bytes([31, 139, 8, 0, 0, 0, 0, 0, 2, 3])
 
     def gather_blobs(blob):
@@ -419,11 +480,12 @@ def main():
     #      (ZOPFLI_AMD_DEVICES = N: api.cc RunPartsSharded deals the master blocks over them and merges) — what a
     #      program that links libzopfli.so.1 gets on a multi-GPU node without any launcher.  Rank 0 runs it after the
     #      RCCL measurement while the other ranks wait; its stream must equal the gathered one.
+    line = None
     in_process = None
     if world > 1 and not args.no_in_process:
         if rank == 0:
             try:
-                os.environ["ZOPFLI_AMD_DEVICES"] = str(world)    # (this process has not used the entry points yet)
+                os.environ["ZOPFLI_AMD_DEVICES"] = args.devices or str(world)    # (this process has not used the entry points yet)
                 if strong:
                     whole_in = corpus[:size] if corpus is not None else generate(args.cls, size, seed=seed0)
                 elif corpus is not None:
@@ -506,7 +568,7 @@ def main():
         copy_gbs = measured_copy_gbs(torch, device) if world == 1 else None
         roofline = None
         if launches > 0 and ksec > 0:
-            per_launch_bytes = 31.0 * size
+            per_launch_bytes = 31.0 * len(shard)   # (this rank's positions: the whole input at N = 1)
             achieved = per_launch_bytes / (ksec / launches) / 1e9
             # HBM bytes per launch from the rocprofv3 PMC passes of this exact workload (FETCH_SIZE x 2 +
             # WRITE_SIZE, MI355X_MICROARCH.md): only reported when the committed profile was taken on the
@@ -639,20 +701,17 @@ def main():
                           "blocksplittingmax=15 (configs[2] on one GPU)"}
         if in_process is not None:
             line["in_process"] = in_process
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
+            # (rank 0's host cores; at N > 1 the other ranks wait at the next collective meanwhile)
             sample = shard[:min(args.cpu_sample, size)]
             res = cpu_baseline(sample, options)
             if res:
                 line["cpu_baseline"] = res[0]
-            allc = cpu_baseline_all_cores(shard, options)
+            allc = cpu_baseline_all_cores(shard, options) if world == 1 else None
             if allc:
                 line["cpu_baseline_all_cores"] = allc
-        print(json.dumps(line), flush=True)
-    if cdist is not None:
-        cdist.close()
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
+    return line if rank == 0 else None
 
 
 if __name__ == "__main__":

@@ -138,6 +138,22 @@ typedef struct zmx_block {
 int zmx_device_count(void);
 /* The message of the last failed zmx_* call on the calling thread. */
 const char* zmx_last_error(void);
+/* ... and what kind of failure it was.  Callers that decide whether doing the work again elsewhere can help (api.cc: a
+ * failed shard is done again on another context) go by this code, never by the message's text. */
+#define ZMX_ERR_NONE 0
+#define ZMX_ERR_DEVICE 1         /* a HIP call failed or the device misbehaved: another context / device may fare better */
+#define ZMX_ERR_OUT_OF_MEMORY 2  /* hipErrorOutOfMemory: likewise (another context may have the room) */
+#define ZMX_ERR_REFUSED 3        /* the request itself is refused — bad arguments, a size limit, a pool that still
+                                    overflows after the device layer's own retries: it would fail the same way anywhere */
+int zmx_last_error_class(void);
+/* The host arrays of a call (symbol stores, bit buffers) take their memory from a cache of large blocks the library keeps
+ * between calls (at most ZOPFLI_AMD_HOST_CACHE_MB, default 1024; zopfli_amd/csrc/host/block_cache.h) instead of changing
+ * the host process's malloc settings.  This frees everything cached and returns the number of bytes given back. */
+size_t zmx_host_cache_trim(void);
+/* 1 in a build with -DZMX_EXPERIMENTS: the kernels that lost their measurement (k_bucket + k_match3 / k_match4, the four-wave
+ * run task k_dp6_spec) are compiled in and selectable (zmx_set_match_kernel 3 / 4, ZOPFLI_AMD_COOP=1); 0 in the shipped
+ * library, which does not contain them. */
+int zmx_has_experiments(void);
 
 int zmx_ctx_create(int device, zmx_ctx** ctx);
 void zmx_ctx_destroy(zmx_ctx* ctx);
@@ -304,6 +320,8 @@ int zmx_dist_unique_id(unsigned char* id128);
 /* Collective: the communicator of `world` ranks, this process being `rank` on ctx's device. */
 int zmx_dist_init(zmx_ctx* ctx, int rank, int world, const unsigned char* id128, zmx_dist** dist);
 void zmx_dist_destroy(zmx_dist* dist);
+/* The number of ranks RCCL itself reports for the communicator (ncclCommCount), or -1. */
+int zmx_dist_comm_count(zmx_dist* dist);
 /* Collective: every rank contributes `size` bytes.  On rank 0 *gathered is a malloc'ed buffer holding
  * the blobs of rank 0, 1, ... back to back and sizes[r] their lengths (sizes has `world` entries);
  * elsewhere *gathered = NULL and sizes is not written. */

@@ -47,6 +47,8 @@ int zmx_device_count(void) {
   return e ? std::atoi(e) : 1;
 }
 const char* zmx_last_error(void) { return g_err.c_str(); }
+int zmx_has_experiments(void) { return 0; }
+int zmx_last_error_class(void) { return g_err.empty() ? ZMX_ERR_NONE : ZMX_ERR_DEVICE; }
 void zmx_internal_set_error(const char* msg) { g_err = msg; }
 
 int zmx_ctx_create(int, zmx_ctx** ctx) {
@@ -79,6 +81,7 @@ int zmx_png_filter_types(zmx_ctx*, const unsigned char*, size_t, size_t, size_t,
 int zmx_dist_unique_id(unsigned char*) { g_err = "no RCCL in the host test library"; return -1; }
 int zmx_dist_init(zmx_ctx*, int, int, const unsigned char*, zmx_dist**) { g_err = "no RCCL in the host test library"; return -1; }
 void zmx_dist_destroy(zmx_dist*) {}
+int zmx_dist_comm_count(zmx_dist*) { return -1; }
 int zmx_dist_gather(zmx_dist*, const unsigned char*, size_t, unsigned char**, size_t*) { g_err = "no RCCL in the host test library"; return -1; }
 
 int zmx_tables_build(zmx_ctx* ctx, const zmx_block* blocks, size_t nblocks, zmx_tables** tables) {

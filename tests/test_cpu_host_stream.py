@@ -326,6 +326,49 @@ def test_failed_shard_is_done_again_on_another_context(fail):
     assert "done again on another context" in res["failing"][1]
 
 
+def test_retry_goes_by_error_class_not_by_text():
+    """The injected failure's MESSAGE holds "pool" and "too large" — the words round 5's filter skipped — and is still done
+    again (above: every case passes); what decides is zmx_last_error_class (include/zopfli_amd.h), whose values the
+    header pins."""
+    import re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "include", "zopfli_amd.h")).read()
+    vals = {k: int(v) for k, v in re.findall(r"#define (ZMX_ERR_[A-Z_]+) (\d+)", hdr)}
+    assert vals == {"ZMX_ERR_NONE": 0, "ZMX_ERR_DEVICE": 1, "ZMX_ERR_OUT_OF_MEMORY": 2, "ZMX_ERR_REFUSED": 3}
+    src = open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "zopfli_amd", "csrc", "host", "api.cc")).read()
+    assert 'err.find("pool")' not in src and "err_class == ZMX_ERR_REFUSED" in src
+
+
+def test_host_block_cache_and_no_mallopt():
+    """The library keeps its large host arrays in a cache of its own (block_cache.h) instead of reconfiguring the host
+    process's malloc: after a call with block splitting zmx_host_cache_trim() gives bytes back, a second trim nothing;
+    with ZOPFLI_AMD_HOST_CACHE_MB=0 nothing is ever cached; the streams are the same; and mallopt is reached only with
+    ZOPFLI_AMD_KEEP_HEAP set (mallinfo2's arena does not jump by the 256 MB top pad round 5 asked for)."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes, hashlib, sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import oracle_lib as ol\n"
+        "from zopfli_amd import ZopfliOptions, api, generate\n"
+        "host = ol.hosttest_library()\n"
+        "host.zmx_host_cache_trim.restype = ctypes.c_size_t\n"
+        "data = generate('T', 1200000)\n"
+        "out = api.compress(data, 0, ZopfliOptions(1, 1, 15), lib=host)\n"
+        "a = host.zmx_host_cache_trim(); b = host.zmx_host_cache_trim()\n"
+        "print(hashlib.sha256(out).hexdigest(), a, b)\n"
+        % (os.path.dirname(os.path.dirname(__file__)), os.path.dirname(__file__)))
+    res = {}
+    for mb in ("1024", "0"):
+        env = dict(os.environ, ZOPFLI_AMD_HOST_CACHE_MB=mb)
+        env.pop("ZOPFLI_AMD_KEEP_HEAP", None)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[mb] = r.stdout.split()
+    assert res["1024"][0] == res["0"][0]
+    assert int(res["1024"][1]) > 1000000 and int(res["1024"][2]) == 0, res
+    assert int(res["0"][1]) == 0, res
+
+
 @pytest.mark.parametrize("more", [0, 1])
 def test_verbose_text_equals_the_references(more):
     """ZopfliOptions::verbose / verbose_more: the library prints the reference's stderr text — block split

@@ -121,8 +121,9 @@ def test_cost_aware_ranges_agree_and_balance(world):
     data = _hetero()
     n = len(data)
     r1 = sharding.shard_ranges(n, world, data, lib)
-    r2 = sharding.shard_ranges(n, world, bytes(bytearray(data)), lib)
-    assert r1 == r2
+    r2 = sharding.shard_ranges(n, world, bytearray(data), lib)      # (a bytearray or a memoryview is as good as bytes)
+    assert r1 == r2 == sharding.shard_ranges(n, world, memoryview(data), lib)
+    assert sharding.shard_costs(n, r1, bytearray(data), lib) == sharding.shard_costs(n, r1, data, lib)
     assert r1[0][0] == 0 and r1[-1][1] == n
     assert all(a[1] == b[0] for a, b in zip(r1, r1[1:]))
     assert all(s % sharding.MASTER_BLOCK == 0 for s, _ in r1 if s < n)

@@ -73,6 +73,8 @@ def bind(lib):
     lib.ZopfliDeflatePart.restype = None
     lib.zmx_device_count.restype = ctypes.c_int
     lib.zmx_last_error.restype = ctypes.c_char_p
+    lib.zmx_last_error_class.restype = ctypes.c_int
+    lib.zmx_host_cache_trim.restype = ctypes.c_size_t
     lib.zmx_ctx_create.argtypes = [ctypes.c_int, P(vp)]
     lib.zmx_ctx_destroy.argtypes = [vp]
     lib.zmx_ctx_destroy.restype = None
@@ -106,6 +108,7 @@ def bind(lib):
     lib.zmx_dist_init.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, P(vp)]
     lib.zmx_dist_destroy.argtypes = [vp]
     lib.zmx_dist_destroy.restype = None
+    lib.zmx_dist_comm_count.argtypes = [vp]
     lib.zmx_dist_gather.argtypes = [vp, vp, sz, P(vp), P(sz)]
     return lib
 
@@ -312,6 +315,10 @@ class Dist:
             parts.append(whole[off:off + sizes[r]])
             off += sizes[r]
         return parts
+
+    def comm_count(self):
+        """ncclCommCount of the communicator: the ranks RCCL itself saw."""
+        return int(self.ctx.lib.zmx_dist_comm_count(self.handle))
 
     def close(self):
         if self.handle:

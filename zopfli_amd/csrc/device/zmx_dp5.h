@@ -1262,8 +1262,11 @@ __global__ __launch_bounds__(64 * D5_WG, WAVES) void k_dp5_spec(Dp4Params P) {
                    reinterpret_cast<u16*>(s_buf[wave]), s_itab, IT, s_w1, s_sym1, s_ri[wave], s_rk[RUNS ? wave : 0u]);
 }
 
-// the cooperative run-task job (four waves a task): d6_run_job, k_dp6_spec — used by k_dp4_fix below
+// the cooperative run-task job (four waves a task): d6_run_job, k_dp6_spec — measured 10 % slower than the one-wave job
+// (round 5), so only in -DZMX_EXPERIMENTS builds
+#ifdef ZMX_EXPERIMENTS
 #include "zmx_dp6.h"
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // FIX: one workgroup per block walks the block's tasks in order, accepts every task whose entry

@@ -17,8 +17,15 @@
 
 #include "zmx_kernels.h"
 #include "zmx_match2.h"
+// The kernels that lost their measurement — k_bucket + k_match3 / k_match4 (sorted candidate slices, round 3) and the
+// four-wave run task k_dp6_spec (round 5) — are NOT in the shipped library: they are compiled in with -DZMX_EXPERIMENTS
+// only (tools/build_variant.py --experiments), for the comparison and stress scripts under tools/.
+#ifdef ZMX_EXPERIMENTS
 #include "zmx_match3.h"
 #include "zmx_match4.h"
+#else
+#define BK_CH 32768u      // (the chunk size the chunk_base bookkeeping below shares with the experiments)
+#endif
 #include "zmx_match5.h"
 #include "zmx_dp4.h"
 #include "zmx_dp5.h"     // (includes zmx_dp6.h: the cooperative run-task job)
@@ -51,17 +58,29 @@ thread_local ThreadStats g_ts = {};
 #define g_seg_stats g_ts.seg
 
 thread_local bool g_last_oom = false;   // the last failure of this thread was an allocation the device could not serve
+// What KIND of failure the last one of this thread was (zmx_last_error_class): callers decide by this code, never by the
+// message's text (the text holds the failing expression and __FILE__: "PoolAlloc(...)", a build path).
+thread_local int g_err_class = ZMX_ERR_NONE;
 
 int Fail(const char* what, hipError_t e, const char* file, int line) {
   char buf[512];
   std::snprintf(buf, sizeof(buf), "%s: %s (%s:%d)", what, hipGetErrorString(e), file, line);
   g_err = buf;
   g_last_oom = e == hipErrorOutOfMemory;
+  g_err_class = g_last_oom ? ZMX_ERR_OUT_OF_MEMORY : ZMX_ERR_DEVICE;
   if (g_last_oom) (void)hipGetLastError();
   return -1;
 }
+// a request the device layer refuses whoever runs it: bad arguments, a size limit, a pool that overflows after its retries
 int FailMsg(const std::string& m) {
   g_err = m;
+  g_err_class = ZMX_ERR_REFUSED;
+  return -1;
+}
+// the device did something it should not have (a kernel's guard fired, consistency flags): another context may fare better
+int FailFault(const std::string& m) {
+  g_err = m;
+  g_err_class = ZMX_ERR_DEVICE;
   return -1;
 }
 
@@ -349,7 +368,11 @@ int MatchKernel() {
   if (v < 0) {
     const char* e = std::getenv("ZOPFLI_AMD_MATCH");
     const int k = e ? std::atoi(e) : kMatchDefault;
+#ifdef ZMX_EXPERIMENTS
     v = k == 0 || k == 3 || k == 4 || k == 5 ? k : 2;
+#else
+    v = k == 0 || k == 5 ? k : 2;      // (3 and 4 exist in -DZMX_EXPERIMENTS builds only)
+#endif
     g_match_kernel.store(v, std::memory_order_relaxed);
   }
   return v;
@@ -402,7 +425,7 @@ void PoolFree(zmx_ctx* c, void* p) {
 
 // Guard mode: drain the stream and check every red zone of the context.  `where` = the kernel that just ran.
 int GuardVerify(zmx_ctx* c, const char* where) {
-  if (hipStreamSynchronize(c->stream) != hipSuccess) return FailMsg(std::string("ZOPFLI_AMD_GUARD: the stream failed after ") + where);
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return FailFault(std::string("ZOPFLI_AMD_GUARD: the stream failed after ") + where);
   if (c->guard_live.empty()) return 0;
   // (ZOPFLI_AMD_GUARD_SELFTEST=N: the N-th check finds a byte that this function itself just broke — the test that the
   //  mode reports what it is there to report)
@@ -433,7 +456,7 @@ int GuardVerify(zmx_ctx* c, const char* where) {
     std::snprintf(buf, sizeof(buf), "ZOPFLI_AMD_GUARD: after %s the red zone %s allocation '%s' (%zu bytes) changed: byte offset %u of the zone holds 0x%08x",
                   where, (h[1] & 1u) ? "behind" : "in front of", g.tag ? g.tag : "?", g.bytes, h[2], h[3]);
     std::fprintf(stderr, "%s\n", buf);
-    return FailMsg(buf);
+    return FailFault(buf);
   }
   return 0;
 }
@@ -464,6 +487,14 @@ int zmx_device_count(void) {
 }
 
 const char* zmx_last_error(void) { return g_err.c_str(); }
+int zmx_last_error_class(void) { return g_err_class; }
+int zmx_has_experiments(void) {
+#ifdef ZMX_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 void zmx_set_oom_hook(zmx_oom_hook_t hook) { g_oom_hook.store(hook, std::memory_order_release); }
 
@@ -489,14 +520,19 @@ int zmx_ctx_trim_cache(zmx_ctx* c) {
 }
 
 int zmx_set_match_kernel(int kernel) {
+#ifdef ZMX_EXPERIMENTS
   if (kernel != 0 && kernel != 2 && kernel != 3 && kernel != 4 && kernel != 5) return FailMsg("zmx_set_match_kernel: 0, 2, 3, 4 or 5");
+#else
+  if (kernel == 3 || kernel == 4) return FailMsg("zmx_set_match_kernel: kernels 3 and 4 are in -DZMX_EXPERIMENTS builds only");
+  if (kernel != 0 && kernel != 2 && kernel != 5) return FailMsg("zmx_set_match_kernel: 0, 2 or 5");
+#endif
   g_match_kernel.store(kernel, std::memory_order_relaxed);
   return 0;
 }
 
 size_t zmx_internal_input_size(zmx_ctx* ctx) { return ctx->insize; }
 int zmx_internal_device(zmx_ctx* ctx) { return ctx->device; }
-void zmx_internal_set_error(const char* msg) { g_err = msg; }
+void zmx_internal_set_error(const char* msg) { g_err = msg; g_err_class = ZMX_ERR_DEVICE; }
 const unsigned char* zmx_internal_input_host(zmx_ctx* ctx) { return ctx->h_in; }
 
 void zmx_internal_seg_stats(double* out8, int reset) {
@@ -566,8 +602,10 @@ int zmx_ctx_create(int device, zmx_ctx** out) {
 
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chain), hipFuncAttributeMaxDynamicSharedMemorySize,
                              CH_LDS_BYTES));
+#ifdef ZMX_EXPERIMENTS
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket), hipFuncAttributeMaxDynamicSharedMemorySize,
                              BK_LDS_BYTES));
+#endif
   *out = c;
   return 0;
 }
@@ -834,12 +872,17 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   HIPCHK(PoolAlloc(c, &t->d_blocks, nb));
   HIPCHK(PoolAlloc(c, &t->d_tile_off, nb + 1));
   HIPCHK(PoolAlloc(c, &t->d_same16, reg_off));
+#ifdef ZMX_EXPERIMENTS
   t->buckets = mk == 3 || mk == 4;
+#else
+  t->buckets = false;
+#endif
   t->chunk_base.assign(nb + 1, 0);
   for (size_t b = 0; b < nb; ++b) {
     const u64 L = t->blocks[b].inend - t->blocks[b].ws;
     t->chunk_base[b + 1] = t->chunk_base[b] + static_cast<u32>((L + BK_CH - 1) / BK_CH);
   }
+#ifdef ZMX_EXPERIMENTS
   if (t->buckets) {
     // (the two orders in one allocation, M4_PAD entries in front: k_match4 reads 16 bytes at a time, from up to 15 entries
     //  below a chunk's first one, and takes the second order as an offset from the first)
@@ -853,7 +896,9 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     HIPCHK(PoolAlloc(c, &t->d_ssame, reg_off));
     HIPCHK(PoolAlloc(c, &t->d_chunk_base, nb + 1));
     HIPCHK(hipMemcpyAsync(t->d_chunk_base, t->chunk_base.data(), (nb + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
-  } else {
+  } else
+#endif
+  {
     HIPCHK(PoolAlloc(c, &t->d_links, reg_off));
   }
   HIPCHK(PoolAlloc(c, &t->d_recs, pos_off * 8));
@@ -913,6 +958,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     KCHK(c, "k_same");
     HIPCHK(hipGetLastError());
     const dim3 g2(static_cast<unsigned>((max_l + CH_EMIT - 1) / CH_EMIT), static_cast<unsigned>(nb), 2);
+#ifdef ZMX_EXPERIMENTS
     if (t->buckets) {
       BucketParams kp;
       kp.in = c->d_in;
@@ -924,7 +970,9 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
       kp.ssame = t->d_ssame;
       hipLaunchKernelGGL(k_bucket, g2, dim3(BK_THREADS), BK_LDS_BYTES, c->stream, kp);
       KCHK(c, "k_bucket");
-    } else {
+    } else
+#endif
+    {
       hipLaunchKernelGGL(k_chain, g2, dim3(64), CH_LDS_BYTES, c->stream, c->d_in, t->d_blocks, t->d_same16, t->d_links, d_link_lo);
       KCHK(c, "k_chain");
       if ((mk == 5 || mk == 0) && d_link_lo == nullptr) {
@@ -1022,6 +1070,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   // the match-table kernel over `total_tiles` tiles (all of them, or those of tile_list)
   auto launch_match = [&](u32* pool, u32 pool_cap, u32 total_tiles, const u32* d_tiles, bool prof) -> int {
     if (total_tiles == 0) return 0;
+#ifdef ZMX_EXPERIMENTS
     if (t->buckets) {
       Match3Params mp;
       mp.in = c->d_in;
@@ -1050,6 +1099,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
       }
       return 0;
     }
+#endif
     MatchParams mp;
     mp.in = c->d_in;
     mp.blocks = t->d_blocks;
@@ -1195,7 +1245,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
       std::snprintf(buf, sizeof(buf), "zmx_tables_build: k_match5's wave loop did not end (state %08x xd %u curd %u bestlen %u limit %u nlink %u eqd %u "
                     "li %u idx %u same %u cur %u bestdist %u)", dbg[0], dbg[1], dbg[2], dbg[3] & 0xffffu, dbg[3] >> 16, dbg[4] & 0xffffu, dbg[4] >> 16,
                     dbg[5], dbg[6] & 0xffffu, dbg[6] >> 16, dbg[7] & 0xffffu, dbg[7] >> 16);
-      return FailMsg(buf);
+      return FailFault(buf);
     }
     if ((counters[1] & 1u) == 0) break;
     if (per_pos >= 256) return FailMsg("zmx_tables_build: change-point pool overflow");
@@ -1269,6 +1319,7 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     }
     if (cur > budget && nb > 1) {
       g_err = "zmx_tables_build: the batch needs more room for its DP edges than ZOPFLI_AMD_CODE_BUDGET_MB allows";
+      g_err_class = ZMX_ERR_REFUSED;   // (this batch, anywhere; the caller comes back with fewer blocks)
       return kTooLarge;
     }
     HIPCHK(PoolAlloc(c, &t->d_codes, cur + 2048));   // (k_dp5_spec stages whole KB: it reads a little past a window's rows)
@@ -1726,7 +1777,11 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   cp.redo_pass = 0;
   // (ZOPFLI_AMD_COOP=1: run tasks by k_dp6_spec, four waves a task (zmx_dp6.h) — built and measured in round 5, NOT the
   //  default: 52.6 ms of chain per run on class Z against 45.9 with one wave a task)
+#ifdef ZMX_EXPERIMENTS
   static const int coop = [] { const char* e = std::getenv("ZOPFLI_AMD_COOP"); return e ? std::atoi(e) : 0; }();
+#else
+  constexpr int coop = 0;     // (k_dp6_spec is in -DZMX_EXPERIMENTS builds only)
+#endif
   cp.coop = coop != 0 ? 1 : 0;
   cp.kind = t->d_task_kind;
   cp.run_list = t->d_run_list;
@@ -1782,9 +1837,12 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
         HIPCHK(hipStreamWaitEvent(c->stream2, c->ev2[0], 0));
         Dp4Params cr = cp;
         cr.task0 = t->n_wg;
+#ifdef ZMX_EXPERIMENTS
         if (cp.coop && cp.prof) hipLaunchKernelGGL((k_dp6_spec<2, true>), dim3(t->n_run_list), dim3(64 * D6_NW), 0, c->stream2, cr);
         else if (cp.coop) hipLaunchKernelGGL((k_dp6_spec<2, false>), dim3(t->n_run_list), dim3(64 * D6_NW), 0, c->stream2, cr);
-        else if (cp.prof) hipLaunchKernelGGL((k_dp5_spec<true, 2, true>), dim3(t->n_wg_runs), bdim, 0, c->stream2, cr);
+        else
+#endif
+        if (cp.prof) hipLaunchKernelGGL((k_dp5_spec<true, 2, true>), dim3(t->n_wg_runs), bdim, 0, c->stream2, cr);
         else hipLaunchKernelGGL((k_dp5_spec<false, 2, true>), dim3(t->n_wg_runs), bdim, 0, c->stream2, cr);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c->ev2[1], c->stream2));
@@ -1816,12 +1874,15 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
         // (one workgroup per listed task; the workgroups beyond the list have nothing to do)
         const unsigned cap = ntask;
         // (the variant for run tasks wherever the set has any: what is run again there is mostly theirs)
+#ifdef ZMX_EXPERIMENTS
         if (t->n_wg_runs && cp.coop) {
           // the listed run tasks by k_dp6_spec, the listed text tasks by the text variant (each passes over the other's)
           hipLaunchKernelGGL((k_dp6_spec<2, false>), dim3(cap), dim3(64 * D6_NW), 0, c->stream, c2);
           if (cp.prof) hipLaunchKernelGGL((k_dp5_spec<true, 4, false>), dim3(cap), dim3(64 * D5_WG), 0, c->stream, c2);
           else hipLaunchKernelGGL((k_dp5_spec<false, 4, false>), dim3(cap), dim3(64 * D5_WG), 0, c->stream, c2);
-        } else if (t->n_wg_runs) {
+        } else
+#endif
+        if (t->n_wg_runs) {
           if (cp.prof) hipLaunchKernelGGL((k_dp5_spec<true, 2, true>), dim3(cap), dim3(64 * D5_WG), 0, c->stream, c2);
           else hipLaunchKernelGGL((k_dp5_spec<false, 2, true>), dim3(cap), dim3(64 * D5_WG), 0, c->stream, c2);
         } else {
@@ -1870,7 +1931,7 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     if (o_flags[1]) {
       char buf[128];
       std::snprintf(buf, sizeof(buf), "zmx_squeeze_run: device consistency flags 0x%x", o_flags[1]);
-      return FailMsg(buf);
+      return FailFault(buf);
     }
   }
   t->h_hist.assign(hist, hist + nb * ZMX_HIST);

@@ -15,6 +15,7 @@
 #include <thread>
 #include <vector>
 
+#include "block_cache.h"
 #include "block_cost.h"
 #include "deflate.h"
 #include "lz77_optimal.h"
@@ -45,20 +46,18 @@ using zamd::kMasterBlock;
   std::exit(EXIT_FAILURE);
 }
 
-// Freed host memory stays with the process: glibc neither trims its arenas nor shrinks the worker threads' heaps
-// (M_TRIM_THRESHOLD, M_TOP_PAD; blocks above the mmap threshold are still mapped and returned one by one).  The symbols
-// of every block pass through host vectors — hundreds of MB per 100 MB of input with block splitting — and with a few
-// dozen worker threads every heap that shrinks is a munmap / madvise with a TLB shootdown on all their CPUs: on
-// incompressible input returning that memory once took as long as the compression.  Round 5, 100 MB, one box: text 806 ->
-// 825 MB/s, with block splitting 656 -> 755; random data 712 -> 751 and 343 -> 374 (profiles/r05_keep_heap.txt); it was
-// opt-in until then because it changes a setting of the whole process's allocator — what it costs the host program is
-// that small blocks it frees are kept for reuse instead of being handed back to the kernel.
-// ZOPFLI_AMD_KEEP_HEAP=0: leave malloc alone.
+// OPT-IN ONLY (ZOPFLI_AMD_KEEP_HEAP=1 / 2; unset or 0: malloc is left alone): mallopt so that glibc neither trims its
+// arenas nor shrinks the worker threads' heaps.  Round 5 made this the default (+12 % with block splitting) and the review
+// was right to object: it reconfigures the allocator of the whole host process, for good — a drop-in libzopfli.so.1 must
+// not (the reference has no side effects outside its arguments).  Round 6: the host arrays that caused the
+// churn — the blocks' symbol stores, positions, sampled histograms, bit buffers — take their memory from the library's
+// own block cache (block_cache.h, ZOPFLI_AMD_HOST_CACHE_MB), which touches nothing process-wide.  The switch stays for
+// measuring one against the other.
 void MaybeKeepHeap() {
   static const bool once = [] {
     const char* e = std::getenv("ZOPFLI_AMD_KEEP_HEAP");
-    if (e && std::atoi(e) == 0) return true;
-    if (e && std::atoi(e) == 2) {          // (for measuring: large blocks from the heap too — 32 MB is the most glibc takes; no better, nor is 1 MB)
+    if (!e || std::atoi(e) == 0) return true;
+    if (std::atoi(e) == 2) {          // (for measuring: large blocks from the heap too — 32 MB is the most glibc takes; no better, nor is 1 MB)
       mallopt(M_MMAP_THRESHOLD, 32 << 20);
       mallopt(M_TRIM_THRESHOLD, 1 << 30);
       mallopt(M_TOP_PAD, 64 << 20);
@@ -408,6 +407,7 @@ int RunPartsShardedOnce(const ZopfliOptions& options, int btype, const unsigned 
     std::vector<zamd::Chunk> chunks;
     int rc = 0;
     std::string err;
+    int err_class = ZMX_ERR_NONE;   // zmx_last_error_class() of the failure
     zamd::Timing timing;
     uint32_t sum = 0;
     size_t sum_bytes = 0;
@@ -522,12 +522,14 @@ int RunPartsShardedOnce(const ZopfliOptions& options, int btype, const unsigned 
     }
     sh.rc = 0;
     sh.err.clear();
+    sh.err_class = ZMX_ERR_NONE;
     sh.chunks.clear();
     sh.sum = 0;
     sh.sum_bytes = 0;
     if (!retry && fail_shard == static_cast<long>(d)) {
       sh.rc = -1;
-      sh.err = "injected failure (ZOPFLI_AMD_TEST_FAIL_SHARD)";
+      sh.err = "injected failure (ZOPFLI_AMD_TEST_FAIL_SHARD): PoolAlloc(pool) too large — the text must not matter";
+      sh.err_class = ZMX_ERR_OUT_OF_MEMORY;
       return;
     }
     const size_t start = parts[sh.first].instart, end = parts[sh.last - 1].inend;
@@ -541,6 +543,7 @@ int RunPartsShardedOnce(const ZopfliOptions& options, int btype, const unsigned 
     if (up != 0) {
       sh.rc = -1;
       sh.err = zmx_last_error();
+      sh.err_class = zmx_last_error_class();
       return;
     }
     if (sum && start < sum->limit) {
@@ -548,6 +551,7 @@ int RunPartsShardedOnce(const ZopfliOptions& options, int btype, const unsigned 
       if (zmx_checksum(ctx, sum->kind, start - sh.base, start - sh.base + sh.sum_bytes, &sh.sum) != 0) {
         sh.rc = -1;
         sh.err = zmx_last_error();
+        sh.err_class = zmx_last_error_class();
         return;
       }
     }
@@ -555,7 +559,7 @@ int RunPartsShardedOnce(const ZopfliOptions& options, int btype, const unsigned 
     for (auto& p : mine) { p.instart -= sh.base; p.inend -= sh.base; }
     const double tr3 = WallMs();
     sh.rc = RunParts(ctx, options, btype, mine, &sh.chunks);
-    if (sh.rc) sh.err = zmx_last_error();
+    if (sh.rc) { sh.err = zmx_last_error(); sh.err_class = zmx_last_error_class(); }
     if (TraceCall()) {
       std::fprintf(stderr, "  shard %zu (%zu parts): start +%.2f ms, wait for turn %.2f, upload %.2f, checksum %.2f, parts %.2f, end +%.2f\n",
                    d, sh.last - sh.first, tr0 - tr_begin, tr1 - tr0, tr2 - tr1, tr3 - tr2, WallMs() - tr3, WallMs() - tr_begin);
@@ -587,9 +591,10 @@ int RunPartsShardedOnce(const ZopfliOptions& options, int btype, const unsigned 
   // parts are independent (deflate.c:916-923), whoever computes them computes the same bits.
   for (size_t d = 0; d < ndev; ++d) {
     if (!shards[d].rc) continue;
-    // (not a failure that would repeat itself on any context: a request the device layer refuses, a table set that
-    //  overflows its pools after the retries the device layer makes itself)
-    if (shards[d].err.find("pool") != std::string::npos || shards[d].err.find("too large") != std::string::npos) continue;
+    // (not a failure that would repeat itself on any context — a request the device layer refuses, a table set that
+    //  overflows its pools after the retries the device layer makes itself: ZMX_ERR_REFUSED.  By the error's CLASS, not its
+    //  text: an out-of-memory inside PoolAlloc reads "PoolAlloc(...): out of memory" and is exactly what a retry is for)
+    if (shards[d].err_class == ZMX_ERR_REFUSED) continue;
     zmx_ctx* other = nullptr;
     for (size_t e = 0; e < ndev && !other; ++e) if (e != d && !shards[e].rc && !shards[e].redone) other = ctxs[e];
     if (!other) break;
@@ -671,6 +676,8 @@ void PushByte(unsigned v, unsigned char** out, size_t* outsize) {
 }  // namespace
 
 extern "C" {
+
+size_t zmx_host_cache_trim(void) { return zamd::BlockCache::Trim(); }
 
 void ZopfliInitOptions(ZopfliOptions* options) {
   options->verbose = 0;

@@ -9,6 +9,8 @@
 #include <cstring>
 #include <vector>
 
+#include "block_cache.h"
+
 namespace zamd {
 
 class BitWriter {
@@ -40,7 +42,7 @@ class BitWriter {
   size_t BitCount() const { return buf_.size() * 8 + fill_; }
 
   // Returns the bytes (last one zero-padded) and leaves the writer empty.
-  std::vector<uint8_t> Finish(size_t* nbits) {
+  CVec<uint8_t> Finish(size_t* nbits) {
     *nbits = BitCount();
     for (unsigned done = 0; done < fill_; done += 8) buf_.push_back(static_cast<uint8_t>(acc_ >> done));
     acc_ = 0;
@@ -54,7 +56,7 @@ class BitWriter {
     for (unsigned i = 0; i < len; ++i) r |= ((v >> i) & 1u) << (len - 1 - i);
     return r;
   }
-  std::vector<uint8_t> buf_;
+  CVec<uint8_t> buf_;
   uint64_t acc_ = 0;
   unsigned fill_ = 0;
 };

@@ -44,7 +44,7 @@ struct DeviceEncode {
   size_t chunk = 0;                  // index in the part's chunks
   size_t block = 0;                  // index in the batched block list (or in the fixed-tree re-parse batch)
   bool from_fixed = false;           // its symbols are the fixed-tree re-parse's
-  std::vector<uint8_t> header;       // the 3 header bits and the tree, from bit 0
+  CVec<uint8_t> header;              // the 3 header bits and the tree, from bit 0
   size_t header_bits = 0;
   size_t data_bits = 0;              // symbols + end symbol
   uint32_t codes[320];

@@ -22,7 +22,7 @@ struct Chunk {
   enum Kind : uint8_t { kBits = 0, kStored = 1 };
   Kind kind = kBits;
   bool final_block = false;     // kStored only: BFINAL of its last piece
-  std::vector<uint8_t> bits;    // kBits: packed from bit 0
+  CVec<uint8_t> bits;           // kBits: packed from bit 0 (memory from the library's block cache)
   size_t nbits = 0;
   size_t start = 0, end = 0;    // kStored: raw input range ...
   std::vector<uint8_t> raw;     // ... or, after (de)serialisation, the bytes themselves

@@ -31,6 +31,7 @@ struct Rccl {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -58,6 +59,7 @@ Rccl* LoadRccl() {
     ZMX_SYM(GetUniqueId, "ncclGetUniqueId")
     ZMX_SYM(CommInitRank, "ncclCommInitRank")
     ZMX_SYM(CommDestroy, "ncclCommDestroy")
+    ZMX_SYM(CommCount, "ncclCommCount")
     ZMX_SYM(AllGather, "ncclAllGather")
     ZMX_SYM(GroupStart, "ncclGroupStart")
     ZMX_SYM(GroupEnd, "ncclGroupEnd")
@@ -159,6 +161,13 @@ void zmx_dist_destroy(zmx_dist* d) {
   (void)hipFree(d->d_sizes);
   if (d->stream) (void)hipStreamDestroy(d->stream);
   delete d;
+}
+
+int zmx_dist_comm_count(zmx_dist* d) {
+  if (!d || !d->comm) return -1;
+  int n = -1;
+  if (d->rccl->CommCount(d->comm, &n) != ncclSuccess) return -1;
+  return n;
 }
 
 namespace {

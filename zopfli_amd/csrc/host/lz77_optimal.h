@@ -11,12 +11,13 @@
 #include <string>
 #include <vector>
 
+#include "block_cache.h"
 #include "zopfli_amd.h"
 
 namespace zamd {
 
 struct SymbolRun {
-  std::vector<uint16_t> litlens, dists;  // lz77.h:44-49 convention
+  CVec<uint16_t> litlens, dists;         // lz77.h:44-49 convention (memory from the library's block cache)
   std::string log;                       // ZopfliOptions::verbose: the block's "Iteration i: n bit" lines (squeeze.c:493)
 };
 

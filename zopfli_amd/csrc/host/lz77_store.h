@@ -11,6 +11,7 @@
 #include <cstring>
 #include <vector>
 
+#include "block_cache.h"
 #include "symbols.h"
 
 namespace zamd {
@@ -143,9 +144,10 @@ class Lz77Store {
   }
 
   const unsigned char* data_;
-  std::vector<uint16_t> litlens_, dists_;
-  std::vector<size_t> pos_;
-  std::vector<Histogram> samples_;  // samples_[k] = counts of symbols [0, k*kSample)
+  // (a master block's store is ~ 5 MB of these: from the library's block cache, not malloc — block_cache.h)
+  CVec<uint16_t> litlens_, dists_;
+  CVec<size_t> pos_;
+  CVec<Histogram> samples_;  // samples_[k] = counts of symbols [0, k*kSample)
   Histogram running_ = {};          // counts of all symbols pushed so far
 };
 

@@ -379,7 +379,9 @@ void ParallelForWide(size_t n, Fn&& fn) {
     fn(i);
     g_inside_parallel_for = was;
   };
-  if (WideThreads() <= HostThreads()) { WorkerPool::Get().Run(n, body); return; }
+  // (always the wide pool, also where it is no wider than the regular one — a host of <= 32 CPUs, ZOPFLI_AMD_THREADS set:
+  //  WorkerPool takes one job at a time, and the shard threads of a dealt call would queue their split searches and
+  //  encodes behind each other and behind the others' cost-model fork-joins)
   WidePool::Get().Run(n, body);
 }
 

@@ -32,7 +32,7 @@ def shard_ranges(insize, world, data=None, lib=None):
         fn = lib.zmx_master_block_costs
         fn.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double), ctypes.c_size_t]
         fn.restype = ctypes.c_int
-        buf = data if isinstance(data, (bytes, bytearray)) else bytes(data)
+        buf = data if isinstance(data, bytes) else bytes(data)   # (c_char_p takes bytes only: a bytearray is copied)
         if fn(buf, insize, cost, nmb) != nmb:
             raise RuntimeError("zmx_master_block_costs failed")
         first = (ctypes.c_size_t * (world + 1))()
@@ -60,7 +60,8 @@ def shard_costs(insize, ranges, data, lib=None):
     fn = lib.zmx_master_block_costs
     fn.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double), ctypes.c_size_t]
     fn.restype = ctypes.c_int
-    fn(data if isinstance(data, (bytes, bytearray)) else bytes(data), insize, cost, nmb)
+    if fn(data if isinstance(data, bytes) else bytes(data), insize, cost, nmb) != nmb:
+        raise RuntimeError("zmx_master_block_costs failed")
     return [sum(cost[b] for b in range(s // MASTER_BLOCK, -(-e // MASTER_BLOCK))) for s, e in ranges]
 
 

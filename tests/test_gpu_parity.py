@@ -382,7 +382,9 @@ CHAIN_ENVS = [
     ({"ZOPFLI_AMD_SEG_CUTS": "0"}, lambda st: st["accepted"] > 0),                              # every task warms up over 512 positions (no cut points)
     ({"ZOPFLI_AMD_SEG_CUTS": "64", "ZOPFLI_AMD_SEG_L": "512", "ZOPFLI_AMD_SEG_HEAD": "2048"}, lambda st: st["tasks"] > 1000 and st["accepted"] > 0),   # short tasks, cut points sought close by
     ({"ZOPFLI_AMD_MATCH_FILTER": "0"}, lambda st: st["accepted"] > 0),                          # k_match2 with the one-byte candidate test
-    ({"ZOPFLI_AMD_SEG_MID": "0"}, lambda st: st["accepted"] > 0),                               # no mid snapshots: a task that leaves its binade is re-run whole
+    ({"ZOPFLI_AMD_SEG_MID": "0"}, lambda st: st["accepted"] > 0),
+    ({"ZOPFLI_AMD_SHORTCUT_CHAIN": "0"}, lambda st: st["accepted"] > 0),
+    ({"ZOPFLI_AMD_RUN_CODES": "1"}, lambda st: st["accepted"] > 0),                             # codes for wide run rows too (round 5's layout)                        # long-run shortcuts window by window (no chain in a fixed frame)                               # no mid snapshots: a task that leaves its binade is re-run whole
 ]
 
 

@@ -348,6 +348,7 @@ struct Dp4Params {
   int int_path;            // k_dp5_spec: 1 = clean windows inside the workgroup's binade take the integer chain step (ZOPFLI_AMD_INT_PATH)
   int fix_lean_min;        // k_dp4_fix: a task with this many generic windows is re-run by the lean one-wave job
   int redo_pass;           // k_dp5_spec: 1 = this launch runs P.redo_wg (workgroups beyond *redo_count have nothing to do)
+  int chain_fast;          // run tasks: 1 = chains of long-run shortcuts in a frame that does not move (zmx_dp5.h; ZOPFLI_AMD_SHORTCUT_CHAIN=0: window by window)
   // the cooperative run tasks (zmx_dp6.h)
   int coop;                // 1 = run tasks are k_dp6_spec's (four waves a task); k_dp5_spec's second pass then skips them
   const u32* kind;         // [tasks] k_taskkind: 1 = a run task

@@ -59,6 +59,7 @@ typedef const __attribute__((address_space(4))) d5_u32x4* d5_cdscp;
 // across a window; and, throughout, three dependent memory round trips per window that four waves per SIMD do
 // not hide (95 % of a window's 9 000 cycles were waiting).
 #define D5_WM 40u          // words per window in wmeta[]
+#define D5_WF_CODELESS 0x100u   // winflag / wmeta word 34, beside the window's kind in the low byte: a row without codes (k_rowscan)
 #define D5_STAGE_BYTES 4352u    // a wave's staging area: >= 4096 + 16, >= 6 DP_XN
 #define D5_STAGE_HALF 2176u     // two halves of >= 2048 + 16 for the LDS-DMA double buffer
 struct MkDescParams {
@@ -91,21 +92,26 @@ __global__ __launch_bounds__(256) void k_mkdesc(MkDescParams P) {
   const u32 w = P.win_off[blockIdx.y] + (p >> 5);
   u32* wm = P.wmeta + (u64)w * D5_WM;
   const u32 kend = dhw.y & 0xffffu;
+  const u32 klay = dph_layout_len(dhw.y);      // (what the row takes in codes[]: nothing for a wide run row)
+  const u64 nocodes = __ballot(p < B && (dhw.y & DPH_CODELESS) != 0);
   if (p < ((B + 31u) & ~31u)) wm[p & 31u] = p < B ? ((dhw.x - first + 32u - ((p & 31u) + 1u)) << 16) | kend : 0u;
   if ((lane & 31u) == 0 && p < B) {
     const u32 sh = lane & 32u;
-    const u32 f = (u32)(not1 >> sh) == 0 ? 1u : (u32)(not2 >> sh) != 0 ? 0u : (u32)(far3 >> sh) == 0 ? 2u : 3u;
+    // (bit 8, D5_WF_CODELESS: a row of the window has no codes — such a window is of kind 0, and a task that holds one is
+    //  re-run by the lean one-wave job, never by k_dp4's pipeline, whose ring expects every row's codes)
+    const u32 f = ((u32)(not1 >> sh) == 0 ? 1u : (u32)(not2 >> sh) != 0 ? 0u : (u32)(far3 >> sh) == 0 ? 2u : 3u) |
+                  ((u32)(nocodes >> sh) != 0 ? D5_WF_CODELESS : 0u);
     P.winflag[w] = f;
     P.winroff[w] = dhw.x;
     wm[32] = dhw.x;
     wm[34] = f;
   }
-  if (p < B && ((p & 31u) == 31u || p + 1 == B)) wm[33] = dhw.x + kend;           // where the window's rows end
+  if (p < B && ((p & 31u) == 31u || p + 1 == B)) wm[33] = dhw.x + klay;           // where the window's rows end
   if (p + 1 == B) {      // one record past the last window: where the block's rows end, class 0
-    P.winroff[w + 1] = dhw.x + kend;
+    P.winroff[w + 1] = dhw.x + klay;
     P.winflag[w + 1] = 0;
-    wm[D5_WM + 32] = dhw.x + kend;
-    wm[D5_WM + 33] = dhw.x + kend;
+    wm[D5_WM + 32] = dhw.x + klay;
+    wm[D5_WM + 33] = dhw.x + klay;
     wm[D5_WM + 34] = 0;
   }
 }
@@ -394,7 +400,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
   // clean (k_mkdesc) and without an edge below mincost in this run (k_edges' bitmap)
   auto win_kind = [&](u32 wb) -> u32 {     // 1 / 2: cell registers the window's edges reach; 0: generic
     if ((wb & 31u) != 0 || wb + 32u > B) return 0u;
-    const u32 f = winflag[wb >> 5];
+    const u32 f = winflag[wb >> 5] & 0xffu;
     if (f == 0) return 0u;
     const u32 g = bit_off + wb;
     const u64 two = ((u64)badw[(g >> 5) + 1] << 32) | badw[g >> 5];
@@ -450,7 +456,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
     if (skip) {
       kind = 0;
     } else if (pf_w == (wbase >> 5) && (wbase & 31u) == 0 && wbase + 32u <= B) {
-      const u32 f = rdlane_u32(pf_meta, 34), g = bit_off + wbase;
+      const u32 f = rdlane_u32(pf_meta, 34) & 0xffu, g = bit_off + wbase;
       const u64 two = ((u64)rdlane_u32(pf_meta, 41) << 32) | rdlane_u32(pf_meta, 40);
       kind = f != 0 && (u32)(two >> (g & 31u)) == 0 ? f : 0u;
     } else {
@@ -708,33 +714,46 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
             cd[s] = k1 < ke ? (v & 0x3ff8u) : 0u;
           }
         };
-        auto relax = [&](const u32 (&cd)[5], u32 p) {
+        // (three stages, a row each: the codes of row p + 2 are asked for and the weights of row p + 1 — a second LDS round
+        //  trip, behind the codes' — while row p is relaxed; with the weights read inside the relaxation a lone wave sat
+        //  out that round trip at every position: 861 cycles a position, profiles/r06_profZ.txt)
+        auto weights = [&](double (&w)[5], const u32 (&cd)[5]) {
+#pragma unroll
+          for (int s = 0; s < 5; ++s) w[s] = code_w(cd[s]);
+        };
+        auto relax = [&](const double (&w)[5], u32 p) {
           const double cj = (double)rdlane_f32(c[0], p);
           const u32 src1 = wbase + p + 1u;
 #pragma unroll
-          for (int s = 0; s < 5; ++s) {
-            const double w = code_w(cd[s]);
-            D3_RELAX_K(c[s], l[s], w, src1)
-          }
+          for (int s = 0; s < 5; ++s) { D3_RELAX_K(c[s], l[s], w[s], src1) }
         };
         u32 cdA[5], cdB[5];
+        double wA[5], wB[5];
         codes(cdA, p0);
-        if (p0 == 0 && stop == 32u) {           // (a whole window, the usual case: a loop without decisions — 717 cycles a position against 1 008)
+        if (p0 == 0 && stop == 32u) {           // (a whole window, the usual case: a loop without decisions)
+          codes(cdB, 1u);
+          weights(wA, cdA);
 #pragma unroll 1
           for (u32 p = 0; p < 32u; p += 2u) {
-            codes(cdB, p + 1u);
-            relax(cdA, p);
+            weights(wB, cdB);
             if (p + 2u < 32u) codes(cdA, p + 2u);
-            relax(cdB, p + 1u);
+            relax(wA, p);
+            if (p + 2u < 32u) weights(wA, cdA);
+            if (p + 3u < 32u) codes(cdB, p + 3u);
+            relax(wB, p + 1u);
           }
         } else {
+          if (p0 + 1u < stop) codes(cdB, p0 + 1u);
+          weights(wA, cdA);
 #pragma unroll 1
           for (u32 p = p0; p < stop; p += 2u) {
-            if (p + 1u < stop) codes(cdB, p + 1u);
-            relax(cdA, p);
-            if (p + 1u >= stop) break;
+            if (p + 1u < stop) weights(wB, cdB);
             if (p + 2u < stop) codes(cdA, p + 2u);
-            relax(cdB, p + 1u);
+            relax(wA, p);
+            if (p + 1u >= stop) break;
+            if (p + 2u < stop) weights(wA, cdA);
+            if (p + 3u < stop) codes(cdB, p + 3u);
+            relax(wB, p + 1u);
           }
         }
         const u32 far_ = d5_max64(lane >= p0 && lane < stop ? lane + W.kend : 0u);
@@ -761,7 +780,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
         const u32 endp = lane + W.kend;                                   // the last cell of the row, from the window's base
         const u64 shortm = __ballot(W.kend != ZMX_MAX_MATCH) & rest;
         const u32 e_rel = shortm ? rdlane_u32(endp, (u32)__ffsll((long long)shortm) - 1u) : 0xffffffffu;
-        const u64 odd = (__ballot(W.fl != f0 || endp > e_rel || (W.kend != ZMX_MAX_MATCH && endp != e_rel) || W.kend < 3u) | W.ms | W.mb) & rest;
+        const u64 odd = (__ballot(((W.fl ^ f0) & 0x1ffu) != 0 || endp > e_rel || (W.kend != ZMX_MAX_MATCH && endp != e_rel) || W.kend < 3u) | W.ms | W.mb) & rest;
         const u32 stop = odd ? (u32)__ffsll((long long)odd) - 1u : W.nav;
         if (stop <= p0) return p0;
         const bool cut_e = (shortm & ((stop >= 64u ? 0ull : (1ull << stop)) - 1ull)) != 0;   // a short row in [p0, stop)
@@ -860,6 +879,28 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
         u32 gk_ = 6;
         if ((W.ms >> p) & 1) {
           // long-run shortcut at position j (squeeze.c:251-271)
+          // ---- (RUNS) what FOLLOWS the shortcut deep inside a run is known before it is walked: position e = j + 258 is
+          // exempt from the test (squeeze.c:273), a full run row, and e + 1 is flagged again — the reference then does 258
+          // more copies, and so on every 259 bytes to the end of the run.  Walked the ordinary way each such cycle was a
+          // spill of the cells to put them back on the 32-position grid, a window header with its memory round trip, a
+          // one-position stretch with its room test: 10 000 - 16 000 cycles for one row and 258 additions (23 % of a run
+          // task's time, profiles/r06_profZ.txt).  The CHAIN below asks for the headers of up to 32 cycles ahead in ONE
+          // load, keeps the cells in a frame that does not move (cycle m: the frame starts at e_0 + 258 m, the exempt cell is
+          // its index m, the copies land on the lanes they came from) and goes back on the grid once, when the pattern or a
+          // task boundary ends it.  Every cycle does what the windows it replaces would have done, in their order.
+          u64 ch_good = 0;
+          uint2 ch_dh = make_uint2(0, 0);
+          if (RUNS && P.chain_fast) {
+            const u32 pe = j + ZMX_MAX_MATCH + 259u * (lane >> 1) + (lane & 1u);     // lane 2m: e_m, lane 2m + 1: e_m + 1
+            const bool pin = pe < B;
+            const u32 pq = pin ? pe : B - 1u;
+            ch_dh = dbase[pq];
+            const u32 pbw = badpos[(bit_off + pq) >> 5];
+            const bool bad = ((pbw >> ((bit_off + pq) & 31u)) & 1u) != 0;
+            const u64 ok_e = __ballot(pin && ((ch_dh.y >> 17) & 1u) != 0 && (ch_dh.y & 0xffffu) == ZMX_MAX_MATCH && !bad);
+            const u64 ok_s = __ballot(pin && ((ch_dh.y >> 16) & 1u) != 0);
+            ch_good = ok_e & (ok_s >> 1) & 0x5555555555555555ull;
+          }
           if (lane >= skip0 && lane < p && wbase + lane >= la_lo) put_la(wbase + lane, (u16)(l[0] ? wbase + lane + 1 - l[0] : 0u));
           if (st_ok && st_land < st_iss) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           st_ok = false;                          // (the cells are spilled where the staged codes lie)
@@ -879,19 +920,107 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
             const u32 t = 64u * r + lane;
             if (t < ZMX_MAX_MATCH && j + t >= la_lo) put_la(j + t, s_xl[p + t]);
           }
-          // the registers go to the window that holds position j + 258: cell j + 258 + t sits at index t + d
-          const u32 d = (j + ZMX_MAX_MATCH) & 31u;
+          u32 e_next = j + ZMX_MAX_MATCH;         // the exempt position behind the last shortcut taken
+          u32 src0 = p;                           // where its cell lies in the spilled copy
+          bool ch_ran = false;
+          if (RUNS && (ch_good & 1ull) != 0) {
+            // the frame: index i = 64 s + lane is cell fb + i; the exempt cell of cycle m is index m
+            u32 fb = e_next, n = 0;
+            bool loaded = false;
+            for (;;) {
+              const u32 e = fb + n;               // = j + 258 + 259 m
+              const u32 d_ = e & 31u, wb_ = e - d_;
+              // what the loop head would do with the window at wb_ (and, for d_ = 31, with the one behind it): end the
+              // task, take the entry snapshot, take a mid snapshot — the ordinary walk does those
+              if (((ch_good >> (2u * n)) & 1ull) == 0 || n >= 30u || d_ == 31u || wb_ >= J.pend) break;
+              if (J.spec && la_lo == SEG_NONE && wb_ >= J.pout) break;
+              if (!loaded) {
+#pragma unroll
+                for (int s = 0; s < 6; ++s) {
+                  const u32 i = 64u * s + lane;
+                  const bool in = i < ZMX_MAX_MATCH;
+                  const float v = s_xc[in ? p + i : 0u];
+                  c[s] = in ? (float)((double)v + symbolcost258) : 1e30f;
+                  l[s] = in ? j + i + 1u : 0u;
+                }
+                loaded = true;
+              }
+              if (mid_hi != 0 && la_lo != SEG_NONE && d_ == 0 && (wb_ & 63u) == 0) {
+                const u32 c0_ = rdlane_u32(__float_as_uint(c[0]), n);
+                if (c0_ < 0x70000000u && __uint_as_float(c0_) + mid_margin >= __uint_as_float(mid_hi)) break;
+              }
+              // ---- the exempt position e: a full run row (the literal and (k, distance 1), k = 3 .. 258; no edge of it below
+              //      mincost — its bit of k_badscan's map is clear —, so squeeze.c:293 is a no-op) from the cell at index n
+              {
+                const u32 y_ = rdlane_u32(ch_dh.y, 2u * n);
+                const double wl = code_w((1u + ((y_ >> 18) & 255u)) * 8u);
+                const double cj = (double)rdlane_f32(c[0], n);
+                const u32 src1 = e + 1u;
+                double w5[5];
+#pragma unroll
+                for (int s = 0; s < 5; ++s) {
+                  const u32 k1 = 64u * (u32)s + lane - n - 1u;
+                  w5[s] = s_w1[k1 < ZMX_MAX_MATCH ? k1 : 1u];         // ([1] = the dead slot k = 2: +inf)
+                }
+#pragma unroll
+                for (int s = 0; s < 5; ++s) {
+                  const u32 k1 = 64u * (u32)s + lane - n - 1u;
+                  const double w = k1 == 0 ? wl : w5[s];
+                  D3_RELAX_K(c[s], l[s], w, src1)
+                }
+              }
+              // cell e is final
+              if (lane == n && e >= la_lo) put_la(e, (u16)(l[0] ? e + 1u - l[0] : 0u));
+#pragma unroll
+              for (int s = 0; s < 5; ++s) vmax = fmaxf(vmax, c[s] < 1e29f ? c[s] : 0.0f);
+              // ---- the shortcut at e + 1: cells e + 1 .. e + 258 (indices n + 1 .. n + 258) are consumed with the lengths
+              //      they have, cell x + 258 = cell x + symbolcost — on the lane it is on, in the frame 258 further on
+#pragma unroll
+              for (int s = 0; s < 5; ++s) {
+                const u32 i = 64u * (u32)s + lane;
+                const u32 x = fb + i;
+                const bool in = i - n - 1u < ZMX_MAX_MATCH;
+                if (in && x >= la_lo) put_la(x, (u16)(l[s] ? x + 1u - l[s] : 0u));
+                c[s] = in ? (float)((double)c[s] + symbolcost258) : 1e30f;
+                l[s] = in ? x + 1u : 0u;
+              }
+              fb += ZMX_MAX_MATCH;
+              ++n;
+              ++n_slow;
+              if (PROF) ++gr[2];
+            }
+            if (loaded) {
+              // (the header of the window the walk goes on in: asked for now — the one requested before the chain was for
+              //  the window behind the first shortcut)
+              {
+                const u32 nb_ = (fb + n) & ~31u;
+                const u32 nj = nb_ + lane < B ? nb_ + lane : B - 1u;
+                gpf_base = nb_;
+                gpf_dh = dbase[nj];
+                gpf_bw = badpos[(bit_off + nj) >> 5];
+              }
+              wave_lds_sync();
+#pragma unroll
+              for (int s = 0; s < 5; ++s) s_xc[64 * s + lane] = c[s];
+              wave_lds_sync();
+              ch_ran = true;
+              e_next = fb + n;
+              src0 = n;
+            }
+          }
+          // the registers go to the window that holds position e_next (j + 258 without the chain): its cell t sits at index t + d
+          const u32 d = e_next & 31u;
 #pragma unroll
           for (int s = 0; s < 6; ++s) {
             const u32 t = 64u * s + lane - d;
             const bool in = t < ZMX_MAX_MATCH;
-            const float v = s_xc[in ? p + t : 0u];
-            c[s] = in ? (float)((double)v + symbolcost258) : 1e30f;
-            l[s] = in ? j + t + 1 : 0u;
+            const float v = s_xc[in ? src0 + t : 0u];
+            c[s] = in ? (ch_ran ? v : (float)((double)v + symbolcost258)) : 1e30f;
+            l[s] = in ? e_next + t - (ZMX_MAX_MATCH - 1u) : 0u;
           }
           wave_lds_sync();
           if (fine_) { gq[0] += (u64)__builtin_readcyclecounter() - tp0_; ++gq[1]; }
-          wbase = j + ZMX_MAX_MATCH - d;
+          wbase = e_next - d;
           skip = d;
           reach = ZMX_MAX_MATCH - 1 + d;
           noshort = true;
@@ -907,7 +1036,8 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
         reach = reach > ke + p ? reach : ke + p;
         const u32 fl = rdlane_u32(W.fl, p);
         if (PROF) ++gr[(fl & 1u) ? 3 : 4];
-        if (RUNS && (fl & 1u)) {
+        if ((RUNS || ((fl >> 9) & 1u) != 0) && (fl & 1u)) {
+          // (the text variant comes here for the wide run rows, which have no codes: DPH_CODELESS = bit 9 of fl)
           // a run row (k_rowscan): the literal and (k, distance 1) for k = 3 .. ke — weights from tables of those edges,
           // nothing read from codes[]: inside runs of equal bytes, where every row is 258 wide, the six scattered code
           // loads per position were all the time there was (2 600 - 3 500 cycles a position).
@@ -918,7 +1048,7 @@ __device__ __forceinline__ void d5_run_job(const Dp4Params& P, const D4Job& J, u
           // table is the wave's own — 29 length symbols at distance symbol 0 plus the run's literal, for one binade —
           // and is rebuilt when the chain leaves the binade or the literal changes (a few times per task).
           const u32 sj = rdlane_u32(__float_as_uint(c[0]), p);
-          bool ipos = P.int_path != 0 && ((W.mb >> p) & 1ull) == 0 && sj >= 0x41800000u && sj < 0x4f000000u;   // (2^4 .. 2^31)
+          bool ipos = RUNS && P.int_path != 0 && ((W.mb >> p) & 1ull) == 0 && sj >= 0x41800000u && sj < 0x4f000000u;   // (2^4 .. 2^31)
           if (ipos && ((sj & 0x7f800000u) != r1_lo || lit != r1_lit)) r1_build(sj, lit);
           ipos = ipos && r1_lo != 0 && sj + r1_rmax < r1_lo + 0x800000u;
           if (ipos) {
@@ -1170,7 +1300,7 @@ __global__ __launch_bounds__(64) void k_taskkind(TaskKindParams P) {
   const u32* wf = P.winflag + P.win_off[K.block];
   const u32 w0 = K.q >> 5, w1 = ((K.pend < B ? K.pend : B) + 31u) >> 5;
   u32 g = 0;
-  for (u32 w = w0 + threadIdx.x; w < w1; w += 64) g += wf[w] == 0 || wf[w] == 3 ? 1u : 0u;
+  for (u32 w = w0 + threadIdx.x; w < w1; w += 64) g += (wf[w] & 0xffu) == 0 || (wf[w] & 0xffu) == 3 ? 1u : 0u;
   g = wave_scan_add(g);
   if (threadIdx.x == 63) P.kind[t] = 4u * g >= (w1 - w0) && g >= 4u ? 1u : 0u;
 }
@@ -1438,8 +1568,12 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
     n_pos += (T.pend < B ? T.pend : B) - (J.start < B ? J.start : B);
     // windows of the task that k_dp5_spec's fast paths cannot take (k_mkdesc)
     const u32 w0 = J.start >> 5, w1 = ((T.pend < B ? T.pend : B) + 31u) >> 5;
-    u32 generic = 0, mine = 0;
-    for (u32 w = w0 + threadIdx.x; w < w1; w += blockDim.x) { generic += winflag[w] == 0 ? 1u : 0u; ++mine; }
+    u32 generic = 0, mine = 0, nocodes = 0;
+    for (u32 w = w0 + threadIdx.x; w < w1; w += blockDim.x) {
+      generic += (winflag[w] & 0xffu) == 0 ? 1u : 0u;
+      nocodes |= winflag[w] & D5_WF_CODELESS;
+      ++mine;
+    }
     // (the barriers also mean: every wave has read the old exit[t] / exit[t - 1])
     // (automatic, P.fix_lean_min < 0: the lean job where most of the windows are of the generic kind — runs of equal
     //  bytes: its run-row path reads no codes, the pipeline's ring would restart at every shortcut.  Counted per
@@ -1447,9 +1581,10 @@ __global__ __launch_bounds__(64 * (D3_NB + 2)) void k_dp4_fix(Dp4Params P) {
     const int n_generic = __syncthreads_count((int)generic);
     const int n_major = __syncthreads_count(mine > 0 && 2 * generic >= mine ? 1 : 0);
     const int n_have = __syncthreads_count(mine > 0 ? 1 : 0);
+    const int n_nocodes = __syncthreads_count(nocodes != 0 ? 1 : 0);   // (a wide run row without codes: only the lean job's tables know its weights)
     // (a predecessor that stopped inside a shortcut's window — skip — can only be continued by the job that knows
     //  about it)
-    const bool lean = (!from_mid && P.exit[t - 1].skip != 0) || (P.fix_lean_min >= 0 ? n_generic >= P.fix_lean_min : 2 * n_major >= n_have);
+    const bool lean = (!from_mid && P.exit[t - 1].skip != 0) || n_nocodes > 0 || (P.fix_lean_min >= 0 ? n_generic >= P.fix_lean_min : 2 * n_major >= n_have);
     const u64 cr0 = __builtin_readcyclecounter();
     if (lean) {
       ++n_lean;

@@ -326,7 +326,7 @@ __device__ __forceinline__ void d6_run_job(const Dp4Params& P, const D4Job& J, u
   }
   auto win_kind = [&](u32 wb) -> u32 {
     if ((wb & 31u) != 0 || wb + 32u > B) return 0u;
-    const u32 f = winflag[wb >> 5];
+    const u32 f = winflag[wb >> 5] & 0xffu;
     if (f == 0) return 0u;
     const u32 g = bit_off + wb;
     const u64 two = ((u64)badw[(g >> 5) + 1] << 32) | badw[g >> 5];
@@ -380,7 +380,7 @@ __device__ __forceinline__ void d6_run_job(const Dp4Params& P, const D4Job& J, u
       if (skip) {
         kind = 0;
       } else if (pf_w == (wbase >> 5) && (wbase & 31u) == 0 && wbase + 32u <= B) {
-        const u32 f = rdlane_u32(pf_meta, 34), g = bit_off + wbase;
+        const u32 f = rdlane_u32(pf_meta, 34) & 0xffu, g = bit_off + wbase;
         const u64 two = ((u64)rdlane_u32(pf_meta, 41) << 32) | rdlane_u32(pf_meta, 40);
         kind = f != 0 && (u32)(two >> (g & 31u)) == 0 ? f : 0u;
       } else {

@@ -1296,6 +1296,10 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
   rp.recs = t->d_recs;
   rp.dph = t->d_dph;
   rp.block_edges = t->d_block_edges;
+  // (ZOPFLI_AMD_RUN_CODES=1: codes for every row, as in round 5; the serial chain — ZOPFLI_AMD_SEG_L=0, k_dp4's pipeline
+  //  over whole blocks — needs them)
+  static const bool all_codes = [] { const char* e = std::getenv("ZOPFLI_AMD_RUN_CODES"); return e && std::atoi(e) != 0; }();
+  rp.codeless = !all_codes && SegL(t->total_b) != 0 ? 1u : 0u;
   hipLaunchKernelGGL(k_rowscan, dim3(static_cast<unsigned>(nb)), dim3(1024), 0, c->stream, rp);
   KCHK(c, "k_rowscan");
   HIPCHK(hipGetLastError());
@@ -1772,6 +1776,8 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   cp.fix_lean_min = fix_lean;
   static const int int_path = [] { const char* e = std::getenv("ZOPFLI_AMD_INT_PATH"); return e ? std::atoi(e) : 1; }();
   cp.int_path = int_path;
+  static const int chain_fast = [] { const char* e = std::getenv("ZOPFLI_AMD_SHORTCUT_CHAIN"); return e ? std::atoi(e) : 1; }();
+  cp.chain_fast = chain_fast;
   cp.redo_count = t->d_redo;
   cp.redo_wg = t->d_redo + 4;
   cp.redo_pass = 0;

@@ -384,9 +384,17 @@ __device__ __forceinline__ uint2 greedy_window(const u32* rbase, u32 wb, u32 lan
 struct RowScanParams {
   const BlockDesc* blocks;
   const u32* recs;
-  uint2* dph;          // per block position: {roff, kend | shortcut << 16 | run row << 17 | literal << 18}
+  uint2* dph;          // per block position: {roff, kend | shortcut << 16 | run row << 17 | literal << 18 | codeless << 26}
   u64* block_edges;    // per block: total row length
+  u32 codeless;        // 1 = wide run rows (64+ edges) get no codes: DPH_CODELESS (0: the serial chain k_dp4 reads every row's codes)
 };
+// A WIDE RUN ROW — one change point, at distance 1, 64 or more edges: the inside of a run of equal bytes — has no codes in
+// codes[]: its weights are w(length symbol of k, distance symbol 0), which every chain kernel takes from tables by length
+// (zmx_dp5.h: s_rk / s_ri / s_w1), never from the row.  Round 5 wrote them all the same — 258 two-byte codes for every such
+// position, 49 GB per 100 MB of long runs, 16 x the input, ~90 % of it never read (profiles/r05_classZ100MB_pmc.json) —
+// and the code budget then split such batches.  The row takes no room in the layout (its offset is its successor's).
+#define DPH_CODELESS (1u << 26)
+__device__ __forceinline__ u32 dph_layout_len(u32 y) { return (y & DPH_CODELESS) ? 0u : (y & 0xffffu); }
 
 __global__ __launch_bounds__(1024) void k_rowscan(RowScanParams P) {
   __shared__ u32 s_wsum[16];
@@ -416,7 +424,9 @@ __global__ __launch_bounds__(1024) void k_rowscan(RowScanParams P) {
         sflag |= same_back > ZMX_MAX_MATCH ? 1u : 0u;
       }
     }
-    const u32 incl = wave_scan_add(kend);
+    const bool nocodes = P.codeless != 0 && (sflag & 2u) != 0 && kend >= 64u;
+    const u32 klay = nocodes ? 0u : kend;          // what the row takes in codes[]
+    const u32 incl = wave_scan_add(klay);
     if (lane == 63) s_wsum[wid] = incl;
     __syncthreads();
     u32 woff = 0, tot = 0;
@@ -426,7 +436,7 @@ __global__ __launch_bounds__(1024) void k_rowscan(RowScanParams P) {
       if (w < wid) woff += v;
       tot += v;
     }
-    if (act) out[jj] = make_uint2((u32)carry + woff + incl - kend, kend | (sflag << 16));
+    if (act) out[jj] = make_uint2((u32)carry + woff + incl - klay, kend | (sflag << 16) | (nocodes ? DPH_CODELESS : 0u));
     carry += tot;
     __syncthreads();
   }
@@ -502,8 +512,9 @@ __global__ __launch_bounds__(256) void k_codes(CodeParams P) {
     const u32 lit = (ra.y >> 16) & 255u;
     const u32 ncpf = ra.y >> 24;
     const u32 kend = dh.y & 0xffffu;
+    const u32 klay = dph_layout_len(dh.y);      // (0: a wide run row, no codes)
     const u32 off = dh.x;                       // block-relative row offset
-    const u32 offend = off + (act ? kend : 0u);
+    const u32 offend = off + (act ? klay : 0u);
     const u32 off0 = rdlane_u32(off, 0);
 
     wave_lds_sync();  // the previous group's headers are dead
@@ -541,7 +552,7 @@ __global__ __launch_bounds__(256) void k_codes(CodeParams P) {
       wave_lds_sync();
       for (u32 e = lane; e < (E + 3) / 4; e += 64) reinterpret_cast<u32*>(mark)[e] = 0;
       wave_lds_sync();
-      if (lane >= q && lane < q + n) mark[off - off_q] = (u8)(lane + 1);
+      if (lane >= q && lane < q + n && klay != 0) mark[off - off_q] = (u8)(lane + 1);
       wave_lds_sync();
       const u32 rel_q = off_q - off0;
       u32 carry = q + 1;
@@ -669,9 +680,18 @@ __global__ __launch_bounds__(256) void k_badscan(BadScanParams P) {
     const uint2 dh = P.dph[bd.pos_off + p];
     const u32 kend = dh.y & 0xffffu;
     bool any = false;
-    for (u32 k = 3; k <= kend; ++k) {
-      const u32 c = (u32)codes[(u64)dh.x + k - 1] >> 3;
-      any |= ((bad[4 + (c >> 5)] >> (c & 31)) & 1u) != 0;
+    if (dh.y & DPH_CODELESS) {
+      // a wide run row: (k, distance 1) for k = 3 .. kend, i.e. every length symbol up to kend's at distance symbol 0
+      const u32 smax = (u32)(dev_length_symbol(kend) - 257);
+      for (u32 sy = 0; sy <= smax; ++sy) {
+        const u32 c = 257u + 30u * sy;
+        any |= ((bad[4 + (c >> 5)] >> (c & 31)) & 1u) != 0;
+      }
+    } else {
+      for (u32 k = 3; k <= kend; ++k) {
+        const u32 c = (u32)codes[(u64)dh.x + k - 1] >> 3;
+        any |= ((bad[4 + (c >> 5)] >> (c & 31)) & 1u) != 0;
+      }
     }
     if (any) {
       const u64 gp = bd.pos_off + p;

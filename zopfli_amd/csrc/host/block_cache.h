@@ -25,25 +25,35 @@ namespace zamd {
 
 class BlockCache {
  public:
-  static constexpr size_t kMinBytes = 32u << 10;   // smaller requests are malloc's own business
-  static constexpr int kClasses = 64;
+  static constexpr int kMinLog2 = 10;
+  static constexpr int kClasses = 80;
 
-  // Size class of a request: capacities 2^k and 3 * 2^(k-1) (at most a third wasted), k >= 15.
+  // smaller requests are malloc's own business (ZOPFLI_AMD_HOST_CACHE_MIN, bytes; at least 2^kMinLog2)
+  static size_t MinBytes() {
+    static const size_t m = [] {
+      const char* e = std::getenv("ZOPFLI_AMD_HOST_CACHE_MIN");
+      const long v = e ? std::atol(e) : (32l << 10);
+      return v > (1l << kMinLog2) ? static_cast<size_t>(v) : static_cast<size_t>(1) << kMinLog2;
+    }();
+    return m;
+  }
+
+  // Size class of a request: capacities 2^k and 3 * 2^(k-2) (at most a third wasted), k >= kMinLog2.
   static int ClassOf(size_t bytes, size_t* cap) {
-    int k = 15;
+    int k = kMinLog2;
     while ((static_cast<size_t>(1) << k) < bytes) ++k;
     const size_t pow2 = static_cast<size_t>(1) << k;
-    const size_t mid = (pow2 >> 2) * 3;           // 3 * 2^(k-2) = 0.75 * 2^k
-    if (k > 15 && mid >= bytes) {
+    const size_t mid = (pow2 >> 2) * 3;           // 0.75 * 2^k
+    if (k > kMinLog2 && mid >= bytes) {
       *cap = mid;
-      return 2 * (k - 15) - 1;
+      return 2 * (k - kMinLog2) - 1;
     }
     *cap = pow2;
-    return 2 * (k - 15);
+    return 2 * (k - kMinLog2);
   }
 
   static void* Take(size_t bytes) {
-    if (bytes < kMinBytes || Budget() == 0) return std::malloc(bytes ? bytes : 1);
+    if (bytes < MinBytes() || Budget() == 0) return std::malloc(bytes ? bytes : 1);
     size_t cap;
     const int c = ClassOf(bytes, &cap);
     if (c < kClasses) {
@@ -62,7 +72,7 @@ class BlockCache {
 
   static void Give(void* p, size_t bytes) {
     if (!p) return;
-    if (bytes >= kMinBytes && Budget() != 0) {
+    if (bytes >= MinBytes() && Budget() != 0) {
       size_t cap;
       const int c = ClassOf(bytes, &cap);
       if (c < kClasses) {

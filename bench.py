@@ -157,6 +157,64 @@ def measured_copy_gbs(torch, device):
         return None
 
 
+def _ref_small(task):
+    """One small file through the reference's ZopfliCompress, in a worker process."""
+    data, n = task
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    return len(ol.ref_compress(data, 0, n))
+
+
+def small_files_line(lib, api, generate, ZopfliOptions, numiterations, sets, callers=(1, 3, 16), with_reference=True):
+    """What zopfli is mostly used on: MANY SMALL FILES (zopfli.h:40-44: "10 - 15 iterations for small files"; zopflipng takes
+    15 iterations below 200 000 bytes, zopflipng_lib.cc:57-58).  Every file is one ZopfliCompress call with the reference's
+    default options, K caller threads at a time (the library's contexts: ZOPFLI_AMD_LANES per device; a caller beyond
+    them waits for a free one) — aggregate MB/s over the whole set, beside the reference on every host core this process
+    may use (one file per worker process at a time).  Class T and X files alternate; every stream is checked to
+    round-trip, the first four of each set against the reference's bytes."""
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as ol
+    opts = ZopfliOptions(numiterations, 1, 15)
+    out = {"options": "the reference's defaults (blocksplitting=1, blocksplittingmax=15), numiterations=%d, gzip" % numiterations,
+           "sets": []}
+    for count, size in sets:
+        files = [generate("TX"[i & 1], size, seed=1000 + i) for i in range(count)]
+        total = count * size / MB
+        rec = {"files": count, "bytes_each": size, "classes": "T and X alternating, seeds 1000 ...", "callers": {}}
+
+        def one(d):
+            return api.compress(d, api.FORMAT_GZIP, opts, lib=lib)
+        for f in files[:3]:
+            one(f)       # (warm: the first contexts exist)
+        ok = True
+        for k in callers:
+            with cf.ThreadPoolExecutor(k) as ex:
+                list(ex.map(one, files[:min(len(files), 2 * k)]))      # (warm: the k-th context exists)
+                t0 = time.perf_counter()
+                res = list(ex.map(one, files))
+                dt = time.perf_counter() - t0
+            ok = ok and all(gzip.decompress(r) == f for r, f in zip(res[:16], files[:16]))
+            rec["callers"][str(k)] = {"value": round(total / dt, 3), "unit": "MB/s", "ms_per_file": round(dt / count * 1e3, 3)}
+            last = res
+        rec["roundtrip_ok"] = ok
+        if with_reference and ol.have_ref():
+            rec["bitexact_vs_reference_first4"] = all(last[i] == ol.ref_compress(files[i], 0, numiterations) for i in range(min(4, count)))
+            cores = usable_cpus()
+            nref = min(count, 2 * cores)
+            with mp.get_context("fork").Pool(min(cores, nref)) as pool:
+                t0 = time.perf_counter()
+                pool.map(_ref_small, [(f, numiterations) for f in files[:nref]], chunksize=1)
+                dtr = time.perf_counter() - t0
+            rec["reference_all_cores"] = {"value": round(nref * size / MB / dtr, 3), "unit": "MB/s", "cores": min(cores, nref),
+                                          "sample": "the first %d files, one per worker process at a time, %.1f s" % (nref, dtr)}
+            best = max(v["value"] for v in rec["callers"].values())
+            rec["best_vs_reference_all_cores"] = round(best / rec["reference_all_cores"]["value"], 2)
+        out["sets"].append(rec)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,6 +248,9 @@ def main():
                     "--size x N of them if it is longer) are the workload; `data` in the line names it")
     ap.add_argument("--devices", default=None, help="N = 1: ZOPFLI_AMD_DEVICES for the ZopfliCompress entry (e.g. 0,0: the "
                     "in-process multi-device path on one GPU)")
+    ap.add_argument("--no-small-files", action="store_true", help="N = 1: skip the `small_files` line (many 64 KiB / 1 MB files through "
+                    "1 / 3 / 16 concurrent ZopfliCompress callers)")
+    ap.add_argument("--small-files-only", action="store_true", help="N = 1: only the `small_files` measurement, on a bigger set")
     ap.add_argument("--no-in-process", action="store_true", help="N > 1: skip the extra measurement of the same total input "
                     "through ZopfliCompress in rank 0's process with ZOPFLI_AMD_DEVICES = N (what a drop-in caller gets)")
     args = ap.parse_args()
@@ -273,6 +334,11 @@ def main():
                     cdist.close()
                 cdist = None
                 gather_kind += " (library RCCL gather unavailable: %s)" % err
+
+    if args.small_files_only:
+        print(json.dumps({"small_files": small_files_line(lib, api, generate, ZopfliOptions, args.numiterations,
+                                                          [(1000, 65536), (200, 1000000)])}), flush=True)
+        return
 
     def run_one(args):
         """One measured configuration (args.scaling / args.blocksplitting resolved); the JSON line on rank 0."""
@@ -701,6 +767,9 @@ def _run_one(args, rank, world, dev_index, device, torch, dist, lib, cdist, gath
                           "blocksplittingmax=15 (configs[2] on one GPU)"}
         if in_process is not None:
             line["in_process"] = in_process
+        if world == 1 and not args.no_small_files and args.entry != "resident" and corpus is None:
+            line["small_files"] = small_files_line(lib, api, generate, ZopfliOptions, args.numiterations, [(200, 65536), (48, 1000000)],
+                                                   with_reference=not args.no_cpu_baseline)
         if not args.no_cpu_baseline:
             # (rank 0's host cores; at N > 1 the other ranks wait at the next collective meanwhile)
             sample = shard[:min(args.cpu_sample, size)]

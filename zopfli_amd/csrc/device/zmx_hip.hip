@@ -157,6 +157,9 @@ struct zmx_ctx {
   hipStream_t alt_stream[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // zmx_ctx_set_priority: [0] the created pair, [1] high, [2] low
   hipEvent_t ev2[2] = {nullptr, nullptr};
   u32* h_stage = nullptr;    // pinned staging for store downloads (grow-only)
+  // pinned buffers of table sets that were freed (h_runin / h_runout: a few KB per block), kept for the next set:
+  // hipHostMalloc + hipHostFree were ~ 0.4 ms of every table set, a tenth of a small call's fixed cost
+  std::vector<std::pair<unsigned char*, size_t>> pinned_free;
   size_t stage_cap = 0;      // in u32
   // ZOPFLI_AMD_GUARD (below): the bytes the caller asked for and who asked, per live allocation (keyed like pool_live)
   struct GuardInfo { size_t bytes; const char* tag; };
@@ -226,6 +229,7 @@ struct zmx_tables {
   unsigned char* d_runout = nullptr;
   unsigned char* h_runin = nullptr;
   unsigned char* h_runout = nullptr;
+  size_t h_runin_cap = 0, h_runout_cap = 0;
   size_t runin_bytes = 0, runout_bytes = 0;
   u64* d_prof = nullptr;      // nb * ZMX_PROF_N counters when ZOPFLI_AMD_PROF is set
   // the chain's tasks (zmx_dp4.h)
@@ -573,6 +577,29 @@ void zmx_internal_stats_add(const double* in19) {
   for (int i = 0; i < 19; ++i) d[i] += in19[i];
 }
 
+// Pinned host buffers of a context, recycled between table sets (see zmx_ctx::pinned_free).
+static hipError_t PinnedTake(zmx_ctx* c, unsigned char** p, size_t bytes, size_t* cap) {
+  size_t best = c->pinned_free.size();
+  for (size_t i = 0; i < c->pinned_free.size(); ++i) {
+    const size_t k = c->pinned_free[i].second;
+    if (k >= bytes && k <= 4 * bytes + 4096 && (best == c->pinned_free.size() || k < c->pinned_free[best].second)) best = i;
+  }
+  if (best != c->pinned_free.size()) {
+    *p = c->pinned_free[best].first;
+    *cap = c->pinned_free[best].second;
+    c->pinned_free.erase(c->pinned_free.begin() + static_cast<long>(best));
+    return hipSuccess;
+  }
+  *cap = bytes < 4096 ? 4096 : bytes;
+  return hipHostMalloc(reinterpret_cast<void**>(p), *cap, hipHostMallocDefault);
+}
+static void PinnedGive(zmx_ctx* c, unsigned char** p, size_t cap) {
+  if (!*p) return;
+  if (c && c->pinned_free.size() < 8 && cap <= (64u << 20)) c->pinned_free.emplace_back(*p, cap);
+  else (void)hipHostFree(*p);
+  *p = nullptr;
+}
+
 int zmx_ctx_create(int device, zmx_ctx** out) {
   int n = 0;
   HIPCHK(hipGetDeviceCount(&n));
@@ -642,6 +669,7 @@ void zmx_ctx_destroy(zmx_ctx* c) {
   if (!c) return;
   DeviceGuard dev_guard(c->device);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
+  for (auto& f : c->pinned_free) (void)hipHostFree(f.first);
   for (auto& f : c->pool_free) (void)hipFree(f.first);
   DevCached(c).fetch_sub(c->pool_free_bytes, std::memory_order_relaxed);
   // (the input and k_match2's scratch are pooled allocations too; in guard mode the caller's pointer lies behind a red zone)
@@ -720,8 +748,8 @@ static void ReleaseTableArrays(zmx_ctx* c, zmx_tables* t, bool keep_stores) {
   rel(t->d_redo);
   for (int h = 0; h < 2; ++h) { rel(t->d_rank[h]); rel(t->d_bucket[h]); }
   t->d_sorted[0] = t->d_sorted[1] = nullptr;
-  if (t->h_runin) { (void)hipHostFree(t->h_runin); t->h_runin = nullptr; }
-  if (t->h_runout) { (void)hipHostFree(t->h_runout); t->h_runout = nullptr; }
+  PinnedGive(c, &t->h_runin, t->h_runin_cap);
+  PinnedGive(c, &t->h_runout, t->h_runout_cap);
   if (!keep_stores) { rel(t->d_store[0]); rel(t->d_store[1]); }
 }
 
@@ -914,8 +942,8 @@ static int BuildTables(zmx_ctx* c, const zmx_block* blocks, size_t nb, zmx_table
     t->runout_bytes = out_flags + 4 * sizeof(u32);
     HIPCHK(PoolAlloc(c, &t->d_runin, t->runin_bytes));
     HIPCHK(PoolAlloc(c, &t->d_runout, t->runout_bytes));
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&t->h_runin), t->runin_bytes, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&t->h_runout), t->runout_bytes, hipHostMallocDefault));
+    HIPCHK(PinnedTake(c, &t->h_runin, t->runin_bytes, &t->h_runin_cap));
+    HIPCHK(PinnedTake(c, &t->h_runout, t->runout_bytes, &t->h_runout_cap));
     t->d_cost = reinterpret_cast<double*>(t->d_runin + in_cost);
     t->d_mincost = reinterpret_cast<double*>(t->d_runin + in_min);
     t->d_runinfo = reinterpret_cast<float*>(t->d_runin + in_info);

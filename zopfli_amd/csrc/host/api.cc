@@ -90,8 +90,12 @@ class ContextPool {
   // contexts: one half's host phases run beside the other half's kernels)
   // `polite`: a call that is not large takes several contexts of a device only while it is the only caller — with other
   // calls in flight (holding contexts or waiting for one) it takes one, as every call below the dealing threshold does.
+  // `small`: a call of a master block or two (a small file: what zopfli is mostly used on).  When every context of its
+  // device is busy such a call gets a context of its own beyond the ZOPFLI_AMD_LANES of the dealing — up to
+  // ZOPFLI_AMD_SMALL_LANES (16) per device — instead of waiting: sixteen callers with 64 KiB files keep eight streams of
+  // small kernels and eight host threads' split searches going, where three contexts left thirteen of them waiting.
   std::vector<zmx_ctx*> Acquire(size_t want, size_t per_device = 1, std::vector<int>* device_of = nullptr,
-                                bool polite = false) {
+                                bool polite = false, bool small = false) {
     std::unique_lock<std::mutex> lock(mu_);
     Init();
     ++in_flight_;
@@ -117,7 +121,8 @@ class ContextPool {
           for (auto& sl : dev.slots) {
             if (!sl->busy && std::find(slots.begin(), slots.end(), sl.get()) == slots.end()) { s = sl.get(); break; }
           }
-          if (!s && dev.slots.size() < lanes_ && (may_create_more || lane == 0)) {
+          if (!s && (dev.slots.size() < lanes_ || (small && per_device == 1 && dev.slots.size() < small_lanes_)) &&
+              (may_create_more || lane == 0)) {
             // a new context: the slot is taken now, the context is created below without the pool's lock (HIP
             // start-up, streams, events: up to seconds on first use, and every Release would wait behind it)
             dev.slots.emplace_back(new Slot{nullptr, false, &dev});
@@ -202,6 +207,10 @@ class ContextPool {
     }
     cv_.notify_all();
   }
+  size_t InFlight() {
+    std::lock_guard<std::mutex> lock(mu_);
+    return in_flight_;
+  }
   void Release(const std::vector<zmx_ctx*>& ctxs) {
     {
       std::lock_guard<std::mutex> lock(mu_);
@@ -261,6 +270,8 @@ class ContextPool {
       Die("no usable gfx950 device (there is no CPU fallback)");
     }
     if (const char* e = std::getenv("ZOPFLI_AMD_LANES")) lanes_ = static_cast<size_t>(std::max(1, std::atoi(e)));
+    if (const char* e = std::getenv("ZOPFLI_AMD_SMALL_LANES")) small_lanes_ = static_cast<size_t>(std::max(1, std::atoi(e)));
+    small_lanes_ = std::max(small_lanes_, lanes_);
     zmx_set_oom_hook(&ContextPool::OomHook);
   }
   static void OomHook(int device);
@@ -268,6 +279,7 @@ class ContextPool {
   std::condition_variable cv_;
   std::vector<Device> devices_;
   size_t lanes_ = 3;
+  size_t small_lanes_ = 16;  // contexts per device that calls of one or two master blocks may bring into being (1000 x 64 KiB through 16 callers: 8.9 MB/s with 3, 20.4 with 8, 27.7 with 16; profiles/r06_small_files.txt)
   size_t in_flight_ = 0;     // calls between Acquire and Release
   size_t polite_wishes_ = 0; // polite calls so far that asked for more than one context of a device
 };
@@ -290,8 +302,8 @@ double WallMs() {
 struct Lease {
   std::vector<int> device_of;      // HIP device index of ctxs[i]
   std::vector<zmx_ctx*> ctxs;
-  explicit Lease(size_t want, size_t per_device = 1, bool polite = false)
-      : ctxs(Pool().Acquire(want, per_device, &device_of, polite)) {}
+  explicit Lease(size_t want, size_t per_device = 1, bool polite = false, bool small = false)
+      : ctxs(Pool().Acquire(want, per_device, &device_of, polite, small)) {}
   ~Lease() { Pool().Release(ctxs); }
 };
 
@@ -398,8 +410,17 @@ int RunPartsShardedOnce(const ZopfliOptions& options, int btype, const unsigned 
   }
   const double tr_begin = WallMs();
   const Lease lease(parts.size(), split_from && parts.size() >= split_from && !one_context ? split_ways : 1,
-                    /*polite=*/parts.size() < 32);
+                    /*polite=*/parts.size() < 32, /*small=*/parts.size() <= 2);
   const double tr_lease = WallMs();
+  // A small call among other calls in flight (many small files, a caller thread each): its host phases — the split
+  // searches' rounds of nine probes, the cost models of a block or two — run on the calling thread.  The worker pool takes
+  // one fork-join at a time: sixteen callers queueing for it, each job a few microseconds of work per woken thread, were
+  // slower than three (profiles/r06_small_files.txt); the callers are the parallelism.
+  struct InlineHostWork {
+    bool on, was;
+    explicit InlineHostWork(bool o) : on(o), was(zamd::g_inside_parallel_for) { if (on) zamd::g_inside_parallel_for = true; }
+    ~InlineHostWork() { if (on) zamd::g_inside_parallel_for = was; }
+  } inline_host(parts.size() <= 2 && Pool().InFlight() > 1);
   const std::vector<zmx_ctx*>& ctxs = lease.ctxs;
   const size_t ndev = std::min(ctxs.size(), parts.size());
   struct Shard {

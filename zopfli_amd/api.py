@@ -4,6 +4,10 @@ import os
 
 from ._build import LIB
 
+# (a variant build for A/B measurements and the -DZMX_EXPERIMENTS suite: tools/build_variant.py)
+if os.environ.get("ZOPFLI_AMD_LIB"):
+    LIB = os.environ["ZOPFLI_AMD_LIB"]
+
 FORMAT_GZIP, FORMAT_ZLIB, FORMAT_DEFLATE = 0, 1, 2  # zopfli.h:70-74
 CRC32, ADLER32 = 0, 1  # ZMX_CRC32, ZMX_ADLER32
 ZMX_HIST = 320

@@ -10,7 +10,9 @@
 // :495-505, writing the record, fetching the next position) as skipped-when-empty side blocks.
 #pragma once
 
+#ifndef M2_THREADS
 #define M2_THREADS 512   // 8 waves share one staged window: twice k_match's waves per CU for the same LDS
+#endif
 #define M2_IDLE 0u      // needs a position
 #define M2_WALK 1u      // at a candidate, not compared yet
 #define M2_CMP 2u       // comparing bytes with the candidate
@@ -36,7 +38,7 @@ __device__ __forceinline__ u64 m2_lds_u64(const u32* win, u32 byte_off) {
 }
 
 template <bool PROF, bool FILT>
-__global__ __launch_bounds__(M2_THREADS, 8) void k_match2(MatchParams P) {
+__global__ __launch_bounds__(M2_THREADS, M2_THREADS == 512 ? 8 : 4) void k_match2(MatchParams P) {
   __shared__ __align__(16) u32 win[MWIN_BYTES / 4 + 4];
   __shared__ u32 s_next, s_tile;
 

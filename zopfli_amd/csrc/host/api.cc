@@ -90,7 +90,9 @@ class ContextPool {
   // contexts: one half's host phases run beside the other half's kernels)
   // `polite`: a call that is not large takes several contexts of a device only while it is the only caller — with other
   // calls in flight (holding contexts or waiting for one) it takes one, as every call below the dealing threshold does.
-  // `small`: a call of a master block or two (a small file: what zopfli is mostly used on).  When every context of its
+  // `small`: a call below the 32 master blocks from which calls are dealt whatever else runs (small files — what zopfli is
+  // mostly used on — and the medium calls that, alone, politely take all three dealing contexts: a second such caller
+  // no longer waits for the first to finish).  When every context of its
   // device is busy such a call gets a context of its own beyond the ZOPFLI_AMD_LANES of the dealing — up to
   // ZOPFLI_AMD_SMALL_LANES (16) per device — instead of waiting: sixteen callers with 64 KiB files keep eight streams of
   // small kernels and eight host threads' split searches going, where three contexts left thirteen of them waiting.
@@ -410,7 +412,7 @@ int RunPartsShardedOnce(const ZopfliOptions& options, int btype, const unsigned 
   }
   const double tr_begin = WallMs();
   const Lease lease(parts.size(), split_from && parts.size() >= split_from && !one_context ? split_ways : 1,
-                    /*polite=*/parts.size() < 32, /*small=*/parts.size() <= 2);
+                    /*polite=*/parts.size() < 32, /*small=*/parts.size() < 32);
   const double tr_lease = WallMs();
   // A small call among other calls in flight (many small files, a caller thread each): its host phases — the split
   // searches' rounds of nine probes, the cost models of a block or two — run on the calling thread.  The worker pool takes

@@ -420,8 +420,8 @@ int RunPartsShardedOnce(const ZopfliOptions& options, int btype, const unsigned 
   // slower than three (profiles/r06_small_files.txt); the callers are the parallelism.
   struct InlineHostWork {
     bool on, was;
-    explicit InlineHostWork(bool o) : on(o), was(zamd::g_inside_parallel_for) { if (on) zamd::g_inside_parallel_for = true; }
-    ~InlineHostWork() { if (on) zamd::g_inside_parallel_for = was; }
+    explicit InlineHostWork(bool o) : on(o), was(zamd::g_host_inline) { if (on) zamd::g_host_inline = true; }
+    ~InlineHostWork() { if (on) zamd::g_host_inline = was; }
   } inline_host(parts.size() <= 2 && Pool().InFlight() > 1);
   const std::vector<zmx_ctx*>& ctxs = lease.ctxs;
   const size_t ndev = std::min(ctxs.size(), parts.size());

@@ -43,7 +43,7 @@ size_t FindMinimum(const SplitCost& f, size_t start, size_t end, double* smalles
   if (end - start < 1024) {
     const size_t n = end - start;
     std::vector<double> v(n);
-    ParallelFor((n + 15) / 16, [&](size_t c) {
+    ParallelForNested((n + 15) / 16, [&](size_t c) {
       for (size_t i = c * 16; i < n && i < c * 16 + 16; ++i) v[i] = f(start + i);
     });
     double best = kLarge;
@@ -65,7 +65,7 @@ size_t FindMinimum(const SplitCost& f, size_t start, size_t end, double* smalles
   while (end - start > kProbes) {
     const size_t step = (end - start) / (kProbes + 1);
     for (int i = 0; i < kProbes; ++i) probe[i] = start + (i + 1) * step;
-    ParallelFor(kProbes, [&](size_t i) { value[i] = f(probe[i]); });
+    ParallelForNested(kProbes, [&](size_t i) { value[i] = f(probe[i]); });
     int arg = 0;
     for (int i = 1; i < kProbes; ++i) {
       if (value[i] < value[arg]) arg = i;

@@ -260,7 +260,13 @@ class WidePool {
       std::lock_guard<std::mutex> lock(mu_);
       jobs_.push_back(job);
     }
-    wake_.notify_all();
+    // (a small job — the nine probes of a split search's round — wakes as many sleepers as it has tasks to give away,
+    //  not all hundred-odd: a round is a few hundred microseconds of work)
+    if (n > 16) {
+      wake_.notify_all();
+    } else {
+      for (size_t k = 1; k < n; ++k) wake_.notify_one();
+    }
     // the caller works on its own job, then waits for the tasks others took
     for (;;) {
       const size_t i = job->next.fetch_add(1, std::memory_order_relaxed);
@@ -324,7 +330,9 @@ class WidePool {
             }
           }
           if (job) break;
+          idle_.fetch_add(1, std::memory_order_relaxed);
           wake_.wait(lock);
+          idle_.fetch_sub(1, std::memory_order_relaxed);
         }
         ++turn;
       }
@@ -345,15 +353,22 @@ class WidePool {
   std::mutex mu_;
   std::condition_variable wake_, done_;
   std::vector<std::shared_ptr<Job>> jobs_;
+  std::atomic<int> idle_{0};     // workers with nothing to do (a nested fork-join is only worth registering when there are any)
+
+ public:
+  int Idle() const { return idle_.load(std::memory_order_relaxed); }
 };
 
 inline thread_local bool g_inside_parallel_for = false;
+// The calling thread's host phases run on the calling thread alone (api.cc: a small call among other calls in flight).
+inline thread_local bool g_host_inline = false;
+inline thread_local int g_nested_level = 0;       // ParallelForNested: one level only
 
 // Calls fn(i) for i in [0, n), dynamically load-balanced.  Nested calls run inline.
 template <typename Fn>
 void ParallelFor(size_t n, Fn&& fn) {
   bool& inside = g_inside_parallel_for;
-  if (n <= 1 || HostThreads() <= 1 || inside) {
+  if (n <= 1 || HostThreads() <= 1 || inside || g_host_inline) {
     for (size_t i = 0; i < n; ++i) fn(i);
     return;
   }
@@ -369,7 +384,7 @@ void ParallelFor(size_t n, Fn&& fn) {
 // The same on the wide pool when there are more tasks than the regular pool has threads.
 template <typename Fn>
 void ParallelForWide(size_t n, Fn&& fn) {
-  if (n <= HostThreads() || g_inside_parallel_for) {
+  if (n <= HostThreads() || g_inside_parallel_for || g_host_inline) {
     ParallelFor(n, fn);
     return;
   }
@@ -383,6 +398,38 @@ void ParallelForWide(size_t n, Fn&& fn) {
   //  WorkerPool takes one job at a time, and the shard threads of a dealt call would queue their split searches and
   //  encodes behind each other and behind the others' cost-model fork-joins)
   WidePool::Get().Run(n, body);
+}
+
+// A fork-join INSIDE a task of a parallel loop — the nine probes of a round of one master block's split search
+// (block_split.cc) while the loop runs a master block per task.  On the wide pool, which serves any number of jobs at
+// once: while every worker has a master block of its own the caller does its nine probes itself, as before; when the loop
+// comes to its tail — a few master blocks whose searches take ten times the others' (PNG-like data: the first master
+// blocks' 27 + 21 ms against 3 + 0.1) — the idle workers take the probes and the tail is up to nine times shorter.  Deeper
+// levels run inline.
+template <typename Fn>
+void ParallelForNested(size_t n, Fn&& fn) {
+  if (!g_inside_parallel_for) {        // (not nested after all)
+    ParallelFor(n, fn);
+    return;
+  }
+  // (no idle worker: every one has a master block of its own — or the host's CPUs are all taken, as with incompressible data,
+  //  where registering a job per round only added switches: 327 -> 272 MB/s)
+  if (n <= 1 || WideThreads() <= 1 || g_host_inline || g_nested_level > 0 || WidePool::Get().Idle() < 2) {
+    for (size_t i = 0; i < n; ++i) fn(i);
+    return;
+  }
+  const std::function<void(size_t)> body = [&](size_t i) {
+    const int was = g_nested_level;
+    const bool was_inside = g_inside_parallel_for;     // (a worker that took the task: whatever it does inside runs inline)
+    g_nested_level = 1;
+    g_inside_parallel_for = true;
+    fn(i);
+    g_inside_parallel_for = was_inside;
+    g_nested_level = was;
+  };
+  ++g_nested_level;
+  WidePool::Get().Run(n, body);
+  --g_nested_level;
 }
 
 }  // namespace zamd

@@ -55,7 +55,9 @@ def baseline_config_name(cls, size, numiterations, blocksplitting):
 WINDOW = 32768
 # rocprofv3 PMC passes per class of the 100 MB, n = 15, blocksplitting 0 workload (tools/collect_profiles.sh; quoted only
 # when taken on this build's device sources)
-PMC_PROFILES = {"T": "r05_bench100MB_pmc.json", "Z": "r05_classZ100MB_pmc.json", "M": "r05_classM100MB_pmc.json"}
+# keyed by (class, bytes, numiterations, blocksplitting)
+PMC_PROFILES = {("T", 100 * MB, 15, 0): "r06_bench100MB_pmc.json", ("Z", 100 * MB, 15, 0): "r06_classZ100MB_pmc.json",
+                ("M", 200 * MB, 50, 1): "r06_config3_M200_n50_pmc.json"}
 SHADER_CLOCK_HZ = 2.4e9   # MI355X peak engine clock; s_memtime counts at this rate (measured)
 
 
@@ -641,10 +643,9 @@ def _run_one(args, rank, world, dev_index, device, torch, dist, lib, cdist, gath
             # same configuration
             traffic = None
             traffic_note = "no PMC profile of this workload"
-            PMC_PROFILE = PMC_PROFILES.get(args.cls, "")
+            PMC_PROFILE = PMC_PROFILES.get((args.cls, size, args.numiterations, args.blocksplitting), "")
             pmc = os.path.join(ROOT, "profiles", PMC_PROFILE)
-            if (PMC_PROFILE and corpus is None and os.path.exists(pmc) and size == 100 * MB and args.numiterations == 15
-                    and args.blocksplitting == 0 and world == 1):
+            if PMC_PROFILE and corpus is None and os.path.exists(pmc) and world == 1:
                 with open(pmc) as f:
                     prof = json.load(f)
                 if prof.get("device_source_sha16") == device_source_hash():

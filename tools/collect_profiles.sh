@@ -10,7 +10,9 @@ ARGS="${BENCH_ARGS:---steps 1 --warmup 0 --no-cpu-baseline}"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- python $REPO/bench.py $ARGS > $OUT/stats.log 2>&1
 grep '^{"metric"' $OUT/stats.log | tail -1 > $OUT/bench_line.json
 i=0
-for set in "SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM" "FETCH_SIZE" "WRITE_SIZE" ${EXTRA_SETS:-}; do
+# (EXTRA_SET: one more pass, e.g. the LDS set "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS")
+for set in "SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM" "FETCH_SIZE" "WRITE_SIZE" "${EXTRA_SET:-}"; do
+  [ -z "$set" ] && continue
   i=$((i+1))
   timeout 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc_$i -o p -- python $REPO/bench.py $ARGS > $OUT/pmc_$i.log 2>&1
 done
@@ -24,7 +26,7 @@ PY
 python - $OUT/pmc.json <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1]))
-for k in ("chain","k_dp5_spec","k_dp4_fix","k_match2","k_chain"):
+for k in ("chain","k_dp5_spec","k_dp4_fix","k_match2","k_chain","k_codes"):
     v=d.get(k,{})
-    print(k, {c: (round(x/1e9,3) if "bytes" in c else round(x)) for c,x in v.items() if c in ("launches","fetch_bytes","write_bytes","hbm_bytes","SQ_INSTS_VALU","SQ_WAVE_CYCLES","SQ_WAIT_ANY","SQ_ACTIVE_INST_ANY")})
+    print(k, {c: (round(x/1e9,3) if "bytes" in c else round(x)) for c,x in v.items() if c in ("launches","fetch_bytes","write_bytes","hbm_bytes","SQ_INSTS_VALU","SQ_INSTS_SALU","SQ_WAVE_CYCLES","SQ_WAIT_ANY","SQ_ACTIVE_INST_ANY","SQ_LDS_BANK_CONFLICT","SQ_LDS_IDX_ACTIVE","SQ_ACTIVE_INST_LDS")})
 PY

@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd $REPO
 : > $OUT/classes.jsonl
 for cls in ${CLASSES:-T X R P B Z M}; do
-  timeout 900 python bench.py --cls $cls --steps ${STEPS:-2} --warmup 1 --no-cpu-baseline > $OUT/bench_${cls}.json 2> $OUT/bench_${cls}.err
+  timeout 900 python bench.py --cls $cls --steps ${STEPS:-2} --warmup 1 --no-cpu-baseline --no-small-files > $OUT/bench_${cls}.json 2> $OUT/bench_${cls}.err
   cat $OUT/bench_${cls}.json >> $OUT/classes.jsonl
   python - $OUT/bench_${cls}.json <<'PY'
 import json,sys

@@ -24,7 +24,10 @@ struct Histogram {
 
 class Lz77Store {
  public:
-  static constexpr size_t kSample = 256;
+  // (a sample is 2.5 KB: every 256 symbols that was 10 bytes written per symbol, more than the symbols themselves — a store of
+  //  random data, a million literals per master block, took as long to build as to search; at 1024 a range histogram adds
+  //  up to 2 x 1023 symbols instead of 2 x 255, ~ 1 us of a 20 - 40 us evaluation)
+  static constexpr size_t kSample = 1024;
 
   explicit Lz77Store(const unsigned char* data = nullptr) : data_(data) {}
 
@@ -55,7 +58,7 @@ class Lz77Store {
     }
     litlens_.push_back(litlen);
     dists_.push_back(dist);
-    pos_.push_back(pos);
+    pos_.push_back(static_cast<uint32_t>(pos));
     if (dist == 0) {
       running_.ll[litlen]++;
     } else {
@@ -80,7 +83,7 @@ class Lz77Store {
     samples_.reserve((base + n) / kSample + 1);
     for (size_t i = 0; i < n; ++i) {
       if ((base + i) % kSample == 0) samples_.push_back(running_);    // counts of the symbols before this one
-      pos_[base + i] = pos;
+      pos_[base + i] = static_cast<uint32_t>(pos);
       const unsigned litlen = litlens[i], dist = dists[i];
       if (dist == 0) {
         running_.ll[litlen]++;
@@ -146,7 +149,7 @@ class Lz77Store {
   const unsigned char* data_;
   // (a master block's store is ~ 5 MB of these: from the library's block cache, not malloc — block_cache.h)
   CVec<uint16_t> litlens_, dists_;
-  CVec<size_t> pos_;
+  CVec<uint32_t> pos_;           // (byte positions in the resident input: 32 bits, as the device layer's)
   CVec<Histogram> samples_;  // samples_[k] = counts of symbols [0, k*kSample)
   Histogram running_ = {};          // counts of all symbols pushed so far
 };

@@ -286,6 +286,31 @@ int zmx_hash_links_download(zmx_ctx* ctx, zmx_tables* tables, size_t block, uint
 /* Parity probe: length_array[0..blocksize] of the last zmx_squeeze_run. */
 int zmx_length_array_download(zmx_ctx* ctx, zmx_tables* tables, size_t block, uint16_t* out);
 
+/* -------- f-1 of SURVEY 8: the block-split search's cost function on the device
+ *
+ * ZopfliCalculateBlockSizeAutoType (deflate.c:610-621) of MANY ranges of LZ77 symbol sequences at once: what every
+ * probe of ZopfliBlockSplitLZ77 evaluates twice (blocksplitter.c:103-135: EstimateCost, SplitCost).  The sizes are
+ * integers; they come back as doubles as the reference returns them, equal to the host's
+ * ZopfliCalculateBlockSizeAutoType value for value (tests/test_gpu_parity.py::test_block_costs).
+ *
+ * A zmx_cost_stores object is a set of symbol sequences ("stores", lz77.h:44-62) resident on the device with their
+ * sampled prefix histograms (lz77.c:98-149's ll_counts / d_counts, here every 256 symbols):
+ *   zmx_cost_stores_create       sequence s = the concatenation of the device stores (block[p], slot[p], nsym[p]) of
+ *                                `tables` for p in [piece_first[s], piece_first[s + 1]) — the greedy store of a master
+ *                                block (blocksplitter.c:296), or the optimal parses of its blocks joined
+ *                                (deflate.c:866); nothing crosses the bus
+ *   zmx_cost_stores_create_host  the same from host arrays (lz77.h:44-49 convention)
+ *   zmx_block_costs              cost[i] = ZopfliCalculateBlockSizeAutoType(sequence ranges[3 i], lstart = ranges[3 i + 1],
+ *                                lend = ranges[3 i + 2])
+ * A sequence holds fewer than 2^22 symbols (a master block has at most 1 000 000). */
+typedef struct zmx_cost_stores zmx_cost_stores;
+int zmx_cost_stores_create(zmx_ctx* ctx, zmx_tables* tables, size_t nstores, const size_t* piece_first,
+                           const size_t* block, const int32_t* slot, const size_t* nsym, zmx_cost_stores** out);
+int zmx_cost_stores_create_host(zmx_ctx* ctx, size_t nstores, const uint16_t* const* litlens,
+                                const uint16_t* const* dists, const size_t* nsym, zmx_cost_stores** out);
+void zmx_cost_stores_free(zmx_ctx* ctx, zmx_cost_stores* stores);
+int zmx_block_costs(zmx_ctx* ctx, zmx_cost_stores* stores, size_t n, const uint32_t* ranges, double* cost);
+
 /* -------- whole-stream entry points on a resident input (bench, multi-GPU) */
 
 /* ZopfliDeflate (deflate.c:908) of bytes [instart, inend) of the resident input,

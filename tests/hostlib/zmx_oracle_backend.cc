@@ -273,6 +273,42 @@ int zmx_length_array_download(zmx_ctx*, zmx_tables* t, size_t block, uint16_t* o
   return 0;
 }
 
+// ---- f-1's device entry points, TEST-ONLY stand-ins: the sequences as host stores, the sizes by the host's own block-cost
+// code (so that DeflateParts' device-split path — queries, the mixing of device and host rounds — runs on CPU)
+struct zmx_cost_stores {
+  std::vector<zamd::Lz77Store> stores;
+};
+int zmx_cost_stores_create(zmx_ctx*, zmx_tables* t, size_t nstores, const size_t* piece_first, const size_t* block,
+                           const int32_t* slot, const size_t* nsym, zmx_cost_stores** out) {
+  zmx_cost_stores* s = new zmx_cost_stores();
+  s->stores.resize(nstores);
+  for (size_t q = 0; q < nstores; ++q) {
+    for (size_t p = piece_first[q]; p < piece_first[q + 1]; ++p) {
+      const BlockData& d = t->blocks[block[p]];
+      if (nsym[p] > d.nsym[slot[p]]) { delete s; g_err = "zmx_cost_stores_create: nsym exceeds the store"; return -1; }
+      s->stores[q].Append(d.litlens[slot[p]].data(), d.dists[slot[p]].data(), nsym[p], d.blk.instart);
+    }
+  }
+  *out = s;
+  return 0;
+}
+int zmx_cost_stores_create_host(zmx_ctx*, size_t nstores, const uint16_t* const* litlens, const uint16_t* const* dists,
+                                const size_t* nsym, zmx_cost_stores** out) {
+  zmx_cost_stores* s = new zmx_cost_stores();
+  s->stores.resize(nstores);
+  for (size_t q = 0; q < nstores; ++q) s->stores[q].Append(litlens[q], dists[q], nsym[q], 0);
+  *out = s;
+  return 0;
+}
+void zmx_cost_stores_free(zmx_ctx*, zmx_cost_stores* s) { delete s; }
+int zmx_block_costs(zmx_ctx*, zmx_cost_stores* s, size_t n, const uint32_t* r, double* cost) {
+  for (size_t i = 0; i < n; ++i) {
+    if (r[3 * i] >= s->stores.size() || r[3 * i + 1] > r[3 * i + 2] || r[3 * i + 2] > s->stores[r[3 * i]].size()) { g_err = "zmx_block_costs: a range outside its sequence"; return -1; }
+    cost[i] = zamd::CalculateBlockSizeAutoType(s->stores[r[3 * i]], r[3 * i + 1], r[3 * i + 2]);
+  }
+  return 0;
+}
+
 // ---- hooks for unit tests of the product's host arithmetic against the real reference
 // (tests/test_cpu_oracle_vs_reference.py)
 __attribute__((visibility("default"))) int zamd_test_code_lengths(const size_t* freq, int n, int maxbits, unsigned* lengths) {

@@ -485,3 +485,34 @@ def test_host_bit_writer_on_every_block():
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.split()[0] == "OK", r.stdout[-2000:]
+
+
+def test_device_split_path_of_the_host_code():
+    """f-1 on the device, the HOST side of it (deflate.cc, block_split.cc: BlockSplitSizesBatch — no host stores for the
+    first split, every round's block sizes asked of zmx_block_costs, the split points' byte positions from one walk over
+    the symbols; the second split's sequences glued from the blocks' stores): forced on with the test library's CPU
+    stand-ins for the zmx_cost_stores_* entry points, the stream and the verbose text (the split points' line) equal the
+    reference's, and equal the host-evaluated path's."""
+    import subprocess
+    import sys
+    if not ol.have_ref():
+        pytest.skip("oracle/_ref not built")
+    body = (
+        "import hashlib, sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import oracle_lib as ol\n"
+        "from zopfli_amd import ZopfliOptions, api, generate\n"
+        "data = generate('M', 1100000) + generate('R', 400000) + generate('T', 700000)\n"
+        % (os.path.dirname(os.path.dirname(__file__)), os.path.dirname(__file__)))
+    mine = body + "out = api.compress(data, 0, ZopfliOptions(2, 1, 15, 1, 0), lib=ol.hosttest_library())\nprint(hashlib.sha256(out).hexdigest())\n"
+    theirs = body + "out = ol.ref_compress(data, 0, 2, 1, 15, 1, 0)\nprint(hashlib.sha256(out).hexdigest())\n"
+    runs = []
+    for code, extra in ((mine, {"ZOPFLI_AMD_DEVICE_SPLIT": "2", "ZOPFLI_AMD_DEVICE_SPLIT_FROM": "1", "ZOPFLI_AMD_TRACE_CALL": "1"}),
+                        (mine, {"ZOPFLI_AMD_DEVICE_SPLIT": "0"}), (theirs, {})):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs.append((r.stdout.split()[-1], r.stderr))
+    assert "first split on the device" in runs[0][1] and "on the device (" in runs[0][1]
+    assert runs[0][0] == runs[1][0] == runs[2][0]
+    lines = [[l for l in t.splitlines() if l.startswith("block split points")] for _, t in runs]
+    assert lines[0] == lines[1] == lines[2] and len(lines[2]) >= 3

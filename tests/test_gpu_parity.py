@@ -975,3 +975,104 @@ def test_run_paths_fuzz(seed):
         ref = ol.ref_compress(data, 0, n, bs, 15)
         mine = api.compress(data, 0, ZopfliOptions(n, bs, 15))
         assert mine == ref, f"seed {seed}: {size} bytes, numiterations {n}, blocksplitting {bs}"
+
+
+def _ref_greedy_store(data, n):
+    """The REAL reference's greedy parse of data[0:n) as its own ZopfliLZ77Store (kept alive for its block-size functions)."""
+    import ctypes
+    lib = ol.ref()
+    h = ol.RefHash()
+    lib.ZopfliAllocHash(32768, ctypes.byref(h))
+    o = ol.RefOptions(0, 0, 15, 1, 0, 15)
+    s = ol.RefBlockState()
+    lib.ZopfliInitBlockState(ctypes.byref(o), 0, n, 0, ctypes.byref(s))
+    st = ol.RefStore()
+    lib.ZopfliInitLZ77Store(data, ctypes.byref(st))
+    lib.ZopfliLZ77Greedy(ctypes.byref(s), data, 0, n, ctypes.byref(st), ctypes.byref(h))
+    lib.ZopfliCleanBlockState(ctypes.byref(s))
+    lib.ZopfliCleanHash(ctypes.byref(h))
+    return st
+
+
+BLOCK_COST_CASES = [("T", 400000), ("X", 300000), ("R", 300000), ("P", 300000), ("M", 300000), ("Z", 60000), ("B", 12000),
+                    ("T", 2600), ("R", 990), ("T", 9)]
+
+
+@pytest.mark.gpu
+def test_block_costs(gpu_ctx):
+    """k_block_cost == ZopfliCalculateBlockSizeAutoType (deflate.c:610-621) of the REAL reference on its own greedy stores:
+    every class, whole stores, single symbols, ranges that end on and around the samples of the prefix histograms, ranges
+    below the direct-count threshold, and stores on either side of the 1000-symbol fixed-tree switch (deflate.c:615)."""
+    import ctypes
+    if not ol.have_ref():
+        pytest.skip("oracle/_ref is not built")
+    lib = ol.ref()
+    stores, refs, keep_alive = [], [], []
+    for i, (cls, n) in enumerate(BLOCK_COST_CASES):
+        data = generate(cls, n, seed=40 + i)
+        keep_alive.append(data)
+        st = _ref_greedy_store(data, n)
+        refs.append(st)
+        m = st.size
+        stores.append((np.ctypeslib.as_array(st.litlens, shape=(m,)).copy(), np.ctypeslib.as_array(st.dists, shape=(m,)).copy()))
+    cs = api.CostStores.from_host(gpu_ctx, stores)
+    try:
+        rng = np.random.default_rng(5)
+        ranges = []
+        for q, (ll, _) in enumerate(stores):
+            m = len(ll)
+            fixed = [(0, m), (0, 1), (m - 1, m), (0, min(m, 300)), (0, min(m, 511)), (0, min(m, 512)), (0, min(m, 513)),
+                     (min(255, m - 1), m), (min(256, m - 1), m), (min(257, m - 1), m), (m // 2, m // 2 + 1)]
+            for k in (256, 512, 1024, 4096, 65536):
+                if k < m:
+                    fixed += [(0, k), (k, m), (k - 1, m), (k + 1, m), (1, k + 1)]
+            for a, b in fixed:
+                if a < b:
+                    ranges.append((q, a, b))
+            for _ in range(120):
+                a, b = sorted(rng.integers(0, m + 1, 2).tolist())
+                if a < b:
+                    ranges.append((q, a, b))
+            for _ in range(40):      # short ranges: the direct count
+                a = int(rng.integers(0, m))
+                b = min(m, a + 1 + int(rng.integers(0, 700)))
+                ranges.append((q, a, b))
+        got = cs.block_costs(ranges)
+        for (q, a, b), g in zip(ranges, got.tolist()):
+            want = lib.ZopfliCalculateBlockSizeAutoType(ctypes.byref(refs[q]), a, b)
+            assert g == want, (BLOCK_COST_CASES[q], a, b, g, want)
+    finally:
+        cs.free()
+        for st in refs:
+            lib.ZopfliCleanLZ77Store(ctypes.byref(st))
+
+
+@pytest.mark.gpu
+def test_block_costs_from_device_stores(gpu_ctx):
+    """zmx_cost_stores_create: sequences glued from the device's own stores (a master block's greedy store; the stores of
+    several blocks one after the other) price like the same symbols uploaded from the host."""
+    n = 300000
+    data = generate("M", n, seed=9)
+    gpu_ctx.set_input(data)
+    blocks = [(0, 100000), (100000, 180000), (180000, 300000)]
+    t = gpu_ctx.build_tables(blocks, matches_only=True)
+    try:
+        nsym, _ = t.greedy(0)
+        host = [t.store(b, 0, nsym[b]) for b in range(3)]
+        joined = (np.concatenate([h[0] for h in host]), np.concatenate([h[1] for h in host]))
+        dev = api.CostStores.from_tables(t, [[(0, 0, nsym[0])], [(b, 0, nsym[b]) for b in range(3)], [(2, 0, nsym[2]), (1, 0, nsym[1])]])
+        up = api.CostStores.from_host(gpu_ctx, [host[0], joined, (np.concatenate([host[2][0], host[1][0]]), np.concatenate([host[2][1], host[1][1]]))])
+        try:
+            rng = np.random.default_rng(2)
+            ranges = []
+            for q in range(3):
+                m = dev.sizes[q]
+                assert m == up.sizes[q]
+                ranges += [(q, 0, m)] + [(q,) + tuple(sorted(rng.integers(0, m + 1, 2).tolist())) for _ in range(60)]
+            ranges = [r for r in ranges if r[1] < r[2]]
+            assert np.array_equal(dev.block_costs(ranges), up.block_costs(ranges))
+        finally:
+            dev.free()
+            up.free()
+    finally:
+        t.free()

@@ -330,6 +330,76 @@ class Dist:
             self.handle = ctypes.c_void_p()
 
 
+class CostStores:
+    """zmx_cost_stores: LZ77 symbol sequences resident on the device with their sampled prefix histograms;
+    block_costs = ZopfliCalculateBlockSizeAutoType (deflate.c:610-621) of many ranges at once, on the device."""
+
+    def __init__(self, ctx, handle, sizes):
+        self.ctx, self.handle, self.sizes = ctx, handle, list(sizes)
+
+    @staticmethod
+    def from_host(ctx, stores):
+        """stores = [(litlens, dists)] (lz77.h:44-49 convention)."""
+        import numpy as np
+        n = len(stores)
+        lls = [np.ascontiguousarray(s[0], dtype=np.uint16) for s in stores]
+        dds = [np.ascontiguousarray(s[1], dtype=np.uint16) for s in stores]
+        pl = (ctypes.c_void_p * n)(*[a.ctypes.data for a in lls])
+        pd = (ctypes.c_void_p * n)(*[a.ctypes.data for a in dds])
+        ns = (ctypes.c_size_t * n)(*[len(a) for a in lls])
+        fn = ctx.lib.zmx_cost_stores_create_host
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        h = ctypes.c_void_p()
+        ctx._check(fn(ctx.handle, n, ctypes.cast(pl, ctypes.c_void_p), ctypes.cast(pd, ctypes.c_void_p),
+                      ctypes.cast(ns, ctypes.c_void_p), ctypes.byref(h)), "zmx_cost_stores_create_host")
+        return CostStores(ctx, h, [len(a) for a in lls])
+
+    @staticmethod
+    def from_tables(tables, sequences):
+        """sequences = [[(block, slot, nsym), ...], ...]: every sequence the concatenation of device stores of `tables`."""
+        ctx = tables.ctx
+        first, blk, slot, nsym = [0], [], [], []
+        for seq in sequences:
+            for b, s, k in seq:
+                blk.append(int(b)); slot.append(int(s)); nsym.append(int(k))
+            first.append(len(blk))
+        n, np_ = len(sequences), len(blk)
+        fn = ctx.lib.zmx_cost_stores_create
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                       ctypes.c_void_p, ctypes.c_void_p]
+        a_first = (ctypes.c_size_t * (n + 1))(*first)
+        a_blk = (ctypes.c_size_t * max(np_, 1))(*blk)
+        a_slot = (ctypes.c_int32 * max(np_, 1))(*slot)
+        a_nsym = (ctypes.c_size_t * max(np_, 1))(*nsym)
+        h = ctypes.c_void_p()
+        ctx._check(fn(ctx.handle, tables.handle, n, ctypes.cast(a_first, ctypes.c_void_p), ctypes.cast(a_blk, ctypes.c_void_p),
+                      ctypes.cast(a_slot, ctypes.c_void_p), ctypes.cast(a_nsym, ctypes.c_void_p), ctypes.byref(h)),
+                   "zmx_cost_stores_create")
+        return CostStores(ctx, h, [sum(k for _, _, k in seq) for seq in sequences])
+
+    def block_costs(self, ranges):
+        """ranges = [(sequence, lstart, lend)] -> float64 array of block sizes in bits."""
+        import numpy as np
+        r = np.ascontiguousarray(np.asarray(ranges, dtype=np.uint32).reshape(-1, 3))
+        out = np.zeros(len(r), dtype=np.float64)
+        fn = self.ctx.lib.zmx_block_costs
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+        self.ctx._check(fn(self.ctx.handle, self.handle, len(r), r.ctypes.data_as(ctypes.c_void_p),
+                           out.ctypes.data_as(ctypes.c_void_p)), "zmx_block_costs")
+        return out
+
+    def free(self):
+        if self.handle:
+            fn = self.ctx.lib.zmx_cost_stores_free
+            fn.restype = None
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+            fn(self.ctx.handle, self.handle)
+            self.handle = None
+
+
 class Tables:
     def __init__(self, ctx, handle, blocks):
         self.ctx, self.handle, self.blocks = ctx, handle, blocks

@@ -34,6 +34,7 @@
 #include "zmx_trace.h"
 #include "zmx_greedy.h"
 #include "zmx_png.h"
+#include "zmx_blockcost.h"
 #include "zopfli_amd.h"
 #include "../host/thread_pool.h"
 
@@ -2456,6 +2457,222 @@ int zmx_length_array_download(zmx_ctx* c, zmx_tables* t, size_t block, uint16_t*
   HIPCHK(dev_guard.err);
   HIPCHK(hipMemcpy(out, t->d_la + t->blocks[block].la_off, (static_cast<size_t>(t->bsize[block]) + 1) * sizeof(u16),
                    hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// f-1 on the device: block sizes of ranges of symbol sequences (zmx_blockcost.h)
+// ---------------------------------------------------------------------------------------------
+struct zmx_cost_stores {
+  size_t n = 0;
+  std::vector<CostStoreDev> desc;
+  u32* d_sym = nullptr;            // the sequences, one after the other
+  u32* d_samples = nullptr;        // their sampled prefix counts
+  CostStoreDev* d_desc = nullptr;
+  CostEval* d_evals = nullptr;
+  double* d_out = nullptr;
+  CostEval* h_evals = nullptr;     // pinned
+  double* h_out = nullptr;         // pinned
+  size_t eval_cap = 0;
+};
+
+namespace {
+
+void CostStoresRelease(zmx_ctx* c, zmx_cost_stores* s) {
+  if (!s) return;
+  PoolFree(c, s->d_sym);
+  PoolFree(c, s->d_samples);
+  PoolFree(c, s->d_desc);
+  PoolFree(c, s->d_evals);
+  PoolFree(c, s->d_out);
+  if (s->h_evals) (void)hipHostFree(s->h_evals);
+  if (s->h_out) (void)hipHostFree(s->h_out);
+  delete s;
+}
+
+// the arrays of `n` sequences of sizes nsym[]; the symbols are put in place by the caller (between Layout and Finish)
+int CostStoresLayout(zmx_ctx* c, size_t n, const std::vector<size_t>& nsym, zmx_cost_stores* s, std::vector<size_t>* sym_off) {
+  size_t total = 0, samples = 0;
+  sym_off->assign(n + 1, 0);
+  for (size_t i = 0; i < n; ++i) {
+    // (the sort key of the package-merge is count << 9 | symbol in 32 bits, and a package weighs at most 15 sequences)
+    if (nsym[i] >= (1u << 22)) return FailMsg("zmx_cost_stores_create: a sequence of 2^22 symbols or more");
+    (*sym_off)[i + 1] = (*sym_off)[i] + nsym[i];
+    samples += nsym[i] / BC_S + 1;
+  }
+  total = (*sym_off)[n];
+  s->n = n;
+  HIPCHK(PoolAllocT(c, &s->d_sym, total + 1, "cost_sym"));
+  HIPCHK(PoolAllocT(c, &s->d_samples, samples * BC_SW, "cost_samples"));
+  HIPCHK(PoolAllocT(c, &s->d_desc, n, "cost_desc"));
+  s->desc.resize(n);
+  size_t so = 0;
+  for (size_t i = 0; i < n; ++i) {
+    s->desc[i].sym = s->d_sym + (*sym_off)[i];
+    s->desc[i].samples = s->d_samples + so * BC_SW;
+    s->desc[i].n = static_cast<u32>(nsym[i]);
+    s->desc[i].nsamples = static_cast<u32>(nsym[i] / BC_S + 1);
+    so += nsym[i] / BC_S + 1;
+  }
+  HIPCHK(hipMemcpyAsync(s->d_desc, s->desc.data(), n * sizeof(CostStoreDev), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+int CostStoresFinish(zmx_ctx* c, zmx_cost_stores* s) {
+  const size_t n = s->n;
+  std::vector<u32> chunk_first(n + 1, 0);
+  for (size_t i = 0; i < n; ++i) chunk_first[i + 1] = chunk_first[i] + s->desc[i].n / BC_S;
+  PoolScope tmp(c);
+  u32* d_cf = nullptr;
+  HIPCHK(tmp.AllocT(&d_cf, n + 1, "cost_chunk_first"));
+  HIPCHK(hipMemcpyAsync(d_cf, chunk_first.data(), (n + 1) * sizeof(u32), hipMemcpyHostToDevice, c->stream));
+  if (chunk_first[n]) {
+    hipLaunchKernelGGL(k_cost_chunks, dim3((chunk_first[n] + 3) / 4), dim3(256), 0, c->stream, s->d_desc, d_cf, static_cast<u32>(n));
+    KCHK(c, "k_cost_chunks");
+  }
+  hipLaunchKernelGGL(k_cost_prefix, dim3(static_cast<unsigned>(n)), dim3(384), 0, c->stream, s->d_desc);
+  KCHK(c, "k_cost_prefix");
+  HIPCHK(hipStreamSynchronize(c->stream));    // (chunk_first and the caller's staging arrays go out of scope)
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zmx_cost_stores_create(zmx_ctx* c, zmx_tables* t, size_t nstores, const size_t* piece_first, const size_t* block,
+                           const int32_t* slot, const size_t* nsym, zmx_cost_stores** out) {
+  *out = nullptr;
+  if (nstores == 0) return FailMsg("zmx_cost_stores_create: no sequence");
+  const size_t np = piece_first[nstores];
+  std::vector<size_t> total(nstores, 0);
+  for (size_t s = 0; s < nstores; ++s) {
+    for (size_t p = piece_first[s]; p < piece_first[s + 1]; ++p) {
+      if (block[p] >= t->nb || (slot[p] != 0 && slot[p] != 1)) return FailMsg("zmx_cost_stores_create: bad block or slot");
+      if (t->store_begin[slot[p]][block[p]] + nsym[p] > t->bsize[block[p]]) return FailMsg("zmx_cost_stores_create: nsym exceeds the store");
+      total[s] += nsym[p];
+    }
+  }
+  DeviceGuard dev_guard(c->device);
+  HIPCHK(dev_guard.err);
+  zmx_cost_stores* s = new zmx_cost_stores();
+  std::vector<size_t> sym_off;
+  int rc = CostStoresLayout(c, nstores, total, s, &sym_off);
+  if (rc) { CostStoresRelease(c, s); return rc; }
+  auto fail = [&](hipError_t e, const char* what) {
+    CostStoresRelease(c, s);
+    return Fail(what, e, __FILE__, __LINE__);
+  };
+  std::vector<CostPiece> pieces(np);
+  size_t longest = 0;
+  for (size_t q = 0; q < nstores; ++q) {
+    size_t off = sym_off[q];
+    for (size_t p = piece_first[q]; p < piece_first[q + 1]; ++p) {
+      pieces[p].src = t->d_store[slot[p]] + t->blocks[block[p]].pos_off + t->store_begin[slot[p]][block[p]];
+      pieces[p].dst = s->d_sym + off;
+      pieces[p].n = static_cast<u32>(nsym[p]);
+      pieces[p].pad = 0;
+      off += nsym[p];
+      longest = std::max(longest, nsym[p]);
+    }
+  }
+  {
+    PoolScope tmp(c);
+    CostPiece* d_pieces = nullptr;
+    hipError_t e = tmp.AllocT(&d_pieces, np, "cost_pieces");
+    if (e != hipSuccess) return fail(e, "cost_pieces");
+    e = hipMemcpyAsync(d_pieces, pieces.data(), np * sizeof(CostPiece), hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) return fail(e, "cost_pieces copy");
+    if (longest) {
+      hipLaunchKernelGGL(k_cost_gather, dim3(static_cast<unsigned>((longest + 4095) / 4096), static_cast<unsigned>(np)), dim3(256), 0, c->stream, d_pieces);
+      e = hipGetLastError();
+      if (e != hipSuccess) return fail(e, "k_cost_gather");
+    }
+    rc = CostStoresFinish(c, s);
+  }
+  if (rc) { CostStoresRelease(c, s); return rc; }
+  *out = s;
+  return 0;
+}
+
+int zmx_cost_stores_create_host(zmx_ctx* c, size_t nstores, const uint16_t* const* litlens, const uint16_t* const* dists,
+                                const size_t* nsym, zmx_cost_stores** out) {
+  *out = nullptr;
+  if (nstores == 0) return FailMsg("zmx_cost_stores_create_host: no sequence");
+  DeviceGuard dev_guard(c->device);
+  HIPCHK(dev_guard.err);
+  zmx_cost_stores* s = new zmx_cost_stores();
+  std::vector<size_t> sym_off;
+  int rc = CostStoresLayout(c, nstores, std::vector<size_t>(nsym, nsym + nstores), s, &sym_off);
+  if (rc) { CostStoresRelease(c, s); return rc; }
+  std::vector<u32> packed(sym_off[nstores] + 1);
+  for (size_t q = 0; q < nstores; ++q) {
+    for (size_t i = 0; i < nsym[q]; ++i) packed[sym_off[q] + i] = static_cast<u32>(litlens[q][i]) | (static_cast<u32>(dists[q][i]) << 16);
+  }
+  hipError_t e = hipMemcpyAsync(s->d_sym, packed.data(), sym_off[nstores] * sizeof(u32), hipMemcpyHostToDevice, c->stream);
+  if (e != hipSuccess) { CostStoresRelease(c, s); return Fail("zmx_cost_stores_create_host: copy", e, __FILE__, __LINE__); }
+  rc = CostStoresFinish(c, s);
+  if (rc) { CostStoresRelease(c, s); return rc; }
+  *out = s;
+  return 0;
+}
+
+void zmx_cost_stores_free(zmx_ctx* c, zmx_cost_stores* s) {
+  if (!s) return;
+  DeviceGuard dev_guard(c->device);
+  CostStoresRelease(c, s);
+}
+
+int zmx_block_costs(zmx_ctx* c, zmx_cost_stores* s, size_t n, const uint32_t* ranges, double* cost) {
+  if (n == 0) return 0;
+  for (size_t i = 0; i < n; ++i) {
+    const uint32_t store = ranges[3 * i], lstart = ranges[3 * i + 1], lend = ranges[3 * i + 2];
+    if (store >= s->n || lstart > lend || lend > s->desc[store].n) return FailMsg("zmx_block_costs: a range outside its sequence");
+  }
+  DeviceGuard dev_guard(c->device);
+  HIPCHK(dev_guard.err);
+  if (n > s->eval_cap) {
+    const size_t cap = n + n / 2 + 256;
+    PoolFree(c, s->d_evals); s->d_evals = nullptr;
+    PoolFree(c, s->d_out); s->d_out = nullptr;
+    if (s->h_evals) { (void)hipHostFree(s->h_evals); s->h_evals = nullptr; }
+    if (s->h_out) { (void)hipHostFree(s->h_out); s->h_out = nullptr; }
+    s->eval_cap = 0;
+    HIPCHK(PoolAllocT(c, &s->d_evals, cap, "cost_evals"));
+    HIPCHK(PoolAllocT(c, &s->d_out, cap, "cost_out"));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->h_evals), cap * sizeof(CostEval), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&s->h_out), cap * sizeof(double), hipHostMallocDefault));
+    s->eval_cap = cap;
+  }
+  for (size_t i = 0; i < n; ++i) s->h_evals[i] = {ranges[3 * i], ranges[3 * i + 1], ranges[3 * i + 2], 0u};
+  HIPCHK(hipMemcpyAsync(s->d_evals, s->h_evals, n * sizeof(CostEval), hipMemcpyHostToDevice, c->stream));
+  BlockCostParams P;
+  P.stores = s->d_desc;
+  P.evals = s->d_evals;
+  P.out = s->d_out;
+  P.n = static_cast<u32>(n);
+  P.prof = nullptr;
+  static const bool bc_prof = std::getenv("ZOPFLI_AMD_BC_PROF") != nullptr;
+  PoolScope tmp(c);
+  if (bc_prof) {
+    HIPCHK(tmp.AllocT(&P.prof, 16, "bc_prof"));
+    HIPCHK(hipMemsetAsync(P.prof, 0, 16 * sizeof(u64), c->stream));
+  }
+  const auto t0_ = std::chrono::steady_clock::now();
+  hipLaunchKernelGGL(k_block_cost, dim3(static_cast<unsigned>((n + BC_WAVES / 2 - 1) / (BC_WAVES / 2))), dim3(64 * BC_WAVES), 0, c->stream, P);
+  KCHK(c, "k_block_cost");
+  HIPCHK(hipMemcpyAsync(s->h_out, s->d_out, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  std::memcpy(cost, s->h_out, n * sizeof(double));
+  if (bc_prof) {
+    u64 pr[16];
+    HIPCHK(hipMemcpy(pr, P.prof, sizeof(pr), hipMemcpyDeviceToHost));
+    const double us = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count() * 1e6;
+    std::fprintf(stderr, "k_block_cost: %zu block sizes in %.0f us; kilocycles a wave: histogram %.1f, lengths ll %.1f d %.1f, tree %.1f, data %.1f, smoothing %.1f, lengths ll %.1f d %.1f, tree + data %.1f\n",
+                 n, us, pr[0] / 1e3 / n, pr[1] / 1e3 / n, pr[2] / 1e3 / n, pr[3] / 1e3 / n, pr[4] / 1e3 / n, pr[5] / 1e3 / n, pr[6] / 1e3 / n, pr[7] / 1e3 / n, pr[8] / 1e3 / n);
+  }
   return 0;
 }
 

@@ -226,9 +226,9 @@ struct SeqSplit {              // ZopfliBlockSplitLZ77's loop over one sequence,
     searches.emplace_back();
     searches.back().Start(s, e);
   }
-  void Init(const Lz77Store& store, size_t maxb, std::vector<size_t>* pts) {
-    lz77 = &store;
-    n = store.size();
+  void Init(const Lz77Store* store, size_t size, size_t maxb, std::vector<size_t>* pts) {
+    lz77 = store;
+    n = size;
     maxblocks = maxb;
     points = pts;
     if (n < 10) { over = true; return; }
@@ -280,14 +280,21 @@ struct SeqSplit {              // ZopfliBlockSplitLZ77's loop over one sequence,
 
 }  // namespace
 
-void BlockSplitLz77Batch(const std::vector<const Lz77Store*>& stores, size_t maxblocks,
-                         std::vector<std::vector<size_t>>* points) {
-  const size_t ns = stores.size();
-  points->assign(ns, {});
-  std::vector<SeqSplit> seq(ns);
-  for (size_t i = 0; i < ns; ++i) seq[i].Init(*stores[i], maxblocks, &(*points)[i]);
+namespace {
+
+// the rounds of BlockSplitLz77Batch; false: a round the device had to serve (no host store) was not served
+bool SplitRounds(std::vector<SeqSplit>& seq, const CostBatchFn* device, size_t device_min) {
+  const size_t ns = seq.size();
   struct Eval { SeqSplit* q; BlockSearch* b; size_t k; };
   std::vector<Eval> evals;
+  std::vector<CostQuery> queries;
+  std::vector<double> answers;
+  static const bool trace = [] { const char* e = std::getenv("ZOPFLI_AMD_TRACE_CALL"); return e && std::atoi(e) != 0; }();
+  size_t rounds_dev = 0, rounds_host = 0, n_dev = 0, n_host = 0;
+  double t_dev = 0, t_host = 0;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  bool host_possible = true;
+  for (auto& q : seq) host_possible &= q.lz77 != nullptr || q.over;
   for (;;) {
     evals.clear();
     for (auto& q : seq) {
@@ -310,7 +317,40 @@ void BlockSplitLz77Batch(const std::vector<const Lz77Store*>& stores, size_t max
       e.b->values[e.k] = p == e.b->s ? CalculateBlockSizeAutoType(*e.q->lz77, e.b->s, e.b->e)
                                      : CalculateBlockSizeAutoType(*e.q->lz77, e.b->s, p) + CalculateBlockSizeAutoType(*e.q->lz77, p, e.b->e);
     };
-    if (evals.size() > 16u * HostThreads()) ParallelForWide(evals.size(), one); else ParallelFor(evals.size(), one);
+    bool served = false;
+    const double tr0 = trace ? now() : 0.0;
+    if (device && *device && !evals.empty() && (2 * evals.size() >= device_min || !host_possible)) {
+      // the round's block sizes in one launch: the block unsplit is one size, a split position two (blocksplitter.c:117-135)
+      queries.clear();
+      for (const Eval& e : evals) {
+        const uint32_t sq = static_cast<uint32_t>(e.q - seq.data());
+        const uint32_t p = static_cast<uint32_t>(e.b->probes[e.k]), s = static_cast<uint32_t>(e.b->s), en = static_cast<uint32_t>(e.b->e);
+        if (p == s) {
+          queries.push_back({sq, s, en});
+        } else {
+          queries.push_back({sq, s, p});
+          queries.push_back({sq, p, en});
+        }
+      }
+      answers.resize(queries.size());
+      served = (*device)(queries.data(), queries.size(), answers.data());
+      if (served) {
+        size_t a = 0;
+        for (const Eval& e : evals) {
+          const size_t p = e.b->probes[e.k];
+          if (p == e.b->s) { e.b->values[e.k] = answers[a]; a += 1; }
+          else { e.b->values[e.k] = answers[a] + answers[a + 1]; a += 2; }
+        }
+      }
+    }
+    if (!served) {
+      if (!host_possible && !evals.empty()) return false;
+      if (evals.size() > 16u * HostThreads()) ParallelForWide(evals.size(), one); else ParallelFor(evals.size(), one);
+    }
+    if (trace) {
+      const double dt = now() - tr0;
+      if (served) { ++rounds_dev; n_dev += queries.size(); t_dev += dt; } else { ++rounds_host; n_host += evals.size(); t_host += dt; }
+    }
     for (auto& q : seq) {
       if (q.over) continue;
       // (Feed may append to nothing; Advance may append searches: indices, not references, across the call)
@@ -318,6 +358,31 @@ void BlockSplitLz77Batch(const std::vector<const Lz77Store*>& stores, size_t max
       q.Advance(true);
     }
   }
+  if (trace) {
+    std::fprintf(stderr, "      block-split rounds (%zu sequences): %zu on the device (%zu block sizes, %.2f ms), %zu on the host (%zu split costs, %.2f ms)\n",
+                 ns, rounds_dev, n_dev, t_dev * 1e3, rounds_host, n_host, t_host * 1e3);
+  }
+  return true;
+}
+
+}  // namespace
+
+void BlockSplitLz77Batch(const std::vector<const Lz77Store*>& stores, size_t maxblocks,
+                         std::vector<std::vector<size_t>>* points, const CostBatchFn* device, size_t device_min) {
+  const size_t ns = stores.size();
+  points->assign(ns, {});
+  std::vector<SeqSplit> seq(ns);
+  for (size_t i = 0; i < ns; ++i) seq[i].Init(stores[i], stores[i]->size(), maxblocks, &(*points)[i]);
+  SplitRounds(seq, device, device_min);
+}
+
+bool BlockSplitSizesBatch(const std::vector<size_t>& sizes, size_t maxblocks, std::vector<std::vector<size_t>>* points,
+                          const CostBatchFn& device) {
+  const size_t ns = sizes.size();
+  points->assign(ns, {});
+  std::vector<SeqSplit> seq(ns);
+  for (size_t i = 0; i < ns; ++i) seq[i].Init(nullptr, sizes[i], maxblocks, &(*points)[i]);
+  return SplitRounds(seq, &device, 0);
 }
 
 std::vector<size_t> SplitPointsToBytes(const Lz77Store& lz77, const std::vector<size_t>& points,

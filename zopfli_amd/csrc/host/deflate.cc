@@ -23,6 +23,37 @@ bool BatchSplit(size_t np) {
   if (forced >= 0) return forced != 0;
   return np * 2 <= WideThreads();
 }
+// f-1 on the device (zmx_blockcost.h): the block sizes of the split search's rounds by zmx_block_costs.
+// ZOPFLI_AMD_DEVICE_SPLIT: 0 = the host evaluates everything, 2 = the device wherever there are `from` sequences, 1 (default)
+// = where that pays.  What the host's search costs grows with the symbols in use (the package-merge) and with the
+// sequence's length (rounds, and block sizes a round): on literal-heavy data — a symbol for nearly every byte: random or
+// encrypted bytes, 1 M symbols and 257 codes in use a master block — it is 14 000 block sizes of 35 us per shard of a 100 MB
+// call, 38 ms on the box's 16 CPUs beside the other shards' work, against 12 ms of device rounds (18 x 0.2 ms plus the
+// queueing behind the other contexts' kernels); on text (4 000 block sizes of ~10 us, seven rounds) the host's 4 ms beat
+// the device's 5 - 24 (profiles/r06_device_split.txt).  Hence: at least `from` sequences AND at least 0.45 symbols a byte.
+bool DeviceSplit(size_t nseq, size_t from_default, size_t symbols, size_t bytes) {
+  static const int on = [] { const char* e = std::getenv("ZOPFLI_AMD_DEVICE_SPLIT"); return e ? std::atoi(e) : 1; }();
+  static const long from_env = [] { const char* e = std::getenv("ZOPFLI_AMD_DEVICE_SPLIT_FROM"); return e ? std::atol(e) : -1L; }();
+  const size_t from = from_env >= 0 ? static_cast<size_t>(from_env) : from_default;
+  if (on == 0 || nseq < from || nseq == 0) return false;
+  return on >= 2 || 20 * symbols >= 9 * bytes;
+}
+size_t DeviceSplitMin() {
+  static const size_t v = [] { const char* e = std::getenv("ZOPFLI_AMD_DEVICE_SPLIT_MIN"); return e ? static_cast<size_t>(std::atoll(e)) : static_cast<size_t>(128); }();
+  return v;
+}
+struct CostStoresGuard {
+  zmx_ctx* ctx;
+  zmx_cost_stores* cs = nullptr;
+  ~CostStoresGuard() { if (cs) zmx_cost_stores_free(ctx, cs); }
+};
+// the evaluator BlockSplitLz77Batch calls (false = this round on the host: the two give the same integers)
+CostBatchFn DeviceCosts(zmx_ctx* ctx, zmx_cost_stores* cs) {
+  return [ctx, cs](const CostQuery* q, size_t n, double* cost) {
+    static_assert(sizeof(CostQuery) == 3 * sizeof(uint32_t), "zmx_block_costs takes the queries as triples");
+    return zmx_block_costs(ctx, cs, n, reinterpret_cast<const uint32_t*>(q), cost) == 0;
+  };
+}
 }  // namespace
 
 namespace {
@@ -154,11 +185,58 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
     if (rc) return rc;
     const double t0 = Now();
     std::atomic<uint64_t> ns_store{0}, ns_search{0};
-    if (BatchSplit(np)) {
+    bool dev_done = false;
+    size_t greedy_symbols = 0, part_bytes = 0;
+    for (size_t p = 0; p < np; ++p) { greedy_symbols += greedy[p].litlens.size(); part_bytes += parts[p].inend - parts[p].instart; }
+    if (DeviceSplit(np, 6, greedy_symbols, part_bytes)) {
+      // the greedy stores are on the device already (slot 0 of the master blocks' tables): every round of the search's
+      // block sizes there (zmx_block_costs), no host store at all — the split points' byte positions from one walk over
+      // the downloaded symbols
+      const double a = Now();
+      CostStoresGuard dev{ctx};
+      std::vector<size_t> first(np + 1), blk(np), nsym(np);
+      std::vector<int32_t> slot(np, 0);
+      for (size_t p = 0; p < np; ++p) { first[p] = p; blk[p] = p; nsym[p] = greedy[p].litlens.size(); }
+      first[np] = np;
+      if (zmx_cost_stores_create(ctx, split_tables, np, first.data(), blk.data(), slot.data(), nsym.data(), &dev.cs) == 0) {
+        const double b = Now();
+        std::vector<std::vector<size_t>> pts;
+        dev_done = BlockSplitSizesBatch(nsym, static_cast<size_t>(options.blocksplittingmax), &pts, DeviceCosts(ctx, dev.cs));
+        const double c = Now();
+        if (dev_done) {
+          ParallelForWide(np, [&](size_t p) {
+            // SplitPointsToBytes without a store: the bytes the symbols before each point stand for
+            split_bytes[p].clear();
+            size_t pos = parts[p].instart, i = 0;
+            const uint16_t* ll = greedy[p].litlens.data();
+            const uint16_t* dd = greedy[p].dists.data();
+            for (size_t pt : pts[p]) {
+              for (; i < pt; ++i) pos += dd[i] == 0 ? 1 : ll[i];
+              split_bytes[p].push_back(pos);
+            }
+            if (options.verbose) {    // blocksplitter.c:266-268, PrintBlockSplitPoints :148-180
+              std::string dec = "block split points: ", hex = "(hex:";
+              char buf[32];
+              for (size_t bp : split_bytes[p]) {
+                const int v = static_cast<int>(bp - parts[p].instart);
+                std::snprintf(buf, sizeof(buf), "%d ", v);
+                dec += buf;
+                std::snprintf(buf, sizeof(buf), " %x", v);
+                hex += buf;
+              }
+              st[p].log += dec + hex + ")\n";
+            }
+          });
+        }
+        if (TraceCallEnv()) std::fprintf(stderr, "    DeflateParts(%zu parts): first split on the device: sequences %.2f ms, rounds %.2f ms, points %.2f ms\n", np, (b - a) * 1e3, (c - b) * 1e3, (Now() - c) * 1e3);
+      }
+      if (!dev_done && TraceCallEnv()) std::fprintf(stderr, "    DeflateParts: no device block sizes (%s): the host evaluates\n", zmx_last_error());
+    }
+    if (dev_done) {
+    } else if (BatchSplit(np)) {
       // a few parts: all their searches advance together, round by round, on the whole pool (block_split.cc)
-      std::vector<Lz77Store> stores;
-      stores.reserve(np);
-      for (size_t p = 0; p < np; ++p) stores.emplace_back(StoreFromRun(greedy[p], parts[p].instart));
+      std::vector<Lz77Store> stores(np);
+      ParallelForWide(np, [&](size_t p) { stores[p] = StoreFromRun(greedy[p], parts[p].instart); });
       std::vector<const Lz77Store*> ptrs(np);
       for (size_t p = 0; p < np; ++p) ptrs[p] = &stores[p];
       std::vector<std::vector<size_t>> pts;
@@ -272,12 +350,39 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
   std::vector<std::vector<size_t>> pts2(np);
   std::vector<char> tried(np, 0);
   for (size_t p = 0; p < np; ++p) tried[p] = options.blocksplitting && st[p].blocks.size() - 1 > 1;
-  if (BatchSplit(np)) {
+  size_t ntried = 0, tried_symbols = 0, tried_bytes = 0;
+  for (size_t p = 0; p < np; ++p) {
+    if (!tried[p]) continue;
+    ++ntried;
+    tried_symbols += st[p].lz77.size();
+    tried_bytes += parts[p].inend - parts[p].instart;
+  }
+  // (the second try has fewer sequences — only the parts that were split — and as many rounds: from 24 sequences on)
+  const bool dev_split2 = device_encode && keep.tables != nullptr && DeviceSplit(ntried, 24, tried_symbols, tried_bytes);
+  if (BatchSplit(np) || dev_split2) {
     std::vector<const Lz77Store*> ptrs;
     std::vector<size_t> owner;
     for (size_t p = 0; p < np; ++p) if (tried[p]) { ptrs.push_back(&st[p].lz77); owner.push_back(p); }
     std::vector<std::vector<size_t>> got;
-    BlockSplitLz77Batch(ptrs, static_cast<size_t>(options.blocksplittingmax), &got);
+    CostStoresGuard dev{ctx};
+    CostBatchFn fn;
+    if (dev_split2 && !ptrs.empty()) {
+      // a part's optimal parse = the best stores of its blocks, one after the other, where they lie on the device
+      std::vector<size_t> first(owner.size() + 1, 0), blk, nsym;
+      std::vector<int32_t> slot;
+      for (size_t i = 0; i < owner.size(); ++i) {
+        const PartState& s = st[owner[i]];
+        for (size_t k = 0; k < s.blocks.size(); ++k) {
+          blk.push_back(s.first_block + k);
+          slot.push_back(keep.slot[s.first_block + k]);
+          nsym.push_back(keep.nsym[s.first_block + k]);
+        }
+        first[i + 1] = blk.size();
+      }
+      if (zmx_cost_stores_create(ctx, keep.tables, owner.size(), first.data(), blk.data(), slot.data(), nsym.data(), &dev.cs) == 0) fn = DeviceCosts(ctx, dev.cs);
+      else if (TraceCallEnv()) std::fprintf(stderr, "    DeflateParts: no device block sizes (%s): the host evaluates\n", zmx_last_error());
+    }
+    BlockSplitLz77Batch(ptrs, static_cast<size_t>(options.blocksplittingmax), &got, fn ? &fn : nullptr, DeviceSplitMin());
     for (size_t i = 0; i < owner.size(); ++i) pts2[owner[i]].swap(got[i]);
   } else {
     ParallelForWide(np, [&](size_t p) {

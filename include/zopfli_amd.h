@@ -294,7 +294,7 @@ int zmx_length_array_download(zmx_ctx* ctx, zmx_tables* tables, size_t block, ui
  * ZopfliCalculateBlockSizeAutoType value for value (tests/test_gpu_parity.py::test_block_costs).
  *
  * A zmx_cost_stores object is a set of symbol sequences ("stores", lz77.h:44-62) resident on the device with their
- * sampled prefix histograms (lz77.c:98-149's ll_counts / d_counts, here every 256 symbols):
+ * sampled prefix histograms (lz77.c:98-149's ll_counts / d_counts, here every 1024 symbols):
  *   zmx_cost_stores_create       sequence s = the concatenation of the device stores (block[p], slot[p], nsym[p]) of
  *                                `tables` for p in [piece_first[s], piece_first[s + 1]) — the greedy store of a master
  *                                block (blocksplitter.c:296), or the optimal parses of its blocks joined
@@ -310,6 +310,9 @@ int zmx_cost_stores_create_host(zmx_ctx* ctx, size_t nstores, const uint16_t* co
                                 const uint16_t* const* dists, const size_t* nsym, zmx_cost_stores** out);
 void zmx_cost_stores_free(zmx_ctx* ctx, zmx_cost_stores* stores);
 int zmx_block_costs(zmx_ctx* ctx, zmx_cost_stores* stores, size_t n, const uint32_t* ranges, double* cost);
+/* ZopfliLZ77GetByteRange (lz77.c:160-166) from the start of a sequence: bytes[i] = the input bytes that symbols
+ * [0, pairs[2 i + 1]) of sequence pairs[2 i] stand for — where a split point lies (blocksplitter.c:303-314). */
+int zmx_cost_positions(zmx_ctx* ctx, zmx_cost_stores* stores, size_t n, const uint32_t* pairs, uint64_t* bytes);
 
 /* -------- whole-stream entry points on a resident input (bench, multi-GPU) */
 

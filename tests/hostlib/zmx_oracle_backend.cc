@@ -301,6 +301,13 @@ int zmx_cost_stores_create_host(zmx_ctx*, size_t nstores, const uint16_t* const*
   return 0;
 }
 void zmx_cost_stores_free(zmx_ctx*, zmx_cost_stores* s) { delete s; }
+int zmx_cost_positions(zmx_ctx*, zmx_cost_stores* s, size_t n, const uint32_t* pairs, uint64_t* bytes) {
+  for (size_t i = 0; i < n; ++i) {
+    if (pairs[2 * i] >= s->stores.size() || pairs[2 * i + 1] > s->stores[pairs[2 * i]].size()) { g_err = "zmx_cost_positions: an index outside its sequence"; return -1; }
+    bytes[i] = s->stores[pairs[2 * i]].ByteRange(0, pairs[2 * i + 1]);
+  }
+  return 0;
+}
 int zmx_block_costs(zmx_ctx*, zmx_cost_stores* s, size_t n, const uint32_t* r, double* cost) {
   for (size_t i = 0; i < n; ++i) {
     if (r[3 * i] >= s->stores.size() || r[3 * i + 1] > r[3 * i + 2] || r[3 * i + 2] > s->stores[r[3 * i]].size()) { g_err = "zmx_block_costs: a range outside its sequence"; return -1; }

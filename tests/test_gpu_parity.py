@@ -1071,6 +1071,12 @@ def test_block_costs_from_device_stores(gpu_ctx):
                 ranges += [(q, 0, m)] + [(q,) + tuple(sorted(rng.integers(0, m + 1, 2).tolist())) for _ in range(60)]
             ranges = [r for r in ranges if r[1] < r[2]]
             assert np.array_equal(dev.block_costs(ranges), up.block_costs(ranges))
+            # zmx_cost_positions == ZopfliLZ77GetByteRange(0, index) (lz77.c:160-166): the running sum of the symbols' lengths
+            span = np.where(joined[1] == 0, 1, joined[0]).astype(np.uint64)
+            csum = np.concatenate([[0], np.cumsum(span)])
+            idx = [0, 1, 1023, 1024, 1025, 2048, dev.sizes[1] - 1, dev.sizes[1]] + rng.integers(0, dev.sizes[1] + 1, 40).tolist()
+            got = dev.positions([(1, int(i)) for i in idx])
+            assert got.tolist() == [int(csum[int(i)]) for i in idx]
         finally:
             dev.free()
             up.free()

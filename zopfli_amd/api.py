@@ -391,6 +391,18 @@ class CostStores:
                            out.ctypes.data_as(ctypes.c_void_p)), "zmx_block_costs")
         return out
 
+    def positions(self, pairs):
+        """pairs = [(sequence, index)] -> the bytes that symbols [0, index) of the sequence stand for (zmx_cost_positions)."""
+        import numpy as np
+        q = np.ascontiguousarray(np.asarray(pairs, dtype=np.uint32).reshape(-1, 2))
+        out = np.zeros(len(q), dtype=np.uint64)
+        fn = self.ctx.lib.zmx_cost_positions
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+        self.ctx._check(fn(self.ctx.handle, self.handle, len(q), q.ctypes.data_as(ctypes.c_void_p),
+                           out.ctypes.data_as(ctypes.c_void_p)), "zmx_cost_positions")
+        return out
+
     def free(self):
         if self.handle:
             fn = self.ctx.lib.zmx_cost_stores_free

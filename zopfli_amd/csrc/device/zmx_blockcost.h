@@ -20,7 +20,7 @@
 //   data size        CalculateBlockSymbolSizeGivenCounts (deflate.c:383-405)
 #pragma once
 
-#define BC_S 256u            // symbols between two samples of the prefix counts
+#define BC_S 1024u           // symbols between two samples of the prefix counts (a sample is 1.3 KB: at 256 a million literals had 5 MB of them)
 #define BC_SW 324u           // words of a sample: 288 litlen counts, 32 distance counts, [320] the bytes covered, 3 of padding
 #define BC_BYTES 320u
 #define BC_WAVES 4u          // block sizes per workgroup (a wave each)
@@ -37,6 +37,8 @@ struct CostPiece {           // k_cost_gather: a store of a table set that becom
   u32 n, pad;
 };
 struct CostEval { u32 store, lstart, lend, pad; };
+
+__device__ __forceinline__ u32 bc_wave_sum_early(u32 v) { return rdlane_u32(wave_scan_add(v), 63); }
 
 // ---- the sequences: pieces copied into place, counts per chunk of BC_S symbols, prefix sums over the chunks
 __global__ __launch_bounds__(256) void k_cost_gather(const CostPiece* __restrict__ pieces) {
@@ -87,6 +89,22 @@ __global__ __launch_bounds__(384) void k_cost_prefix(const CostStoreDev* __restr
     for (int u = 0; u < 8; ++u) { acc += v[u]; S.samples[(u64)(k + u) * BC_SW + w] = acc; }
   }
   for (; k < S.nsamples; ++k) { acc += S.samples[(u64)k * BC_SW + w]; S.samples[(u64)k * BC_SW + w] = acc; }
+}
+
+// ZopfliLZ77GetByteRange (lz77.c:160-166) from the start of a sequence: out[q] = the bytes symbols [0, index) stand for —
+// where a split point lies in the input (blocksplitter.c:303-314).  One wave per query.
+struct CostPosQuery { u32 store, index; };
+__global__ __launch_bounds__(64) void k_cost_positions(const CostStoreDev* __restrict__ stores, const CostPosQuery* __restrict__ q, u64* __restrict__ out) {
+  const CostPosQuery Q = q[blockIdx.x];
+  const CostStoreDev S = stores[Q.store];
+  const u32 lane = threadIdx.x, k = Q.index / BC_S;
+  u32 bytes = 0;
+  for (u32 i = k * BC_S + lane; i < Q.index; i += 64u) {
+    const u32 v = S.sym[i];
+    bytes += (v >> 16) ? (v & 0xffffu) : 1u;
+  }
+  bytes = bc_wave_sum_early(bytes);
+  if (lane == 0) out[blockIdx.x] = (u64)S.samples[(u64)k * BC_SW + BC_BYTES] + bytes;
 }
 
 // ---- one wave's LDS

@@ -2619,6 +2619,28 @@ int zmx_cost_stores_create_host(zmx_ctx* c, size_t nstores, const uint16_t* cons
   return 0;
 }
 
+int zmx_cost_positions(zmx_ctx* c, zmx_cost_stores* s, size_t n, const uint32_t* pairs, uint64_t* bytes) {
+  if (n == 0) return 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (pairs[2 * i] >= s->n || pairs[2 * i + 1] > s->desc[pairs[2 * i]].n) return FailMsg("zmx_cost_positions: an index outside its sequence");
+  }
+  DeviceGuard dev_guard(c->device);
+  HIPCHK(dev_guard.err);
+  const hipStream_t cs = c->stream;   // (a stream of its own at the highest priority was measured: no shorter rounds — profiles/r06_device_split.txt)
+  PoolScope tmp(c);
+  CostPosQuery* d_q = nullptr;
+  u64* d_out = nullptr;
+  HIPCHK(tmp.AllocT(&d_q, n, "cost_pos_q"));
+  HIPCHK(tmp.AllocT(&d_out, n, "cost_pos_out"));
+  static_assert(sizeof(CostPosQuery) == 2 * sizeof(uint32_t), "the queries come as pairs");
+  HIPCHK(hipMemcpyAsync(d_q, pairs, n * sizeof(CostPosQuery), hipMemcpyHostToDevice, cs));
+  hipLaunchKernelGGL(k_cost_positions, dim3(static_cast<unsigned>(n)), dim3(64), 0, cs, s->d_desc, d_q, d_out);
+  KCHK(c, "k_cost_positions");
+  HIPCHK(hipMemcpyAsync(bytes, d_out, n * sizeof(u64), hipMemcpyDeviceToHost, cs));
+  HIPCHK(hipStreamSynchronize(cs));
+  return 0;
+}
+
 void zmx_cost_stores_free(zmx_ctx* c, zmx_cost_stores* s) {
   if (!s) return;
   DeviceGuard dev_guard(c->device);
@@ -2633,6 +2655,7 @@ int zmx_block_costs(zmx_ctx* c, zmx_cost_stores* s, size_t n, const uint32_t* ra
   }
   DeviceGuard dev_guard(c->device);
   HIPCHK(dev_guard.err);
+  const hipStream_t cs = c->stream;   // (a stream of its own at the highest priority was measured: no shorter rounds — profiles/r06_device_split.txt)
   if (n > s->eval_cap) {
     const size_t cap = n + n / 2 + 256;
     PoolFree(c, s->d_evals); s->d_evals = nullptr;
@@ -2647,7 +2670,7 @@ int zmx_block_costs(zmx_ctx* c, zmx_cost_stores* s, size_t n, const uint32_t* ra
     s->eval_cap = cap;
   }
   for (size_t i = 0; i < n; ++i) s->h_evals[i] = {ranges[3 * i], ranges[3 * i + 1], ranges[3 * i + 2], 0u};
-  HIPCHK(hipMemcpyAsync(s->d_evals, s->h_evals, n * sizeof(CostEval), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(s->d_evals, s->h_evals, n * sizeof(CostEval), hipMemcpyHostToDevice, cs));
   BlockCostParams P;
   P.stores = s->d_desc;
   P.evals = s->d_evals;
@@ -2658,13 +2681,13 @@ int zmx_block_costs(zmx_ctx* c, zmx_cost_stores* s, size_t n, const uint32_t* ra
   PoolScope tmp(c);
   if (bc_prof) {
     HIPCHK(tmp.AllocT(&P.prof, 16, "bc_prof"));
-    HIPCHK(hipMemsetAsync(P.prof, 0, 16 * sizeof(u64), c->stream));
+    HIPCHK(hipMemsetAsync(P.prof, 0, 16 * sizeof(u64), cs));
   }
   const auto t0_ = std::chrono::steady_clock::now();
-  hipLaunchKernelGGL(k_block_cost, dim3(static_cast<unsigned>((n + BC_WAVES / 2 - 1) / (BC_WAVES / 2))), dim3(64 * BC_WAVES), 0, c->stream, P);
+  hipLaunchKernelGGL(k_block_cost, dim3(static_cast<unsigned>((n + BC_WAVES / 2 - 1) / (BC_WAVES / 2))), dim3(64 * BC_WAVES), 0, cs, P);
   KCHK(c, "k_block_cost");
-  HIPCHK(hipMemcpyAsync(s->h_out, s->d_out, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(hipMemcpyAsync(s->h_out, s->d_out, n * sizeof(double), hipMemcpyDeviceToHost, cs));
+  HIPCHK(hipStreamSynchronize(cs));
   std::memcpy(cost, s->h_out, n * sizeof(double));
   if (bc_prof) {
     u64 pr[16];

@@ -180,23 +180,26 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
     std::vector<zmx_block> ranges(np);
     for (size_t p = 0; p < np; ++p) ranges[p] = {parts[p].instart, parts[p].inend};
     std::vector<SymbolRun> greedy;
+    std::vector<uint32_t> greedy_nsym;
     const double tg0 = Now();
-    rc = Lz77GreedyBatch(ctx, ranges, &greedy, &split_tables);
+    // (the symbols stay on the device until somebody wants them on the host: with the search's block sizes computed there
+    //  nobody does — a shard of incompressible data is 130 MB of them)
+    rc = Lz77GreedyBatch(ctx, ranges, &greedy, &split_tables, &greedy_nsym, DeviceSplit(np, 6, 1, 1));
     if (rc) return rc;
     const double t0 = Now();
     std::atomic<uint64_t> ns_store{0}, ns_search{0};
     bool dev_done = false;
+    bool have_symbols = !DeviceSplit(np, 6, 1, 1);
     size_t greedy_symbols = 0, part_bytes = 0;
-    for (size_t p = 0; p < np; ++p) { greedy_symbols += greedy[p].litlens.size(); part_bytes += parts[p].inend - parts[p].instart; }
+    for (size_t p = 0; p < np; ++p) { greedy_symbols += greedy_nsym[p]; part_bytes += parts[p].inend - parts[p].instart; }
     if (DeviceSplit(np, 6, greedy_symbols, part_bytes)) {
       // the greedy stores are on the device already (slot 0 of the master blocks' tables): every round of the search's
-      // block sizes there (zmx_block_costs), no host store at all — the split points' byte positions from one walk over
-      // the downloaded symbols
+      // block sizes there (zmx_block_costs), no host store at all — and the split points' byte positions from there too
       const double a = Now();
       CostStoresGuard dev{ctx};
       std::vector<size_t> first(np + 1), blk(np), nsym(np);
       std::vector<int32_t> slot(np, 0);
-      for (size_t p = 0; p < np; ++p) { first[p] = p; blk[p] = p; nsym[p] = greedy[p].litlens.size(); }
+      for (size_t p = 0; p < np; ++p) { first[p] = p; blk[p] = p; nsym[p] = greedy_nsym[p]; }
       first[np] = np;
       if (zmx_cost_stores_create(ctx, split_tables, np, first.data(), blk.data(), slot.data(), nsym.data(), &dev.cs) == 0) {
         const double b = Now();
@@ -204,16 +207,15 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
         dev_done = BlockSplitSizesBatch(nsym, static_cast<size_t>(options.blocksplittingmax), &pts, DeviceCosts(ctx, dev.cs));
         const double c = Now();
         if (dev_done) {
-          ParallelForWide(np, [&](size_t p) {
-            // SplitPointsToBytes without a store: the bytes the symbols before each point stand for
+          // SplitPointsToBytes without a store: the bytes the symbols before each point stand for (zmx_cost_positions)
+          std::vector<uint32_t> pairs;
+          for (size_t p = 0; p < np; ++p) for (size_t pt : pts[p]) { pairs.push_back(static_cast<uint32_t>(p)); pairs.push_back(static_cast<uint32_t>(pt)); }
+          std::vector<uint64_t> bytes(pairs.size() / 2);
+          dev_done = zmx_cost_positions(ctx, dev.cs, bytes.size(), pairs.data(), bytes.data()) == 0;
+          size_t k = 0;
+          for (size_t p = 0; p < np && dev_done; ++p) {
             split_bytes[p].clear();
-            size_t pos = parts[p].instart, i = 0;
-            const uint16_t* ll = greedy[p].litlens.data();
-            const uint16_t* dd = greedy[p].dists.data();
-            for (size_t pt : pts[p]) {
-              for (; i < pt; ++i) pos += dd[i] == 0 ? 1 : ll[i];
-              split_bytes[p].push_back(pos);
-            }
+            for (size_t i = 0; i < pts[p].size(); ++i) split_bytes[p].push_back(parts[p].instart + bytes[k++]);
             if (options.verbose) {    // blocksplitter.c:266-268, PrintBlockSplitPoints :148-180
               std::string dec = "block split points: ", hex = "(hex:";
               char buf[32];
@@ -226,11 +228,15 @@ int DeflateParts(zmx_ctx* ctx, const ZopfliOptions& options, int btype, const st
               }
               st[p].log += dec + hex + ")\n";
             }
-          });
+          }
         }
         if (TraceCallEnv()) std::fprintf(stderr, "    DeflateParts(%zu parts): first split on the device: sequences %.2f ms, rounds %.2f ms, points %.2f ms\n", np, (b - a) * 1e3, (c - b) * 1e3, (Now() - c) * 1e3);
       }
       if (!dev_done && TraceCallEnv()) std::fprintf(stderr, "    DeflateParts: no device block sizes (%s): the host evaluates\n", zmx_last_error());
+    }
+    if (!dev_done && !have_symbols) {
+      rc = Lz77GreedyDownload(ctx, split_tables, greedy_nsym, &greedy);
+      if (rc) return rc;
     }
     if (dev_done) {
     } else if (BatchSplit(np)) {

@@ -143,8 +143,16 @@ Timing& ThreadTiming() {
   return t;
 }
 
+int Lz77GreedyDownload(zmx_ctx* ctx, zmx_tables* tables, const std::vector<uint32_t>& nsym, std::vector<SymbolRun>* out) {
+  const double t1 = Now();
+  out->assign(nsym.size(), SymbolRun());
+  const int rc = DownloadAll(ctx, tables, std::vector<int32_t>(nsym.size(), 0), nsym, out);
+  ThreadTiming().greedy += Now() - t1;
+  return rc;
+}
+
 int Lz77GreedyBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks, std::vector<SymbolRun>* out,
-                    zmx_tables** keep) {
+                    zmx_tables** keep, std::vector<uint32_t>* nsym_out, bool defer_download) {
   const size_t nb = blocks.size();
   out->assign(nb, SymbolRun());
   if (keep) *keep = nullptr;
@@ -158,7 +166,8 @@ int Lz77GreedyBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks, std::vec
   std::vector<uint32_t> nsym(nb), hist(nb * ZMX_HIST);
   rc = zmx_lz77_greedy(ctx, t, 0, nsym.data(), hist.data());
   if (!rc && VerifyWanted()) rc = VerifyAll(ctx, t, std::vector<int32_t>(nb, 0), nsym);
-  if (!rc) rc = DownloadAll(ctx, t, std::vector<int32_t>(nb, 0), nsym, out);
+  if (!rc && !(defer_download && nsym_out)) rc = DownloadAll(ctx, t, std::vector<int32_t>(nb, 0), nsym, out);
+  if (nsym_out) *nsym_out = nsym;
   ThreadTiming().greedy += Now() - t1;
   if (keep && !rc) *keep = t;
   else zmx_tables_free(ctx, t);

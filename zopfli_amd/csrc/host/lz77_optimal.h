@@ -29,8 +29,11 @@ Timing& ThreadTiming();
 
 // ZopfliLZ77Greedy (lz77.c:544) for each block.  With `keep`, the device tables of the blocks are
 // handed to the caller (to be passed to Lz77OptimalBatch or freed with zmx_tables_free).
+// With `nsym` and `defer_download`, the symbols stay on the device (only their number comes back): Lz77GreedyDownload
+// fetches them later if somebody needs them on the host after all.
 int Lz77GreedyBatch(zmx_ctx* ctx, const std::vector<zmx_block>& blocks, std::vector<SymbolRun>* out,
-                    zmx_tables** keep = nullptr);
+                    zmx_tables** keep = nullptr, std::vector<uint32_t>* nsym = nullptr, bool defer_download = false);
+int Lz77GreedyDownload(zmx_ctx* ctx, zmx_tables* tables, const std::vector<uint32_t>& nsym, std::vector<SymbolRun>* out);
 
 // ZopfliLZ77Optimal (squeeze.c:446) for each block: best of `numiterations`
 // cost-model iterations seeded by a greedy parse.  `parent` (optional, consumed): tables of blocks

@@ -1082,3 +1082,18 @@ def test_block_costs_from_device_stores(gpu_ctx):
             up.free()
     finally:
         t.free()
+
+
+@pytest.mark.gpu
+def test_split_search_on_the_device_fuzz():
+    """f-1 end to end with EVERY round of both split searches on the device (tools/fuzz_split.py: k_block_cost forced from one
+    sequence on, no host rounds): streams glued from every class, copies and noise, random options and containers — the
+    real reference's bytes."""
+    import subprocess
+    import sys
+    if not ol.have_ref():
+        pytest.skip("oracle/_ref is not built")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_split.py"), "10", "3"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, FUZZ_SIZES="9000,70000,300000,1000001,2300000"))
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert "10 of 10 identical" in r.stdout

@@ -380,6 +380,10 @@ int zmx_last_timing(double* out8);
  * zmx_deflate_range call started: [0] k_wtab + k_badscan (the run's weight tables) [1] the chain kernels
  * [2] k_trace_* (exits + link + emit) [3] squeeze runs launched. */
 int zmx_last_kernel_timing(double* out4);
+/* The phase times of the squeeze runs (above; zmx_last_timing's dp_kernel) cost four event records and three readings a
+ * run, a third of a run's runtime calls: they are taken only when asked for — this call, ZOPFLI_AMD_KERNEL_TIMING=1 or
+ * ZOPFLI_AMD_PROF.  (The match-table times of zmx_last_match_timing are always taken: once per table build.) */
+void zmx_set_kernel_timing(int on);
 
 /* Host tail of the last call on this thread, seconds: [0] best LZ77 stores device -> host
  * [1] chunk serialisation (zmx_deflate_range). */

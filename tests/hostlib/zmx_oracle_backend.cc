@@ -48,6 +48,7 @@ int zmx_device_count(void) {
 }
 const char* zmx_last_error(void) { return g_err.c_str(); }
 int zmx_has_experiments(void) { return 0; }
+void zmx_set_kernel_timing(int) {}
 int zmx_last_error_class(void) { return g_err.empty() ? ZMX_ERR_NONE : ZMX_ERR_DEVICE; }
 void zmx_internal_set_error(const char* msg) { g_err = msg; }
 

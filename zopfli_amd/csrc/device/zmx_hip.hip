@@ -493,6 +493,22 @@ int zmx_device_count(void) {
 
 const char* zmx_last_error(void) { return g_err.c_str(); }
 int zmx_last_error_class(void) { return g_err_class; }
+// The phase times of a squeeze run (k_wtab / the chain / the trace: zmx_last_kernel_timing, zmx_last_timing's dp_kernel)
+// are four event records and three readings a run — seven of a run's ~22 runtime calls, which is what sixteen concurrent
+// callers of small files queue for.  Off unless somebody asks: ZOPFLI_AMD_KERNEL_TIMING=1, ZOPFLI_AMD_PROF, or this call
+// (bench.py, tools/latency.py and the tests' harness do).
+static std::atomic<int> g_kernel_timing{-1};
+static bool KernelTiming() {
+  int v = g_kernel_timing.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = std::getenv("ZOPFLI_AMD_KERNEL_TIMING");
+    v = (e ? std::atoi(e) != 0 : std::getenv("ZOPFLI_AMD_PROF") != nullptr) ? 1 : 0;
+    g_kernel_timing.store(v, std::memory_order_relaxed);
+  }
+  return v != 0;
+}
+void zmx_set_kernel_timing(int on) { g_kernel_timing.store(on ? 1 : 0, std::memory_order_relaxed); }
+
 int zmx_has_experiments(void) {
 #ifdef ZMX_EXPERIMENTS
   return 1;
@@ -1849,19 +1865,20 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   tp.block0 = 0;
   tp.seg0 = 0;
   double ksec[3] = {0, 0, 0};
+  const bool timing = KernelTiming();
   const dim3 dpdim(64 * (D3_NB + 2));
   {
     const unsigned nblk = static_cast<unsigned>(nb);
     const unsigned tiles = t->tile_off[nb];
     const unsigned ntask = t->task_off[nb];
-    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    if (timing) HIPCHK(hipEventRecord(c->ev[0], c->stream));
     // the run's weights per block, and (rarely) the positions that own an edge below mincost
     hipLaunchKernelGGL(k_wtab, dim3(nblk), dim3(256), 0, c->stream, wp);
     KCHK(c, "k_wtab");
     if (tiles && scan_bad) hipLaunchKernelGGL(k_badscan, dim3(tiles), dim3(256), 0, c->stream, bp);
     KCHK(c, "k_badscan");
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    if (timing) HIPCHK(hipEventRecord(c->ev[1], c->stream));
     // the chain: every task speculatively on all CUs (four tasks of a block per workgroup, the workgroups
     // with a head first), then the per-block walk that accepts or re-runs
     {
@@ -1933,7 +1950,7 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
       KCHK(c, "k_dp4_fix");
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c->ev[2], c->stream));
+    if (timing) HIPCHK(hipEventRecord(c->ev[2], c->stream));
     const unsigned nseg = t->seg_off[nb];
     if (nseg) hipLaunchKernelGGL(k_trace_exits, dim3(nseg), dim3(TS_THREADS), 0, c->stream, tp);
     KCHK(c, "k_trace_exits");
@@ -1942,7 +1959,7 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
     if (nseg) hipLaunchKernelGGL(k_trace_emit, dim3(nseg), dim3(64), 0, c->stream, tp);
     KCHK(c, "k_trace_emit");
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c->ev[3], c->stream));
+    if (timing) HIPCHK(hipEventRecord(c->ev[3], c->stream));
   }
   // ONE host round trip per run: the results travel behind the last kernel, the host waits for the copy and reads the
   // phase times then (waiting for ev[3] first and only then asking for the copy was two).  The task statistics are
@@ -1950,7 +1967,7 @@ int zmx_squeeze_run(zmx_ctx* c, zmx_tables* t, const double* cost, const double*
   u32 segstats[8];
   HIPCHK(hipMemcpyAsync(t->h_runout, t->d_runout, t->runout_bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < 3 && timing; ++i) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
     ksec[i] += ms * 1e-3;

@@ -6,6 +6,7 @@
 // against the real reference on machines without a GPU.  The product library
 // libzopfli_amd.so never links this file: its zmx_* symbols come from the HIP
 // device layer only.
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -310,6 +311,10 @@ int zmx_cost_positions(zmx_ctx*, zmx_cost_stores* s, size_t n, const uint32_t* p
   return 0;
 }
 int zmx_block_costs(zmx_ctx*, zmx_cost_stores* s, size_t n, const uint32_t* r, double* cost) {
+  // (ZOPFLI_HOSTTEST_COSTS_FAIL_AFTER=k: the k-th call and every later one fails — the host's fall-back in mid-search)
+  static const long fail_after = [] { const char* e = std::getenv("ZOPFLI_HOSTTEST_COSTS_FAIL_AFTER"); return e ? std::atol(e) : -1L; }();
+  static std::atomic<long> calls{0};
+  if (fail_after >= 0 && calls.fetch_add(1) >= fail_after) { g_err = "zmx_block_costs: injected failure"; return -1; }
   for (size_t i = 0; i < n; ++i) {
     if (r[3 * i] >= s->stores.size() || r[3 * i + 1] > r[3 * i + 2] || r[3 * i + 2] > s->stores[r[3 * i]].size()) { g_err = "zmx_block_costs: a range outside its sequence"; return -1; }
     cost[i] = zamd::CalculateBlockSizeAutoType(s->stores[r[3 * i]], r[3 * i + 1], r[3 * i + 2]);

@@ -507,12 +507,16 @@ def test_device_split_path_of_the_host_code():
     mine = body + "out = api.compress(data, 0, ZopfliOptions(2, 1, 15, 1, 0), lib=ol.hosttest_library())\nprint(hashlib.sha256(out).hexdigest())\n"
     theirs = body + "out = ol.ref_compress(data, 0, 2, 1, 15, 1, 0)\nprint(hashlib.sha256(out).hexdigest())\n"
     runs = []
-    for code, extra in ((mine, {"ZOPFLI_AMD_DEVICE_SPLIT": "2", "ZOPFLI_AMD_DEVICE_SPLIT_FROM": "1", "ZOPFLI_AMD_TRACE_CALL": "1"}),
-                        (mine, {"ZOPFLI_AMD_DEVICE_SPLIT": "0"}), (theirs, {})):
+    forced = {"ZOPFLI_AMD_DEVICE_SPLIT": "2", "ZOPFLI_AMD_DEVICE_SPLIT_FROM": "1", "ZOPFLI_AMD_TRACE_CALL": "1"}
+    for code, extra in ((mine, forced), (mine, {"ZOPFLI_AMD_DEVICE_SPLIT": "0"}), (theirs, {}),
+                        # the device's answers stop coming in mid-search (the 4th round on): the first split falls back to the
+                        # host's search on the downloaded symbols, the second split's later rounds to the host's pool
+                        (mine, dict(forced, ZOPFLI_HOSTTEST_COSTS_FAIL_AFTER="3"))):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=1200)
         assert r.returncode == 0, r.stderr[-2000:]
         runs.append((r.stdout.split()[-1], r.stderr))
     assert "first split on the device" in runs[0][1] and "on the device (" in runs[0][1]
-    assert runs[0][0] == runs[1][0] == runs[2][0]
+    assert runs[0][0] == runs[1][0] == runs[2][0] == runs[3][0]
+    assert "no device block sizes" in runs[3][1]
     lines = [[l for l in t.splitlines() if l.startswith("block split points")] for _, t in runs]
-    assert lines[0] == lines[1] == lines[2] and len(lines[2]) >= 3
+    assert lines[0] == lines[1] == lines[2] == lines[3] and len(lines[2]) >= 3

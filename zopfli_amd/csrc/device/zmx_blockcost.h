@@ -2,8 +2,9 @@
 // sequences — what every probe of the block-split search costs (blocksplitter.c:103-135: EstimateCost, SplitCost; two
 // block sizes a probe, ~800 probes a master block of incompressible data, 30 - 40 us each on a host core).
 //
-// One WAVE per block size.  Nothing here is floating point: the stored, fixed and dynamic sizes are integers (the
-// reference returns them as doubles), so "the same result" is equality of integers.
+// TWO WAVES per block size (k_block_cost: one prices the counts as they are, one the smoothed counts).  Nothing here is
+// floating point: the stored, fixed and dynamic sizes are integers (the reference returns them as doubles), so "the same
+// result" is equality of integers.
 //
 //   histogram        ZopfliLZ77GetHistogram (lz77.c:189-222): prefix counts sampled every BC_S symbols (k_cost_chunks +
 //                    k_cost_prefix, once per sequence) + the symbols between the range's ends and their samples
@@ -15,15 +16,17 @@
 //                    2n - 2 items of the top list (a leaf's length = the number of lists it is active in).
 //                    tools/models/pm_levels_model.cc checks this formulation against the host's boundary package-merge.
 //   tree size        CalculateTreeSize (deflate.c:277-291): EncodeTree's eight ways of using the repeat codes 16 / 17 / 18
-//                    (:105-249), each a 19-symbol code of at most 7 bits — eight lanes, a lane each, serial
-//   RLE smoothing    OptimizeHuffmanForRle (deflate.c:413-491) + TryOptimizeHuffmanForRle (:525-566): one lane per alphabet
+//                    (:105-249), each a 19-symbol code of at most 7 bits — the eight package-merges side by side
+//   RLE smoothing    OptimizeHuffmanForRle (deflate.c:413-491) + TryOptimizeHuffmanForRle (:525-566): by the whole wave
+//                    (frozen-run masks, next-break pointers, jump tables over the breaks the walk visits;
+//                    tools/models/smooth_model.cc)
 //   data size        CalculateBlockSymbolSizeGivenCounts (deflate.c:383-405)
 #pragma once
 
 #define BC_S 1024u           // symbols between two samples of the prefix counts (a sample is 1.3 KB: at 256 a million literals had 5 MB of them)
 #define BC_SW 324u           // words of a sample: 288 litlen counts, 32 distance counts, [320] the bytes covered, 3 of padding
 #define BC_BYTES 320u
-#define BC_WAVES 4u          // block sizes per workgroup (a wave each)
+#define BC_WAVES 4u          // waves per workgroup: two block sizes, two waves each
 
 struct CostStoreDev {        // one symbol sequence (ZopfliLZ77Store: litlen | dist << 16 per symbol)
   const u32* sym;
